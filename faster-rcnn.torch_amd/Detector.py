@@ -1,0 +1,122 @@
+"""Detector -- host-side mirror of Detector.lua.  detect(input) keeps the reference's pipeline and
+thresholds (p > 0.95, NMS 0.25, class != background and p > 0.2, per-class NMS 0.1) but the 26 544
+iteration Lua loop of Detector.lua:39-66 is one scan+compaction kernel (frcnn_rpn_scan), the per-ROI
+pooling loop (:94-98) one batched kernel, and both NMS passes run on the device.  Note that both NMS
+calls of the reference pass a tensor as `scores`, which nms.lua:37-43 ignores: boxes are processed
+by descending max-y.  That behaviour is reproduced."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .Anchors import Anchors
+from .Localizer import Localizer
+from .Rect import Rect
+from .nms import nms
+from .objective import roi_window
+from .tensor import DeviceTensor, ptr, stream_ptr, to_device
+
+MAX_MATCHES = 32768
+
+
+class Detector(object):
+    def __init__(self, model):  # Detector.lua:8-15
+        self.model = model
+        cfg = model["cfg"]
+        self.anchors = Anchors(model["pnet"], cfg["scales"])
+        self.localizer = Localizer(model["pnet"].outnode.children[-1])
+        self._aw = DeviceTensor.from_numpy(self.anchors.w)
+        self._ah = DeviceTensor.from_numpy(self.anchors.h)
+        self._bufs = {}
+        self.verbose = False
+
+    def _buf(self, name, shape, dtype=np.float32):
+        need = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < need:
+            b = DeviceTensor.empty((max(need, 256),), np.uint8)
+            self._bufs[name] = b
+        return DeviceTensor(b.ptr, shape, dtype, owner=b)
+
+    def scan(self, outputs, img_w, img_h, threshold=0.95):
+        """Detector.lua:39-66 on device -> dict(p, idx, rect, box(dev), n)."""
+        Hs = (C.c_int * 4)(*[outputs[i].shape[1] for i in range(4)])
+        Ws = (C.c_int * 4)(*[outputs[i].shape[2] for i in range(4)])
+        maps = (C.c_void_p * 4)(*[outputs[i].ptr for i in range(4)])
+        wsb = _lib.load().frcnn_rpn_scan_workspace_bytes(Hs, Ws)
+        ws = self._buf("scan_ws", (wsb,), np.uint8)
+        cap = MAX_MATCHES
+        mp = self._buf("match_p", (cap,)); mi = self._buf("match_idx", (cap, 4), np.int32)
+        mr = self._buf("match_rect", (cap, 4), np.float64); mb = self._buf("match_box", (cap, 4))
+        cnt = self._buf("count", (1,), np.int32)
+        _lib.call("frcnn_rpn_scan", maps, Hs, Ws, ptr(self._aw), ptr(self._ah), float(img_w), float(img_h),
+                  float(threshold), cap, ptr(mp), ptr(mi), ptr(mr), ptr(mb), ptr(cnt), ptr(ws), wsb, stream_ptr())
+        n = min(int(cnt.numpy()[0]), cap)
+        return dict(n=n, p=DeviceTensor(mp.ptr, (n,), np.float32, owner=mp),
+                    idx=DeviceTensor(mi.ptr, (n, 4), np.int32, owner=mi),
+                    rect=DeviceTensor(mr.ptr, (n, 4), np.float64, owner=mr),
+                    box=DeviceTensor(mb.ptr, (n, 4), np.float32, owner=mb))
+
+    def detect(self, input):  # Detector.lua:17-141
+        model = self.model
+        cfg = model["cfg"]
+        pnet, cnet = model["pnet"], model["cnet"]
+        kh, kw = cfg["roi_pooling"]["kh"], cfg["roi_pooling"]["kw"]
+        bgclass = cfg["class_count"] + 1
+        ncls = cfg["class_count"] + 1
+        planes = model["layers"][-1]["filters"]
+        s = stream_ptr()
+
+        inp = to_device(input)
+        _, H, W = inp.shape
+        pnet.evaluate()  # :31
+        outputs = pnet.forward(inp)  # :33
+        m = self.scan(outputs, W, H)  # :39-66
+        self.last_scan = m
+        winners = []
+        if m["n"] == 0:  # :71
+            return winners
+        # NON-MAXIMUM SUPPRESSION (:74-85); the score tensor is ignored by nms.lua -> key = max-y
+        pick = nms(m["box"], 0.25, m["p"])
+        rect_all = m["rect"].numpy(); p_all = m["p"].numpy(); idx_all = m["idx"].numpy()
+        cand = [int(i) - 1 for i in pick]
+        self.last_pick = pick
+        if self.verbose:
+            print("candidates: %d" % len(cand))
+        # REGION CLASSIFICATION (:90-101)
+        cnet.evaluate()
+        fm = outputs[-1]
+        fmC, fmH, fmW = fm.shape
+        R = len(cand)
+        rects = [Rect(*rect_all[i]) for i in cand]
+        wins = np.array([roi_window(r, self.localizer, fmH, fmW) for r in rects], dtype=np.int32)
+        dwins = self._buf("wins", wins.shape, np.int32)
+        dwins.copy_from_numpy(wins)
+        cinput = self._buf("cinput", (R, kh * kw * planes))
+        pidx = self._buf("pidx", (R, kh * kw * planes), np.int32)
+        _lib.call("frcnn_roi_pool_forward", ptr(fm), fmC, fmH, fmW, ptr(dwins), R, kh, kw, ptr(cinput), ptr(pidx), s)
+        bbox_out, cls_out = cnet.forward(cinput)  # :101
+        dcls = self._buf("cls", (R,), np.int32); dconf = self._buf("conf", (R,))
+        _lib.call("frcnn_cnet_decode", ptr(cls_out), R, ncls, ptr(dcls), ptr(dconf), s)  # :110-113
+        bbox_h = bbox_out.numpy(); cls_h = dcls.numpy(); conf_h = dconf.numpy()
+        self.last_cnet = dict(bbox=bbox_h, cls=cls_out.numpy())
+        yclass = {}
+        for k, i in enumerate(cand):  # :106-122
+            x = dict(p=float(p_all[i]), r=rects[k], l=int(idx_all[i][0]),
+                     a=self.anchors.get(*[int(v) for v in idx_all[i]]))
+            x["r2"] = Anchors.anchorToInput(x["r"], bbox_h[k])  # :107
+            x["class"] = int(cls_h[k]); x["confidence"] = float(conf_h[k])
+            if x["class"] != bgclass and math.exp(x["confidence"]) > 0.2:  # :115
+                yclass.setdefault(x["class"], []).append(x)
+        # per-class NMS (:125-136); classes in ascending order (pairs() order is unspecified in Lua)
+        for cidx in sorted(yclass.keys()):
+            c = yclass[cidx]
+            bb = np.zeros((len(c), 5), dtype=np.float32)
+            for j, r in enumerate(c):
+                bb[j, 0:4] = r["r2"].totensor()
+                bb[j, 4] = r["confidence"]
+            pk = nms(bb, 0.1, bb[:, 4])  # tensor scores -> ignored, key = max-y (nms.lua:42)
+            for v in pk:
+                winners.append(c[int(v) - 1])
+        return winners

@@ -1,0 +1,265 @@
+// api.cpp -- C ABI plumbing of libfrcnn_hip.so (include/frcnn_hip.h): errors, device buffers,
+// the HIP-event profiler, and the per-operator entry points that wrap the kernels.
+#include <cstring>
+#include <mutex>
+
+#include "kernels.h"
+
+namespace frcnn {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// ---------------------------------------------------------------- profiler
+struct ProfRec { int klass; double flops, bytes; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_pending;
+static std::mutex g_mu;
+
+bool prof_enabled() { return g_prof; }
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_before(int, hipStream_t s) {
+  g_pending = get_event();
+  (void)hipEventRecord(g_pending, s);
+}
+void prof_after(int klass, double flops, double bytes, hipStream_t s) {
+  ProfRec r;
+  r.klass = klass; r.flops = flops; r.bytes = bytes; r.a = g_pending; r.b = get_event();
+  (void)hipEventRecord(r.b, s);
+  g_recs.push_back(r);
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_version(void) { return 100; }
+const char* frcnn_last_error(void) { return g_err.c_str(); }
+
+int frcnn_device_count(int* n) {
+  FR_HIP(hipGetDeviceCount(n));
+  return FRCNN_OK;
+}
+int frcnn_set_device(int device) {
+  FR_HIP(hipSetDevice(device));
+  return FRCNN_OK;
+}
+int frcnn_device_name(char* buf, int len) {
+  int dev;
+  FR_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  FR_HIP(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return FRCNN_OK;
+}
+
+int frcnn_malloc(void** ptr, size_t bytes) {
+  FR_HIP(hipMalloc(ptr, bytes ? bytes : 16));
+  return FRCNN_OK;
+}
+int frcnn_free(void* ptr) {
+  FR_HIP(hipFree(ptr));
+  return FRCNN_OK;
+}
+int frcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  return FRCNN_OK;
+}
+int frcnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+  return FRCNN_OK;
+}
+int frcnn_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream)));
+  return FRCNN_OK;
+}
+int frcnn_stream_sync(void* stream) {
+  FR_HIP(hipStreamSynchronize(S(stream)));
+  return FRCNN_OK;
+}
+int frcnn_zero(void* ptr, size_t bytes, void* stream) { return fill_zero(ptr, bytes, S(stream)); }
+int frcnn_scale(float* x, long long n, float s, void* stream) { return scale_inplace(x, n, s, S(stream)); }
+
+int frcnn_prof_enable(int on) {
+  g_prof = on != 0;
+  return FRCNN_OK;
+}
+int frcnn_prof_collect(long long* launches, double* ms, double* flops, double* bytes) {
+  FR_HIP(hipDeviceSynchronize());
+  for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; }
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    FR_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    launches[r.klass] += 1; ms[r.klass] += t; flops[r.klass] += r.flops; bytes[r.klass] += r.bytes;
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return FRCNN_OK;
+}
+
+// ---------------------------------------------------------------- nms
+size_t frcnn_nms_workspace_bytes(int n) { return nms_workspace_bytes(n); }
+int frcnn_nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
+                     long long* pick, int* count, void* ws, size_t ws_bytes, void* stream) {
+  return nms_device(boxes, n, ncols, overlap, key_mode, key_col, pick, count, ws, ws_bytes, S(stream));
+}
+int frcnn_nms_host(const float* boxes_host, int n, int ncols, float overlap, int key_mode, int key_col,
+                   long long* pick_host, int* count_host) {
+  if (n <= 0) { *count_host = 0; return FRCNN_OK; }
+  size_t wsb = nms_workspace_bytes(n);
+  char* buf = nullptr;
+  size_t bb = ((size_t)n * ncols * 4 + 255) / 256 * 256, pb = ((size_t)n * 8 + 255) / 256 * 256;
+  FR_HIP(hipMalloc((void**)&buf, bb + pb + 256 + wsb));
+  float* dboxes = (float*)buf;
+  long long* dpick = (long long*)(buf + bb);
+  int* dcount = (int*)(buf + bb + pb);
+  void* ws = buf + bb + pb + 256;
+  int rc = FRCNN_OK;
+  hipError_t e = hipMemcpy(dboxes, boxes_host, (size_t)n * ncols * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) rc = nms_device(dboxes, n, ncols, overlap, key_mode, key_col, dpick, dcount, ws, wsb, 0);
+  if (e == hipSuccess && rc == FRCNN_OK) e = hipMemcpy(count_host, dcount, 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == FRCNN_OK && *count_host > 0)
+    e = hipMemcpy(pick_host, dpick, (size_t)*count_host * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess) { set_error("frcnn_nms_host: %s", hipGetErrorString(e)); return FRCNN_ERR_HIP; }
+  return rc;
+}
+
+// ---------------------------------------------------------------- conv (operator-level, for parity tests
+// and hosts that drive single layers; the model runtime keeps packed weights resident instead)
+int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_slope, const float* in_scale,
+                         const float* weight, const float* bias, int O, int k, int pad, float* out,
+                         void* stream) {
+  float* wf = nullptr;
+  FR_HIP(hipMalloc((void**)&wf, conv_pack_floats(C, O, k) * 4));
+  int rc = conv_pack_weights(weight, O, C, k, wf, nullptr, S(stream));
+  if (rc == FRCNN_OK) rc = conv_igemm(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream));
+  (void)hipStreamSynchronize(S(stream));
+  (void)hipFree(wf);
+  return rc;
+}
+int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const float* weight, int C, int k,
+                                int pad, float* gin, int accumulate, void* stream) {
+  float* wd = nullptr;
+  FR_HIP(hipMalloc((void**)&wd, conv_pack_floats(O, C, k) * 4));
+  int rc = conv_pack_weights(weight, O, C, k, nullptr, wd, S(stream));
+  if (rc == FRCNN_OK)
+    rc = conv_igemm(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin,
+                    accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
+  (void)hipStreamSynchronize(S(stream));
+  (void)hipFree(wd);
+  return rc;
+}
+int frcnn_conv2d_backward_weight(const float* in, int C, int H, int W, const float* in_slope,
+                                 const float* in_scale, const float* gout, int O, int k, int pad,
+                                 float* gweight, float* gbias, void* stream) {
+  FR_TRY(conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, S(stream)));
+  if (gbias) {
+    int Ho = H + 2 * pad - k + 1, Wo = W + 2 * pad - k + 1;
+    FR_TRY(channel_sum(gout, O, (long)Ho * Wo, gbias, S(stream)));
+  }
+  return FRCNN_OK;
+}
+
+int frcnn_maxpool_act_forward(const float* x, int C, int H, int W, const float* slope, const float* scale,
+                              float* out, unsigned char* idx, void* stream) {
+  return maxpool_act_forward(x, C, H, W, slope, scale, out, idx, S(stream));
+}
+int frcnn_maxpool_act_backward(const float* gpool, const unsigned char* idx, const float* x, int C, int H, int W,
+                               const float* slope, const float* scale, float* gx, float* gbias, float* gslope,
+                               void* stream) {
+  return maxpool_act_backward(gpool, idx, x, C, H, W, slope, scale, gx, gbias, gslope, S(stream));
+}
+int frcnn_act_forward(const float* x, int C, long long hw, const float* slope, const float* scale, float* y,
+                      void* stream) {
+  return act_forward(x, C, hw, slope, scale, y, S(stream));
+}
+int frcnn_act_backward(const float* gy, const float* x, int C, long long hw, const float* slope,
+                       const float* scale, float* gx, float* gbias, float* gslope, void* stream) {
+  return act_backward(gy, x, C, hw, slope, scale, gx, gbias, gslope, S(stream));
+}
+
+int frcnn_roi_pool_forward(const float* fmap, int C, int H, int W, const int* wins, int R, int kh, int kw,
+                           float* out, int* idx, void* stream) {
+  return roi_pool_forward(fmap, C, H, W, wins, R, kh, kw, out, idx, S(stream));
+}
+int frcnn_roi_pool_backward(float* gmap, int C, int H, int W, const float* gout, const int* idx, int R, int kh,
+                            int kw, void* stream) {
+  return roi_pool_backward(gmap, C, H, W, gout, idx, R, kh, kw, S(stream));
+}
+
+static void to_layers(const float* const* maps, const int* H, const int* W, RpnLayers* L) {
+  for (int l = 0; l < 4; ++l) { L->map[l] = maps ? maps[l] : nullptr; L->H[l] = H[l]; L->W[l] = W[l]; }
+}
+size_t frcnn_rpn_scan_workspace_bytes(const int* H, const int* W) {
+  RpnLayers L;
+  to_layers(nullptr, H, W, &L);
+  return rpn_scan_workspace_bytes(L);
+}
+int frcnn_rpn_scan(const float* const* maps, const int* H, const int* W, const float* anchor_w,
+                   const float* anchor_h, double img_w, double img_h, double p_threshold, int cap,
+                   float* match_p, int* match_idx, double* match_rect, float* match_box, int* count,
+                   void* ws, size_t ws_bytes, void* stream) {
+  RpnLayers L;
+  to_layers(maps, H, W, &L);
+  return rpn_scan(L, anchor_w, anchor_h, img_w, img_h, p_threshold, cap, match_p, match_idx, match_rect,
+                  match_box, count, ws, ws_bytes, S(stream));
+}
+int frcnn_rpn_loss(const float* const* maps, float* const* deltas, const int* H, const int* W, const int* ex_idx,
+                   const double* ex_anchor, const double* ex_roi, const int* ex_class, int npos, int nneg,
+                   int bgclass, double* ex_loss, float* crtarget, float* cctarget, void* stream) {
+  RpnLayers L;
+  to_layers(maps, H, W, &L);
+  return rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget,
+                  cctarget, S(stream));
+}
+
+int frcnn_loss_accumulate(const double* ex_loss, int E, double* acc, void* stream) {
+  return loss_accumulate(ex_loss, E, acc, S(stream));
+}
+
+int frcnn_linear_forward(const float* x, int R, int I, const float* weight, const float* bias, int O, float* y,
+                         void* stream) {
+  // Y[R][O] = X[R][I] * W[O][I]^T + b
+  return gemm_f32(x, I, 1, weight, 1, I, y, O, R, O, I, OUT_STORE, bias, S(stream));
+}
+int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const float* weight, int O, float* gx,
+                          float* gweight, float* gbias, void* stream) {
+  if (gx) FR_TRY(gemm_f32(gy, O, 1, weight, I, 1, gx, I, R, I, O, OUT_STORE, nullptr, S(stream)));
+  if (gweight) FR_TRY(gemm_f32(gy, 1, O, x, I, 1, gweight, I, O, I, R, OUT_ADD, nullptr, S(stream)));
+  if (gbias) FR_TRY(channel_sum_cols(gy, R, O, gbias, S(stream)));
+  return FRCNN_OK;
+}
+
+int frcnn_rmsprop(float* x, const float* g, float* m, long long n, float lr, float alpha, float eps,
+                  void* stream) {
+  return rmsprop_step(x, g, m, n, lr, alpha, eps, S(stream));
+}
+
+int frcnn_cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,
+                      int npos, int ncls, float* crdelta, float* ccdelta, double* loss2, void* stream) {
+  return cnet_losses(crout, crtarget, ccout, cctarget, R, npos, ncls, crdelta, ccdelta, loss2, S(stream));
+}
+int frcnn_cnet_decode(const float* cls_out, int R, int ncls, int* cls, float* conf, void* stream) {
+  return cnet_decode(cls_out, R, ncls, cls, conf, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// cnet.hip -- the small row-wise layers of the classification network
+// (models/model_utilities.lua:76-124): nn.BatchNormalization, nn.PReLU + nn.Dropout, nn.LogSoftMax,
+// and the two criteria of objective.lua:170-177 fused with their gradients.  R (number of ROIs)
+// is a few hundred at most, so these are latency-bound: one launch each, fp64 accumulators for
+// the per-feature statistics (cheap at this size), coalesced along the feature dimension.
+#include "kernels.h"
+
+namespace frcnn {
+
+#define BN_EPS 1e-5
+#define BN_MOM 0.1
+
+// thread per feature j; rows are read with stride n (coalesced across threads)
+__global__ void bn_forward_kernel(const float* __restrict__ x, int R, int n, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, float* running, int training,
+                                  float* __restrict__ xhat, float* __restrict__ invstd, float* __restrict__ y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double mean, var;
+  if (training) {
+    mean = 0.0;
+    for (int r = 0; r < R; ++r) mean += x[(size_t)r * n + j];
+    mean /= R;
+    var = 0.0;
+    for (int r = 0; r < R; ++r) { double d = x[(size_t)r * n + j] - mean; var += d * d; }
+    const double unb = R > 1 ? var / (R - 1) : var / R;
+    var /= R;
+    if (running) {
+      running[j] = (float)((1.0 - BN_MOM) * running[j] + BN_MOM * mean);
+      running[n + j] = (float)((1.0 - BN_MOM) * running[n + j] + BN_MOM * unb);
+    }
+  } else {
+    mean = running[j];
+    var = running[n + j];
+  }
+  const double is = 1.0 / sqrt(var + BN_EPS);
+  invstd[j] = (float)is;
+  const double g = gamma[j], b = beta[j];
+  for (int r = 0; r < R; ++r) {
+    const double xh = (x[(size_t)r * n + j] - mean) * is;
+    xhat[(size_t)r * n + j] = (float)xh;
+    y[(size_t)r * n + j] = (float)(xh * g + b);
+  }
+}
+int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,
+               int training, float* xhat, float* invstd, float* y, hipStream_t s) {
+  FR_CHECK(training || running, "bn_forward: evaluate mode needs running statistics");
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_forward_kernel, dim3(cdiv(n, 64)), dim3(64), 0, x, R, n,
+            gamma, beta, running, training, xhat, invstd, y);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void bn_backward_kernel(const float* __restrict__ gy, const float* __restrict__ xhat,
+                                   const float* __restrict__ invstd, const float* __restrict__ gamma, int R,
+                                   int n, int training, float* __restrict__ gx, float* ggamma, float* gbeta) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const double g = gy[(size_t)r * n + j];
+    sg += g;
+    sgx += g * xhat[(size_t)r * n + j];
+  }
+  ggamma[j] = (float)((double)ggamma[j] + sgx);
+  gbeta[j] = (float)((double)gbeta[j] + sg);
+  const double is = invstd[j], gm = gamma[j];
+  for (int r = 0; r < R; ++r) {
+    const double g = gy[(size_t)r * n + j];
+    const double xh = xhat[(size_t)r * n + j];
+    const double v = training ? (g - sg / R - xh * sgx / R) * gm * is : g * gm * is;
+    gx[(size_t)r * n + j] = (float)v;
+  }
+}
+int bn_backward(const float* gy, const float* xhat, const float* invstd, const float* gamma, int R,
+                int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s) {
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, 64)), dim3(64), 0, gy,
+            xhat, invstd, gamma, R, n, training, gx, ggamma, gbeta);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// y = prelu(x) * (mask * inv_keep)   (nn.PReLU then nn.Dropout v2; mask==null -> identity)
+__global__ void prelu_dropout_forward_kernel(const float* __restrict__ x, long n, const float* slope,
+                                             const float* __restrict__ mask, float inv_keep,
+                                             float* __restrict__ y) {
+  const float a = *slope;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    v = v > 0.f ? v : a * v;
+    if (mask) v = v * (mask[i] * inv_keep);
+    y[i] = v;
+  }
+}
+int prelu_dropout_forward(const float* x, long n, const float* slope, const float* mask, float inv_keep,
+                          float* y, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 1024);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 12.0, s, prelu_dropout_forward_kernel, dim3(grid), dim3(256), 0, x, n, slope,
+            mask, inv_keep, y);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void prelu_dropout_backward_kernel(const float* __restrict__ gy, const float* __restrict__ x, long n,
+                                              const float* slope, const float* __restrict__ mask,
+                                              float inv_keep, float* __restrict__ gx, float* gslope) {
+  __shared__ float sh[4];
+  const float a = *slope;
+  float sa = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float g = gy[i];
+    if (mask) g = g * (mask[i] * inv_keep);
+    const float xv = x[i];
+    float r = g;
+    if (!(xv > 0.f)) { r = a * g; sa += xv * g; }
+    gx[i] = r;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sa += __shfl_down(sa, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sa;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(gslope, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+int prelu_dropout_backward(const float* gy, const float* x, long n, const float* slope,
+                           const float* mask, float inv_keep, float* gx, float* gslope, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 256);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 16.0, s, prelu_dropout_backward_kernel, dim3(grid), dim3(256), 0, gy, x, n,
+            slope, mask, inv_keep, gx, gslope);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// nn.LogSoftMax per row (max-shifted), fp32 result
+__global__ void log_softmax_rows_kernel(const float* __restrict__ x, int R, int n, float* __restrict__ y) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* xr = x + (size_t)r * n;
+  double m = xr[0];
+  for (int i = 1; i < n; ++i) m = xr[i] > m ? (double)xr[i] : m;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += exp((double)xr[i] - m);
+  const double lse = m + log(s);
+  for (int i = 0; i < n; ++i) y[(size_t)r * n + i] = (float)((double)xr[i] - lse);
+}
+int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 8.0, s, log_softmax_rows_kernel, dim3(cdiv(R, 64)), dim3(64), 0, x, R,
+            n, y);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// gx = gy - exp(lsm) * sum_j gy_j
+__global__ void log_softmax_backward_kernel(const float* __restrict__ gy, const float* __restrict__ lsm, int R,
+                                            int n, float* __restrict__ gx) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += gy[(size_t)r * n + i];
+  for (int i = 0; i < n; ++i)
+    gx[(size_t)r * n + i] = (float)((double)gy[(size_t)r * n + i] - exp((double)lsm[(size_t)r * n + i]) * sum);
+}
+int log_softmax_backward(const float* gy, const float* lsm, int R, int n, float* gx, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 12.0, s, log_softmax_backward_kernel, dim3(cdiv(R, 64)), dim3(64), 0,
+            gy, lsm, R, n, gx);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// objective.lua:170-177 in one workgroup:
+//   crout[npos.., :] = 0 ; creg_loss = SmoothL1(crout, crtarget) * 10 ; crdelta = grad * 10
+//   ccls_loss = ClassNLL(ccout, cctarget) (sizeAverage=true) ; ccdelta = -1/R at the target
+// loss2[0] += creg_loss ; loss2[1] += ccls_loss   (fp64 accumulators, objective.lua:57-58)
+__global__ void cnet_losses_kernel(float* __restrict__ crout, const float* __restrict__ crtarget,
+                                   const float* __restrict__ ccout, const float* __restrict__ cctarget, int R,
+                                   int npos, int ncls, float* __restrict__ crdelta, float* __restrict__ ccdelta,
+                                   double* loss2) {
+  __shared__ double shr[256], shc[256];
+  double sr = 0.0, sc = 0.0;
+  for (int i = threadIdx.x; i < R * 4; i += blockDim.x) {
+    float v = crout[i];
+    if (i >= npos * 4) { v = 0.f; crout[i] = 0.f; }
+    const float z = v - crtarget[i];
+    const float az = fabsf(z);
+    sr += az < 1.0f ? 0.5 * (double)z * (double)z : (double)az - 0.5;
+    crdelta[i] = (az < 1.0f ? z : (z > 0.f ? 1.0f : -1.0f)) * 10.0f;
+  }
+  for (int i = threadIdx.x; i < R * ncls; i += blockDim.x) ccdelta[i] = 0.f;
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const int t = (int)cctarget[r] - 1;
+    sc -= (double)ccout[(size_t)r * ncls + t];
+    ccdelta[(size_t)r * ncls + t] = (float)(-1.0 / R);
+  }
+  shr[threadIdx.x] = sr;
+  shc[threadIdx.x] = sc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { shr[threadIdx.x] += shr[threadIdx.x + o]; shc[threadIdx.x] += shc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss2[0] += (double)(float)shr[0] * 10.0;
+    loss2[1] += (double)(float)(shc[0] / R);
+  }
+}
+int cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,
+                int npos, int ncls, float* crdelta, float* ccdelta, double* loss2, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * (ncls + 8) * 8.0, s, cnet_losses_kernel, dim3(1), dim3(256), 0, crout,
+            crtarget, ccout, cctarget, R, npos, ncls, crdelta, ccdelta, loss2);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// torch.sort(cprob, 1, true)[1] (Detector.lua:110): class = argmax (first max), confidence = max
+__global__ void cnet_decode_kernel(const float* __restrict__ lsm, int R, int ncls, int* __restrict__ cls,
+                                   float* __restrict__ conf) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int best = 0;
+  for (int j = 1; j < ncls; ++j)
+    if (lsm[(size_t)r * ncls + j] > lsm[(size_t)r * ncls + best]) best = j;
+  cls[r] = best + 1;
+  conf[r] = lsm[(size_t)r * ncls + best];
+}
+int cnet_decode(const float* cls_lsm, int R, int ncls, int* cls_out, float* conf_out, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * ncls * 4.0, s, cnet_decode_kernel, dim3(cdiv(R, 64)), dim3(64), 0,
+            cls_lsm, R, ncls, cls_out, conf_out);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn

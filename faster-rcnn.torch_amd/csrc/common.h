@@ -1,0 +1,83 @@
+// common.h -- shared host-side plumbing for libfrcnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/frcnn_hip.h"
+
+namespace frcnn {
+
+void set_error(const char* fmt, ...);
+
+#define FR_HIP(expr)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      frcnn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                       __LINE__);                                                       \
+      return FRCNN_ERR_HIP;                                                             \
+    }                                                                                   \
+  } while (0)
+
+#define FR_CHECK(cond, ...)                  \
+  do {                                       \
+    if (!(cond)) {                           \
+      frcnn::set_error(__VA_ARGS__);         \
+      return FRCNN_ERR_ARG;                  \
+    }                                        \
+  } while (0)
+
+#define FR_TRY(expr)            \
+  do {                          \
+    int r_ = (expr);            \
+    if (r_ != FRCNN_OK) return r_; \
+  } while (0)
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+// ---- per-kernel-class HIP-event profiler (bench.py's roofline leg) -----------------
+// When enabled, every launch made through FR_LAUNCH is bracketed by two events on the
+// launch stream; frcnn_prof_collect() synchronises and aggregates per class.
+enum KClass {
+  KC_CONV_IGEMM_K3 = 0,   // conv_igemm<3,...> fwd + dgrad (the dominant kernel)
+  KC_CONV_IGEMM_OTHER,    // 1x1 / 5x5 / 7x7 instantiations
+  KC_CONV_WGRAD_K3,
+  KC_CONV_WGRAD_OTHER,
+  KC_GEMM,                // cnet Linear
+  KC_ELEMWISE,            // pool / prelu-bwd / pack / zero / scale
+  KC_ROI,
+  KC_RPN,
+  KC_NMS,
+  KC_OPTIM,
+  KC_COUNT
+};
+
+bool prof_enabled();
+void prof_before(int klass, hipStream_t s);
+void prof_after(int klass, double flops, double bytes, hipStream_t s);
+
+#define FR_LAUNCH(klass, flops, bytes, stream, kernel, grid, block, shmem, ...)        \
+  do {                                                                                 \
+    if (frcnn::prof_enabled()) frcnn::prof_before((klass), (stream));                  \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
+    if (frcnn::prof_enabled()) frcnn::prof_after((klass), (flops), (bytes), (stream)); \
+  } while (0)
+
+#define FR_LAUNCH_CHECK()                                                          \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      frcnn::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),  \
+                       __FILE__, __LINE__);                                        \
+      return FRCNN_ERR_HIP;                                                        \
+    }                                                                              \
+  } while (0)
+
+}  // namespace frcnn

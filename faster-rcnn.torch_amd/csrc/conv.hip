@@ -1,0 +1,522 @@
+// conv.hip -- nn.SpatialConvolution forward / updateGradInput / accGradParameters
+// (reference call sites: models/model_utilities.lua:8,31,33 driven by objective.lua:71,189 and
+// Detector.lua:33) as hand-written implicit-GEMM kernels on the gfx950 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
+//
+// Layout: activations CHW fp32 exactly like the reference's tensors.  The input patch (with halo)
+// of one output tile is staged ONCE in LDS and re-used by all k*k taps -- no im2col matrix ever
+// exists in HBM.  Weights are pre-packed per step into a [K'][M] matrix (M fastest) whose K' order
+// interleaves channel pairs, so that the two 32-lane halves of a wave (the two k-slices of
+// v_mfma_f32_32x32x2_f32) address LDS at  lane_base + compile-time immediate.
+//
+// updateGradInput is the same kernel: a "full" correlation of gradOutput with the flipped,
+// transposed filter bank (pad' = k-1-pad), fed by the second packed matrix.
+#include "kernels.h"
+
+namespace frcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+int conv_cc(int k) { return k == 1 ? 32 : (k == 3 ? 8 : 2); }
+int conv_mpad(int M) { return M <= 64 ? 64 : cdiv(M, 128) * 128; }
+size_t conv_pack_floats(int Kchan, int M, int k) {
+  int cc = conv_cc(k);
+  return (size_t)cdiv(Kchan, cc) * cc * k * k * conv_mpad(M);
+}
+
+// dst[row][m], row = ((cp*k+ky)*k+kx)*2+h, kc = 2cp+h.
+//  mode 0 (fwd):   dst = W[m][kc][ky][kx]            (W is [O][C][k][k], M=O, Kchan=C)
+//  mode 1 (dgrad): dst = W[kc][m][k-1-ky][k-1-kx]    (M=C, Kchan=O)
+__global__ void pack_weights_kernel(const float* __restrict__ w, int O, int C, int k, int mode,
+                                    int Kchan_pad, int M, int Mpad, float* __restrict__ dst) {
+  long total = (long)Kchan_pad * k * k * Mpad;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long)gridDim.x * blockDim.x) {
+    int m = (int)(t % Mpad);
+    long row = t / Mpad;
+    int h = (int)(row & 1);
+    long r2 = row >> 1;
+    int kx = (int)(r2 % k);
+    r2 /= k;
+    int ky = (int)(r2 % k);
+    int cp = (int)(r2 / k);
+    int kc = cp * 2 + h;
+    float v = 0.f;
+    if (mode == 0) {
+      if (m < O && kc < C) v = w[(((long)m * C + kc) * k + ky) * k + kx];
+    } else {
+      if (m < C && kc < O) v = w[(((long)kc * C + m) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+    }
+    (void)M;
+    dst[t] = v;
+  }
+}
+
+int conv_pack_weights(const float* w, int O, int C, int k, float* wf, float* wd, hipStream_t s) {
+  int cc = conv_cc(k);
+  if (wf) {
+    int kp = cdiv(C, cc) * cc, mp = conv_mpad(O);
+    long total = (long)kp * k * k * mp;
+    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, pack_weights_kernel, dim3(grid), dim3(256), 0, w, O, C, k,
+              0, kp, O, mp, wf);
+  }
+  if (wd) {
+    int kp = cdiv(O, cc) * cc, mp = conv_mpad(C);
+    long total = (long)kp * k * k * mp;
+    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, pack_weights_kernel, dim3(grid), dim3(256), 0, w, O, C, k,
+              1, kp, C, mp, wd);
+  }
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit GEMM: forward and input-gradient
+// ------------------------------------------------------------------------------------------
+struct IgemmArgs {
+  const float* in;
+  const float* in_slope;  // device scalar or null
+  const float* in_scale;  // device [Cin] or null
+  const float* wp;        // packed [Kp][Mpad]
+  const float* bias;      // [M] or null
+  float* out;             // [M][Ho][Wo]
+  int Cin, H, W, M, Mpad, Ho, Wo, pad;
+  int TH, TW, tilesX, tilesY, mTiles;
+  int nChunks, splitK, chunksPerSplit;
+  int out_mode;           // 0 store, 1 add, 2 atomic add
+};
+
+#define IG_MAXIT 4  // patch plane <= 1024 positions
+
+template <int KS, int CC, int BM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
+  constexpr int KC = CC * KS * KS;   // K rows per chunk
+  constexpr int WM = BM / 2;         // 2x2 waves
+  constexpr int MT = WM / 32;        // 32x32 tiles per wave along M
+  constexpr int NTW = 2;             // ... along N (wave covers 64 pixels)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;            // [KC][BM]
+  float* Bs = smem + KC * BM;  // [CC][plane]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, li = lane & 31;
+
+  int bid = blockIdx.x;
+  const int nT = p.tilesX * p.tilesY;
+  const int nt_id = bid % nT;
+  bid /= nT;
+  const int mt_id = bid % p.mTiles;
+  const int split = bid / p.mTiles;
+  const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
+  const int m0 = mt_id * BM;
+  const int PW = p.TW + KS - 1, PH = p.TH + KS - 1, plane = PH * PW;
+  const int NT = p.TH * p.TW;
+  const long HW = (long)p.H * p.W;
+
+  // this thread's patch positions (same for every channel and chunk)
+  int gofs[IG_MAXIT];
+#pragma unroll
+  for (int it = 0; it < IG_MAXIT; ++it) {
+    int e = tid + it * 256;
+    int r = e / PW, col = e - r * PW;
+    int gy = ty0 - p.pad + r, gx = tx0 - p.pad + col;
+    bool ok = e < plane && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    gofs[it] = ok ? gy * p.W + gx : -1;
+  }
+  const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
+  const float slope = has_slope ? *p.in_slope : 1.f;
+
+  // lane bases for the MFMA operand reads
+  const float* Abase = As + h * BM + wm * WM + li;
+  int boff[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    int q = wn * 64 + nt * 32 + li;
+    q = q < NT ? q : NT - 1;
+    int ty = q / p.TW, tx = q - ty * p.TW;
+    boff[nt] = h * plane + ty * PW + tx;
+  }
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int cbeg = split * p.chunksPerSplit;
+  const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    // ---- stage A (weights): KC rows x BM floats, 16 B per thread per pass
+    {
+      constexpr int TPR = BM / 4, RPP = 256 / TPR;
+      const int rr = tid / TPR, cq = (tid % TPR) * 4;
+      const float* src = p.wp + ((size_t)chunk * KC) * p.Mpad + m0 + cq;
+#pragma unroll 4
+      for (int r = rr; r < KC; r += RPP) {
+        float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * p.Mpad);
+        *reinterpret_cast<float4*>(As + r * BM + cq) = v;
+      }
+    }
+    // ---- stage B (input patch with halo), activation of the producing layer fused on load
+    {
+      const int c0 = chunk * CC;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        const int c = c0 + cc;
+        const bool cok = c < p.Cin;
+        const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
+        const float* src = p.in + (size_t)c * HW;
+#pragma unroll
+        for (int it = 0; it < IG_MAXIT; ++it) {
+          if (it * 256 < plane) {
+            int e = tid + it * 256;
+            if (e < plane) {
+              float v = 0.f;
+              if (cok && gofs[it] >= 0) {
+                v = src[gofs[it]];
+                if (has_slope) v = v > 0.f ? v : slope * v;
+                if (has_scale) v *= sc;
+              }
+              Bs[cc * plane + e] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: K' order inside the chunk = ((cp*KS+ky)*KS+kx)*2 + h
+#pragma unroll
+    for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int rowoff = cp * 2 * plane + ky * PW;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int kp = (cp * KS + ky) * KS + kx;
+          float a[MT], b[NTW];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt] = Abase[kp * 2 * BM + mt * 32];
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) b[nt] = Bs[boff[nt] + rowoff + kx];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+  const long HoWo = (long)p.Ho * p.Wo;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int q = wn * 64 + nt * 32 + li;
+    const int ty = q / p.TW, tx = q - ty * p.TW;
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    const bool pok = q < NT && oy < p.Ho && ox < p.Wo;
+    const long pofs = (long)oy * p.Wo + ox;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (pok && m < p.M) {
+          float v = acc[mt][nt][r];
+          if (p.bias != nullptr && split == 0) v += p.bias[m];
+          float* dst = p.out + (size_t)m * HoWo + pofs;
+          if (p.out_mode == 0) *dst = v;
+          else if (p.out_mode == 1) *dst += v;
+          else unsafeAtomicAdd(dst, v);
+        }
+      }
+    }
+  }
+}
+
+__global__ void bias_fill_kernel(float* out, const float* bias, int M, long hw) {
+  long total = (long)M * hw;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long)gridDim.x * blockDim.x)
+    out[t] = bias ? bias[t / hw] : 0.f;
+}
+
+// choose the output tile (TH x TW <= 128 pixels, patch plane <= 1024) that wastes the least work
+static void choose_tile(int Ho, int Wo, int k, int maxNT, int* TH, int* TW) {
+  long best = -1;
+  int bth = 1, btw = 1;
+  for (int tw = 1; tw <= std::min(Wo, maxNT); ++tw) {
+    if (tw < 8 && Wo >= 8) continue;
+    int th = std::min(maxNT / tw, Ho);
+    if (th < 1) continue;
+    if ((long)(th + k - 1) * (tw + k - 1) > 256 * IG_MAXIT) continue;
+    long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
+    long cost = tiles * maxNT * 64 + tiles * (th + k - 1) * (tw + k - 1);  // MFMA slots + halo traffic
+    if (best < 0 || cost < best || (cost == best && tw > btw)) {
+      best = cost; bth = th; btw = tw;
+    }
+  }
+  *TH = bth; *TW = btw;
+}
+
+template <int KS, int CC, int BM>
+static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
+  size_t lds = ((size_t)CC * KS * KS * BM + (size_t)CC * (a.TH + KS - 1) * (a.TW + KS - 1)) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
+  double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
+  FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM>), dim3(grid), dim3(256), lds, a);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
+               const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
+               double algo_flops, hipStream_t s) {
+  IgemmArgs a;
+  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
+  a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.Mpad = conv_mpad(M);
+  a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1; a.pad = pad;
+  FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_igemm: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
+  FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_igemm: unsupported kernel size %d", k);
+  const int BM = a.Mpad == 64 ? 64 : 128;
+  choose_tile(a.Ho, a.Wo, k, 128, &a.TH, &a.TW);
+  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
+  a.mTiles = a.Mpad / BM;
+  const int cc = conv_cc(k);
+  a.nChunks = cdiv(Cin, cc);
+  long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
+  int splitK = 1;
+  if (blocks < 512) splitK = (int)std::min<long>(std::max<long>(1, 768 / blocks), std::max(1, a.nChunks / 2));
+  a.chunksPerSplit = cdiv(a.nChunks, splitK);
+  a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
+  a.out_mode = out_mode;
+  if (a.splitK > 1) {
+    if (out_mode == OUT_STORE) {  // initialise with the bias, then accumulate atomically
+      long total = (long)M * a.Ho * a.Wo;
+      int grid = (int)std::min<long>(cdivl(total, 256), 2048);
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0, s, bias_fill_kernel, dim3(grid), dim3(256), 0, out, bias, M,
+                (long)a.Ho * a.Wo);
+      a.bias = nullptr;
+    }
+    a.out_mode = 2;
+  }
+  if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
+  int klass = k == 3 ? KC_CONV_IGEMM_K3 : KC_CONV_IGEMM_OTHER;
+  if (k == 3) return BM == 64 ? launch_igemm<3, 8, 64>(a, klass, algo_flops, s)
+                              : launch_igemm<3, 8, 128>(a, klass, algo_flops, s);
+  if (k == 1) return BM == 64 ? launch_igemm<1, 32, 64>(a, klass, algo_flops, s)
+                              : launch_igemm<1, 32, 128>(a, klass, algo_flops, s);
+  if (k == 5) return BM == 64 ? launch_igemm<5, 2, 64>(a, klass, algo_flops, s)
+                              : launch_igemm<5, 2, 128>(a, klass, algo_flops, s);
+  return BM == 64 ? launch_igemm<7, 2, 64>(a, klass, algo_flops, s)
+                  : launch_igemm<7, 2, 128>(a, klass, algo_flops, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: gw[o][c][ky][kx] += sum_pix g[o][pix] * act(in)[c][pix + (ky,kx) - pad]
+// GEMM view per tap: M = o (32/wave), N = c (32/wave), K = pixels.  One block = 64 o x 64 c x
+// (TYS x KS taps), looping over its share of pixel tiles, then one atomic add per element.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* in;
+  const float* in_slope;
+  const float* in_scale;
+  const float* g;
+  float* gw;
+  int Cin, H, W, O, Ho, Wo, pad;
+  int TH, TW, tilesX, tilesY;
+  int oTiles, cTiles, kyGroups, nSplit;
+};
+
+#define WG_NT 64    // staged gradient pixels per tile (TH*TW <= 64)
+#define WG_NTP 65   // odd pitch -> conflict-free column reads
+#define WG_MAXIT 4
+
+template <int KS, int TYS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  constexpr int NTAP = TYS * KS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gs = smem;                  // [64][WG_NTP]
+  float* ps = smem + 64 * WG_NTP;    // [64][PP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wo = wave >> 1, wc = wave & 1;
+  const int h = lane >> 5, li = lane & 31;
+
+  int bid = blockIdx.x;
+  const int ot = bid % p.oTiles; bid /= p.oTiles;
+  const int ct = bid % p.cTiles; bid /= p.cTiles;
+  const int kyg = bid % p.kyGroups;
+  const int split = bid / p.kyGroups;
+  const int o0 = ot * 64, c0 = ct * 64, ky0 = kyg * TYS;
+  const int PW = p.TW + KS - 1, PHs = p.TH + TYS - 1;
+  const int pplane = PHs * PW;
+  const int PP = pplane | 1;
+  const int NT = p.TH * p.TW, halfrows = p.TH >> 1;
+  const long HW = (long)p.H * p.W, HoWo = (long)p.Ho * p.Wo;
+  const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
+  const float slope = has_slope ? *p.in_slope : 1.f;
+  const bool wave_active = (c0 + wc * 32 < p.Cin) && (o0 + wo * 32 < p.O);
+
+  f32x16 acc[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging geometry of this thread
+  const int gq = lane;                                   // gradient pixel slot
+  const int gty = gq / p.TW, gtx = gq - gty * p.TW;
+  const int nPix = p.tilesX * p.tilesY;
+  for (int t = split; t < nPix; t += p.nSplit) {
+    const int oy0 = (t / p.tilesX) * p.TH, ox0 = (t % p.tilesX) * p.TW;
+    // ---- stage gradient tile gs[o][q]
+    {
+      const int oy = oy0 + gty, ox = ox0 + gtx;
+      const bool ok = gq < NT && oy < p.Ho && ox < p.Wo;
+      const long pofs = (long)oy * p.Wo + ox;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int o = wave + it * 4;
+        float v = 0.f;
+        if (ok && o0 + o < p.O) v = p.g[(size_t)(o0 + o) * HoWo + pofs];
+        gs[o * WG_NTP + gq] = v;
+      }
+    }
+    // ---- stage input patch ps[c][r][col] with the producer's activation fused
+    {
+#pragma unroll
+      for (int it = 0; it < WG_MAXIT; ++it) {
+        if (it * 256 < pplane) {
+          const int e = tid + it * 256;
+          if (e < pplane) {
+            const int r = e / PW, col = e - r * PW;
+            const int iy = oy0 - p.pad + ky0 + r, ix = ox0 - p.pad + col;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const long gofs = (long)iy * p.W + ix;
+            for (int c = 0; c < 64; ++c) {
+              float v = 0.f;
+              if (ok && c0 + c < p.Cin) {
+                v = p.in[(size_t)(c0 + c) * HW + gofs];
+                if (has_slope) v = v > 0.f ? v : slope * v;
+                if (has_scale) v *= p.in_scale[c0 + c];
+              }
+              ps[c * PP + e] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave_active) {
+      const float* ga = gs + (wo * 32 + li) * WG_NTP + h * halfrows * p.TW;
+      const float* pb = ps + (wc * 32 + li) * PP + h * halfrows * PW;
+      for (int r = 0; r < halfrows; ++r) {
+        for (int x = 0; x < p.TW; ++x) {
+          const float a = ga[r * p.TW + x];
+          const float* pbx = pb + r * PW + x;
+#pragma unroll
+          for (int ty = 0; ty < TYS; ++ty)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+              const float b = pbx[ty * PW + kx];
+              acc[ty * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ty * KS + kx], 0, 0, 0);
+            }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: D col = lane&31 -> c, row -> o
+  if (wave_active) {
+    const int c = c0 + wc * 32 + li;
+#pragma unroll
+    for (int ty = 0; ty < TYS; ++ty) {
+      const int ky = ky0 + ty;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (o < p.O && c < p.Cin && ky < KS)
+            unsafeAtomicAdd(p.gw + (((size_t)o * p.Cin + c) * KS + ky) * KS + kx, acc[ty * KS + kx][r]);
+        }
+      }
+    }
+  }
+}
+
+static void choose_wgrad_tile(int Ho, int Wo, int* TH, int* TW) {
+  long best = -1;
+  int bth = 2, btw = 1;
+  for (int th = 2; th <= 8; th += 2) {
+    for (int tw = 1; tw <= std::min(Wo, WG_NT / th); ++tw) {
+      if (tw < 8 && Wo >= 8) continue;
+      long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
+      long cost = tiles * th * tw + tiles * 24;  // K-steps + per-tile staging overhead
+      if (best < 0 || cost < best || (cost == best && tw > btw)) {
+        best = cost; bth = th; btw = tw;
+      }
+    }
+  }
+  *TH = bth; *TW = btw;
+}
+
+template <int KS, int TYS>
+static int launch_wgrad(WgradArgs& a, int klass, double flops, hipStream_t s) {
+  int pplane = (a.TH + TYS - 1) * (a.TW + KS - 1);
+  size_t lds = ((size_t)64 * WG_NTP + (size_t)64 * (pplane | 1)) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, TYS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int grid = a.oTiles * a.cTiles * a.kyGroups * a.nSplit;
+  double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
+  FR_LAUNCH(klass, flops, bytes, s, (conv_wgrad_kernel<KS, TYS>), dim3(grid), dim3(256), lds, a);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
+               const float* g, int O, int k, int pad, float* gw, hipStream_t s) {
+  WgradArgs a;
+  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g; a.gw = gw;
+  a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
+  a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
+  FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
+  choose_wgrad_tile(a.Ho, a.Wo, &a.TH, &a.TW);
+  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
+  a.oTiles = cdiv(O, 64); a.cTiles = cdiv(Cin, 64);
+  const int tys = k == 3 ? 3 : 1;
+  a.kyGroups = k / tys;
+  long base = (long)a.oTiles * a.cTiles * a.kyGroups;
+  long npix = (long)a.tilesX * a.tilesY;
+  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, cdivl(1024, base)));
+  double flops = 2.0 * O * Cin * k * k * (double)a.Ho * a.Wo;
+  int klass = k == 3 ? KC_CONV_WGRAD_K3 : KC_CONV_WGRAD_OTHER;
+  if (k == 3) return launch_wgrad<3, 3>(a, klass, flops, s);
+  if (k == 1) return launch_wgrad<1, 1>(a, klass, flops, s);
+  if (k == 5) return launch_wgrad<5, 1>(a, klass, flops, s);
+  return launch_wgrad<7, 1>(a, klass, flops, s);
+}
+
+}  // namespace frcnn

@@ -1,0 +1,317 @@
+// elem.hip -- bandwidth-bound pieces of the proposal network and the optimiser:
+//   nn.PReLU / nn.SpatialDropout / nn.SpatialMaxPooling(2,2,2,2):ceil() forward+backward
+//   (models/model_utilities.lua:9-12,23), bias/slope gradient reductions, flat-buffer ops
+//   (objective.lua:49,200) and optim.rmsprop (main.lua:133).
+// No MFMA here: these are gather / argmax / streaming kernels; the design rule is coalesced
+// 16-byte accesses where the layout allows and one wave-level reduction + one atomic per block.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace frcnn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = threadIdx.x < (blockDim.x >> 6) ? sh[threadIdx.x] : 0.f;
+    r = wave_sum(r);
+  }
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------- flat buffer ops
+int fill_zero(void* p, size_t bytes, hipStream_t s) {
+  if (prof_enabled()) prof_before(KC_ELEMWISE, s);
+  FR_HIP(hipMemsetAsync(p, 0, bytes, s));
+  if (prof_enabled()) prof_after(KC_ELEMWISE, 0, (double)bytes, s);
+  return FRCNN_OK;
+}
+
+__global__ void scale_kernel(float* __restrict__ x, long n, float sc) {
+  long n4 = n >> 2;
+  float4* x4 = reinterpret_cast<float4*>(x);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    x4[i] = v;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    x[i] *= sc;
+}
+int scale_inplace(float* x, long n, float sc, hipStream_t s) {
+  FR_CHECK(((uintptr_t)x & 15) == 0, "scale_inplace: buffer must be 16-byte aligned");
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n / 4, 256)), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 8.0, s, scale_kernel, dim3(grid), dim3(256), 0, x, n, sc);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void add_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] += x[i];
+}
+int add_inplace(float* y, const float* x, long n, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 12.0, s, add_kernel, dim3(grid), dim3(256), 0, y, x, n);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void fill_kernel(float* x, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    x[i] = v;
+}
+int fill_value(float* x, long n, float v, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 4.0, s, fill_kernel, dim3(grid), dim3(256), 0, x, n, v);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---------------------------------------------------------------- activation (tests)
+__global__ void act_forward_kernel(const float* __restrict__ x, int C, long hw, const float* slope,
+                                   const float* scale, float* __restrict__ y) {
+  const float a = slope ? *slope : 1.f;
+  long total = (long)C * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (slope) v = v > 0.f ? v : a * v;
+    if (scale) v *= scale[i / hw];
+    y[i] = v;
+  }
+}
+int act_forward(const float* x, int C, long hw, const float* slope, const float* scale, float* y,
+                hipStream_t s) {
+  long total = (long)C * hw;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, act_forward_kernel, dim3(grid), dim3(256), 0, x, C, hw, slope,
+            scale, y);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---------------------------------------------------------------- max pool (fused activation)
+// One thread per output element; output rows are contiguous so loads of the two input rows are
+// 8-byte-per-lane strided reads (coalesced across the wave).
+__global__ void maxpool_act_forward_kernel(const float* __restrict__ x, int C, int H, int W, int Ho,
+                                           int Wo, const float* slope, const float* scale,
+                                           float* __restrict__ out, unsigned char* __restrict__ idx) {
+  const float a = slope ? *slope : 1.f;
+  long total = (long)C * Ho * Wo;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int ox = (int)(t % Wo);
+    long r = t / Wo;
+    int oy = (int)(r % Ho);
+    int c = (int)(r / Ho);
+    const float sc = scale ? scale[c] : 1.f;
+    const float* xp = x + (size_t)c * H * W;
+    float best = -3.402823466e+38f;
+    int bi = 0;
+    bool any = false;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      int y = oy * 2 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        int xx = ox * 2 + dx;
+        if (y < H && xx < W) {
+          float v = xp[(size_t)y * W + xx];
+          if (slope) v = v > 0.f ? v : a * v;
+          if (scale) v *= sc;
+          if (!any || v > best) { best = v; bi = dy * 2 + dx; any = true; }
+        }
+      }
+    }
+    out[t] = best;
+    idx[t] = (unsigned char)bi;
+  }
+}
+int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope, const float* scale,
+                        float* out, unsigned char* idx, hipStream_t s) {
+  int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;  // ceil((n-2)/2)+1
+  long total = (long)C * Ho * Wo;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 4096);
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 4.0 + total * 5.0, s, maxpool_act_forward_kernel, dim3(grid),
+            dim3(256), 0, x, C, H, W, Ho, Wo, slope, scale, out, idx);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// gx[c][y][x] = (argmax of window == this position ? gpool : 0) * scale[c] * prelu'(x)
+// One block per (channel, slab of rows): the bias-gradient and slope-gradient partial sums are
+// reduced in the block and leave through one atomic each.
+template <bool POOLED>
+__global__ void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
+                                    const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
+                                    const float* slope, const float* scale, float* __restrict__ gx,
+                                    float* gbias, float* gslope, int chunks) {
+  __shared__ float sh[16];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long hw = (long)H * W;
+  const long per = cdivl(hw, chunks);
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  const float a = slope ? *slope : 1.f;
+  const float sc = scale ? scale[c] : 1.f;
+  float sb = 0.f, sa = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    float g;
+    if (POOLED) {
+      int y = (int)(i / W), xx = (int)(i - (long)y * W);
+      int oy = y >> 1, ox = xx >> 1;
+      long po = ((long)c * Ho + oy) * Wo + ox;
+      g = (idx[po] == (unsigned char)((y & 1) * 2 + (xx & 1))) ? gin[po] : 0.f;
+    } else {
+      g = gin[(size_t)c * hw + i];
+    }
+    if (scale) g *= sc;
+    float xv = x[(size_t)c * hw + i];
+    float r = g;
+    if (slope) {
+      if (!(xv > 0.f)) { r = a * g; sa += xv * g; }
+    }
+    gx[(size_t)c * hw + i] = r;
+    sb += r;
+  }
+  float tb = block_sum(sb, sh);
+  if (threadIdx.x == 0 && gbias) unsafeAtomicAdd(gbias + c, tb);
+  if (slope && gslope) {
+    float ta = block_sum(sa, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(gslope, ta);
+  }
+}
+
+static int act_bwd_chunks(int C, long hw) {
+  long want = cdivl(2048, C);
+  long maxc = cdivl(hw, 1024);
+  return (int)std::max<long>(1, std::min<long>(want, maxc));
+}
+
+int maxpool_act_backward(const float* gpool, const unsigned char* idx, const float* x, int C, int H,
+                         int W, const float* slope, const float* scale, float* gx, float* gbias,
+                         float* gslope, hipStream_t s) {
+  int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
+  int chunks = act_bwd_chunks(C, (long)H * W);
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, act_backward_kernel<true>, dim3(C * chunks),
+            dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
+                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s) {
+  int chunks = act_bwd_chunks(C, hw);
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, act_backward_kernel<false>, dim3(C * chunks),
+            dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, (int)hw, 1, 1, 1, slope, scale, gx,
+            gbias, gslope, chunks);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks) {
+  __shared__ float sh[16];
+  const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long per = cdivl(hw, chunks);
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  float sb = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) sb += g[(size_t)c * hw + i];
+  float tb = block_sum(sb, sh);
+  if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, tb);
+}
+int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s) {
+  int chunks = act_bwd_chunks(C, hw);
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 4.0, s, channel_sum_kernel, dim3(C * chunks), dim3(256), 0, g,
+            hw, gbias, chunks);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// gb[o] += sum_r g[r][o]  (row-major R x O; nn.Linear bias gradient)
+__global__ void channel_sum_cols_kernel(const float* __restrict__ g, int R, int O, float* gb) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= O) return;
+  float sacc = 0.f;
+  for (int r = 0; r < R; ++r) sacc += g[(size_t)r * O + o];
+  gb[o] += sacc;
+}
+int channel_sum_cols(const float* g, int R, int O, float* gb, hipStream_t s) {
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * O * 4.0, s, channel_sum_cols_kernel, dim3(cdiv(O, 64)), dim3(64), 0, g, R,
+            O, gb);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---------------------------------------------------------------- RNG (throughput runs)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void bernoulli_kernel(float* m, long n, float p, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned long long r = splitmix64(seed * 0x100000001B3ull + (unsigned long long)i);
+    float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+    m[i] = u < p ? 0.f : 1.f;  // keep with probability 1-p
+  }
+}
+int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, hipStream_t s) {
+  FR_LAUNCH(KC_ELEMWISE, 0, C * 4.0, s, bernoulli_kernel, dim3(cdiv(C, 256)), dim3(256), 0, scale, (long)C,
+            p, seed);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 1024);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 4.0, s, bernoulli_kernel, dim3(grid), dim3(256), 0, mask, n, p, seed);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---------------------------------------------------------------- optim.rmsprop
+// m = alpha*m + (1-alpha)*g*g ; x -= lr * g / (sqrt(m) + eps).  5 streams of n floats: HBM-bound.
+__global__ void rmsprop_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                               long n, float lr, float alpha, float eps) {
+  const long n4 = n >> 2;
+  float4* x4 = reinterpret_cast<float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  const float oma = 1.0f - alpha;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 xv = x4[i], gv = g4[i], mv = m4[i];
+    mv.x = alpha * mv.x + oma * (gv.x * gv.x); xv.x = xv.x - lr * gv.x / (sqrtf(mv.x) + eps);
+    mv.y = alpha * mv.y + oma * (gv.y * gv.y); xv.y = xv.y - lr * gv.y / (sqrtf(mv.y) + eps);
+    mv.z = alpha * mv.z + oma * (gv.z * gv.z); xv.z = xv.z - lr * gv.z / (sqrtf(mv.z) + eps);
+    mv.w = alpha * mv.w + oma * (gv.w * gv.w); xv.w = xv.w - lr * gv.w / (sqrtf(mv.w) + eps);
+    m4[i] = mv;
+    x4[i] = xv;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float mi = alpha * m[i] + oma * (g[i] * g[i]);
+    m[i] = mi;
+    x[i] = x[i] - lr * g[i] / (sqrtf(mi) + eps);
+  }
+}
+int rmsprop_step(float* x, const float* g, float* m, long n, float lr, float alpha, float eps,
+                 hipStream_t s) {
+  FR_CHECK((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m) & 15) == 0, "rmsprop_step: buffers must be 16-byte aligned");
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n / 4, 256)), 2048);
+  FR_LAUNCH(KC_OPTIM, 0, n * 20.0, s, rmsprop_kernel, dim3(grid), dim3(256), 0, x, g, m, n, lr, alpha, eps);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn

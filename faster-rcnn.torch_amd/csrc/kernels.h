@@ -1,0 +1,107 @@
+// kernels.h -- internal host-side launchers (C++), shared by the C-ABI entry points (api.cpp)
+// and the native pnet/cnet runtime (net.cpp).  All pointers are DEVICE pointers unless named
+// *_host.  Every launcher is asynchronous on `s` and returns FRCNN_OK / error code.
+#pragma once
+#include <algorithm>
+
+#include "common.h"
+
+namespace frcnn {
+
+// ---------------------------------------------------------------- conv (conv.hip)
+// Packed weight matrices for the implicit GEMM: [Kp rows][Mpad cols], M fastest.
+//   fwd   : row ((cp*k+ky)*k+kx)*2+h  <-  W[m][c=2cp+h][ky][kx]            (M = O, K-chan = C)
+//   dgrad : row ((op*k+ky)*k+kx)*2+h  <-  W[o=2op+h][m][k-1-ky][k-1-kx]    (M = C, K-chan = O)
+int conv_cc(int k);                          // channels per K-chunk for kernel size k
+int conv_mpad(int M);                        // padded M
+size_t conv_pack_floats(int Kchan, int M, int k);
+int conv_pack_weights(const float* w, int O, int C, int k, float* wf, float* wd, hipStream_t s);
+
+enum { OUT_STORE = 0, OUT_ADD = 1 };
+// out[M][Ho][Wo] (=|+=) conv(act(in)[Cin][H][W], wp) (+ bias).  act(x) = scale[c]*prelu(x, *slope)
+// when the pointers are non-null.  Ho = H + 2*pad - k + 1.
+int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
+               const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
+               double algo_flops, hipStream_t s);
+
+// gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (atomic accumulation)
+int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
+               const float* g, int O, int k, int pad, float* gw, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise (elem.hip)
+int fill_zero(void* p, size_t bytes, hipStream_t s);
+int scale_inplace(float* x, long n, float sc, hipStream_t s);
+int add_inplace(float* y, const float* x, long n, hipStream_t s);   // y += x
+// y[c][hw] = scale[c] * prelu(x[c][hw])       (materialise an activated tensor; tests only)
+int act_forward(const float* x, int C, long hw, const float* slope, const float* scale, float* y,
+                hipStream_t s);
+// 2x2 stride-2 ceil-mode max pool of act(x); idx = argmax code 0..3 (dy*2+dx), first max wins
+int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope, const float* scale,
+                        float* out, unsigned char* idx, hipStream_t s);
+// gx = route(gpool, idx) * scale[c] * prelu'(x);  gbias[c] += sum gx;  *gslope += sum_{x<=0} x*gy*scale
+int maxpool_act_backward(const float* gpool, const unsigned char* idx, const float* x, int C, int H,
+                         int W, const float* slope, const float* scale, float* gx, float* gbias,
+                         float* gslope, hipStream_t s);
+// gx = gy * scale[c] * prelu'(x) (in place allowed); gbias[c] += sum gx; *gslope += ...
+int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
+                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s);
+// gbias[c] += sum_hw g[c][hw]
+int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s);
+// gb[o] += sum_r g[r][o] for a row-major R x O matrix
+int channel_sum_cols(const float* g, int R, int O, float* gb, hipStream_t s);
+// per-channel Bernoulli keep mask (nn.SpatialDropout, model_utilities.lua:10-12): scale[c] in {0,1}
+int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, hipStream_t s);
+int fill_value(float* x, long n, float v, hipStream_t s);
+int rmsprop_step(float* x, const float* g, float* m, long n, float lr, float alpha, float eps,
+                 hipStream_t s);
+
+// ---------------------------------------------------------------- gemm (gemm.hip)
+// C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.
+int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
+             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s);
+
+// ---------------------------------------------------------------- roi (roi.hip)
+int roi_pool_forward(const float* fmap, int C, int H, int W, const int* wins, int R, int kh, int kw,
+                     float* out, int* idx, hipStream_t s);
+int roi_pool_backward(float* gmap, int C, int H, int W, const float* gout, const int* idx, int R,
+                      int kh, int kw, hipStream_t s);
+
+// ---------------------------------------------------------------- rpn (rpn.hip)
+struct RpnLayers {
+  const float* map[4];
+  int H[4], W[4];
+};
+int rpn_scan(const RpnLayers& L, const float* anchor_w, const float* anchor_h, double img_w,
+             double img_h, double p_threshold, int cap, float* match_p, int* match_idx,
+             double* match_rect, float* match_box, int* count, void* ws, size_t ws_bytes,
+             hipStream_t s);
+size_t rpn_scan_workspace_bytes(const RpnLayers& L);
+int rpn_loss(const RpnLayers& L, float* const* delta, const int* ex_idx, const double* ex_anchor,
+             const double* ex_roi, const int* ex_class, int npos, int nneg, int bgclass,
+             double* ex_loss, float* crtarget, float* cctarget, hipStream_t s);
+
+int loss_accumulate(const double* ex_loss, int E, double* acc, hipStream_t s);
+
+// ---------------------------------------------------------------- nms (nms.hip)
+size_t nms_workspace_bytes(int n);
+int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s);
+
+// ---------------------------------------------------------------- cnet small ops (cnet.hip)
+int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,
+               int training, float* xhat, float* invstd, float* y, hipStream_t s);
+int bn_backward(const float* gy, const float* xhat, const float* invstd, const float* gamma, int R,
+                int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s);
+int prelu_dropout_forward(const float* x, long n, const float* slope, const float* mask, float inv_keep,
+                          float* y, hipStream_t s);
+int prelu_dropout_backward(const float* gy, const float* x, long n, const float* slope,
+                           const float* mask, float inv_keep, float* gx, float* gslope, hipStream_t s);
+int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s);
+int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s);
+// losses of objective.lua:170-177 + their gradients, fused
+int cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,
+                int npos, int ncls, float* crdelta, float* ccdelta, double* loss2, hipStream_t s);
+int log_softmax_backward(const float* gy, const float* lsm, int R, int n, float* gx, hipStream_t s);
+int cnet_decode(const float* cls_lsm, int R, int ncls, int* cls_out, float* conf_out, hipStream_t s);
+
+}  // namespace frcnn

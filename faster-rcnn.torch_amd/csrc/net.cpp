@@ -1,0 +1,560 @@
+// net.cpp -- native runtime of the two networks built by models/model_utilities.lua:
+//   create_proposal_net (:3-74)       -> frcnn_pnet_forward / frcnn_pnet_backward
+//   create_classification_net (:76-124) -> frcnn_cnet_forward / frcnn_cnet_backward
+// The Lua modules own their output/gradInput buffers and reuse them on the next call; so does
+// this runtime (all activations, gradient buffers and packed weights live in HBM for the life of
+// the model and are re-used every step; nothing is allocated inside a step once shapes settle).
+//
+// What is stored per convolution is only its PRE-activation output x.  nn.PReLU and
+// nn.SpatialDropout are applied by whoever consumes x (the next conv's LDS loader, the pool, the
+// weight-gradient loader), and their backward is fused with the pooling backward / bias-gradient
+// reduction, so each layer costs one HBM write in forward and one in backward.
+//
+// Flat parameter order (utilities.lua:136-147): see frcnn_model_param_table.
+#include <array>
+#include <cmath>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace frcnn {
+
+static const int HEAD_OUT = 18;  // 3 * (2 + 4), model_utilities.lua:33
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return FRCNN_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+    FR_HIP(hipMalloc(&p, need));
+    bytes = need;
+    return FRCNN_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  float* f() const { return (float*)p; }
+};
+
+struct Conv {
+  int Cin, Cout, k, pad;
+  int H, W, Ho, Wo;           // input / output spatial size (set by ensure_shapes)
+  long w_off, b_off, a_off;   // flat offsets; a_off = PReLU slope following this conv (-1: none)
+  int block, step;            // backbone position (block -1 for head convs)
+  DevBuf wf, wd;              // packed weights (forward / input-gradient)
+  DevBuf x, gx;               // pre-activation output and its gradient
+};
+
+struct Block {
+  int first_conv, nconv;
+  bool has_drop;
+  float p_drop;
+  DevBuf scale;               // per-channel SpatialDropout scale (mask | 1-p)
+  DevBuf pooled, gpooled;
+  DevBuf pidx;
+  int Hp, Wp;
+};
+
+struct Head {
+  Conv c3;                    // k x k valid conv + PReLU
+  Conv c1;                    // 1 x 1 conv -> 18 planes
+  int input;                  // 0-based block index
+  DevBuf delta;               // delta_outputs[h]
+};
+
+struct ClsLayer {
+  int in, n;
+  bool bn;
+  float p_drop;
+  long w_off, b_off, bnw_off, bnb_off, a_off;
+  DevBuf lin, pre, post, xhat, invstd, mask, g;
+};
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+struct frcnn_model {
+  frcnn_model_desc d;
+  std::vector<Conv> convs;     // backbone convs in order
+  std::vector<Block> blocks;
+  std::vector<Head> heads;
+  std::vector<ClsLayer> cls;
+  long pnet_params = 0, total_params = 0;
+  long bbox_w_off = 0, bbox_b_off = 0, clsw_off = 0, clsb_off = 0;
+  int H = 0, W = 0;            // current image size
+  int training = 0;
+  DevBuf delta_last;           // delta_outputs[nheads+1]
+  DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
+  // cnet state
+  int R = 0, D = 0;
+  const float* cnet_x = nullptr;
+  DevBuf feat_g, logits, lsm, glog, gtmp;
+  std::vector<std::array<long long, 4>> table;
+};
+
+static int pool_out(int n) { return (n - 2 + 1) / 2 + 1; }
+
+static void build_layout(frcnn_model* m) {
+  const frcnn_model_desc& d = m->d;
+  long off = 0;
+  int cin = 3;
+  for (int b = 0; b < d.nblocks; ++b) {
+    Block blk;
+    blk.first_conv = (int)m->convs.size();
+    blk.nconv = d.conv_steps[b];
+    blk.has_drop = d.dropout[b] > 0.f;  // model_utilities.lua:10
+    blk.p_drop = d.dropout[b];
+    for (int s = 0; s < d.conv_steps[b]; ++s) {
+      Conv c;
+      c.Cin = cin; c.Cout = d.filters[b]; c.k = d.ksize[b]; c.pad = d.pad[b];
+      c.block = b; c.step = s;
+      long wsz = (long)c.Cout * c.Cin * c.k * c.k;
+      c.w_off = off; c.b_off = off + wsz; c.a_off = off + wsz + c.Cout;
+      m->table.push_back({c.w_off, wsz, 0, (long long)c.k * c.k * c.Cout});
+      m->table.push_back({c.b_off, c.Cout, 1, 0});
+      m->table.push_back({c.a_off, 1, 2, 0});
+      off += wsz + c.Cout + 1;
+      cin = c.Cout;
+      m->convs.push_back(std::move(c));
+    }
+    m->blocks.push_back(std::move(blk));
+  }
+  for (int h = 0; h < d.nheads; ++h) {
+    Head hd;
+    hd.input = d.head_input[h] - 1;
+    Conv& a = hd.c3;
+    a.Cin = d.filters[hd.input]; a.Cout = d.head_n[h]; a.k = d.head_k[h]; a.pad = 0;
+    a.block = -1; a.step = 0;
+    long wsz = (long)a.Cout * a.Cin * a.k * a.k;
+    a.w_off = off; a.b_off = off + wsz; a.a_off = off + wsz + a.Cout;
+    m->table.push_back({a.w_off, wsz, 0, (long long)a.k * a.k * a.Cout});
+    m->table.push_back({a.b_off, a.Cout, 1, 0});
+    m->table.push_back({a.a_off, 1, 2, 0});
+    off += wsz + a.Cout + 1;
+    Conv& c = hd.c1;
+    c.Cin = a.Cout; c.Cout = HEAD_OUT; c.k = 1; c.pad = 0; c.block = -1; c.step = 1;
+    long w1 = (long)HEAD_OUT * c.Cin;
+    c.w_off = off; c.b_off = off + w1; c.a_off = -1;
+    m->table.push_back({c.w_off, w1, 0, (long long)HEAD_OUT});
+    m->table.push_back({c.b_off, HEAD_OUT, 1, 0});
+    off += w1 + HEAD_OUT;
+    m->heads.push_back(std::move(hd));
+  }
+  m->pnet_params = off;
+  int in = d.kh * d.kw * d.filters[d.nblocks - 1];  // model_utilities.lua:127
+  m->D = in;
+  for (int l = 0; l < d.ncls; ++l) {
+    ClsLayer L;
+    L.in = in; L.n = d.cls_n[l]; L.bn = d.cls_bn[l] != 0; L.p_drop = d.cls_dropout[l];
+    L.w_off = off; L.b_off = off + (long)in * L.n;
+    m->table.push_back({L.w_off, (long long)in * L.n, 3, in});
+    m->table.push_back({L.b_off, L.n, 4, in});
+    off += (long)in * L.n + L.n;
+    L.bnw_off = L.bnb_off = -1;
+    if (L.bn) {
+      L.bnw_off = off; L.bnb_off = off + L.n;
+      m->table.push_back({L.bnw_off, L.n, 5, 0});
+      m->table.push_back({L.bnb_off, L.n, 6, 0});
+      off += 2L * L.n;
+    }
+    L.a_off = off;
+    m->table.push_back({L.a_off, 1, 2, 0});
+    off += 1;
+    in = L.n;
+    m->cls.push_back(std::move(L));
+  }
+  m->bbox_w_off = off; m->bbox_b_off = off + (long)in * 4;
+  m->table.push_back({m->bbox_w_off, (long long)in * 4, 3, in});
+  m->table.push_back({m->bbox_b_off, 4, 4, in});
+  off += (long)in * 4 + 4;
+  int nc = d.class_count + 1;
+  m->clsw_off = off; m->clsb_off = off + (long)in * nc;
+  m->table.push_back({m->clsw_off, (long long)in * nc, 3, in});
+  m->table.push_back({m->clsb_off, nc, 4, in});
+  off += (long)in * nc + nc;
+  m->total_params = off;
+}
+
+static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
+  c.H = H; c.W = W;
+  c.Ho = H + 2 * c.pad - c.k + 1; c.Wo = W + 2 * c.pad - c.k + 1;
+  FR_CHECK(c.Ho > 0 && c.Wo > 0, "image too small: a %dx%d map reaches a %dx%d convolution", H, W, c.k, c.k);
+  size_t n = (size_t)c.Cout * c.Ho * c.Wo * 4;
+  FR_TRY(c.x.ensure(n));
+  FR_TRY(c.gx.ensure(n));
+  FR_TRY(c.wf.ensure(conv_pack_floats(c.Cin, c.Cout, c.k) * 4));
+  if (need_dgrad) FR_TRY(c.wd.ensure(conv_pack_floats(c.Cout, c.Cin, c.k) * 4));
+  return FRCNN_OK;
+}
+
+static int ensure_shapes(frcnn_model* m, int H, int W) {
+  int h = H, w = W;
+  for (size_t b = 0; b < m->blocks.size(); ++b) {
+    Block& blk = m->blocks[b];
+    for (int s = 0; s < blk.nconv; ++s) {
+      Conv& c = m->convs[blk.first_conv + s];
+      FR_TRY(ensure_conv(c, h, w, !(b == 0 && s == 0)));
+      h = c.Ho; w = c.Wo;
+    }
+    FR_CHECK(h >= 2 && w >= 2, "image too small for block %zu pooling", b + 1);
+    blk.Hp = pool_out(h); blk.Wp = pool_out(w);
+    int C = m->d.filters[b];
+    FR_TRY(blk.pooled.ensure((size_t)C * blk.Hp * blk.Wp * 4));
+    FR_TRY(blk.gpooled.ensure((size_t)C * blk.Hp * blk.Wp * 4));
+    FR_TRY(blk.pidx.ensure((size_t)C * blk.Hp * blk.Wp));
+    if (blk.has_drop) FR_TRY(blk.scale.ensure((size_t)C * 4));
+    h = blk.Hp; w = blk.Wp;
+  }
+  for (auto& hd : m->heads) {
+    const Block& in = m->blocks[hd.input];
+    FR_TRY(ensure_conv(hd.c3, in.Hp, in.Wp, true));
+    FR_TRY(ensure_conv(hd.c1, hd.c3.Ho, hd.c3.Wo, true));
+    FR_TRY(hd.delta.ensure((size_t)HEAD_OUT * hd.c1.Ho * hd.c1.Wo * 4));
+  }
+  const Block& last = m->blocks.back();
+  FR_TRY(m->delta_last.ensure((size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4));
+  m->H = H; m->W = W;
+  return FRCNN_OK;
+}
+
+extern "C" {
+
+int frcnn_model_create(const frcnn_model_desc* desc, frcnn_model** out) {
+  FR_CHECK(desc && out, "frcnn_model_create: null argument");
+  FR_CHECK(desc->nblocks >= 1 && desc->nblocks <= 8 && desc->nheads >= 0 && desc->nheads <= 8 &&
+               desc->ncls >= 0 && desc->ncls <= 8,
+           "frcnn_model_create: bad layer counts");
+  for (int b = 0; b < desc->nblocks; ++b) {
+    FR_CHECK(desc->ksize[b] == 1 || desc->ksize[b] == 3 || desc->ksize[b] == 5 || desc->ksize[b] == 7,
+             "block %d: kernel size %d unsupported (1,3,5,7)", b + 1, desc->ksize[b]);
+    FR_CHECK(desc->conv_steps[b] >= 1, "block %d: conv_steps must be >= 1", b + 1);
+  }
+  for (int h = 0; h < desc->nheads; ++h) {
+    FR_CHECK(desc->head_input[h] >= 1 && desc->head_input[h] <= desc->nblocks, "anchor net %d: bad input", h + 1);
+    FR_CHECK(desc->head_k[h] == 1 || desc->head_k[h] == 3 || desc->head_k[h] == 5 || desc->head_k[h] == 7,
+             "anchor net %d: kernel size %d unsupported", h + 1, desc->head_k[h]);
+  }
+  frcnn_model* m = new frcnn_model();
+  m->d = *desc;
+  build_layout(m);
+  *out = m;
+  return FRCNN_OK;
+}
+
+int frcnn_model_destroy(frcnn_model* m) {
+  if (!m) return FRCNN_OK;
+  auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.x.release(); c.gx.release(); };
+  for (auto& c : m->convs) rel(c);
+  for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); }
+  for (auto& h : m->heads) { rel(h.c3); rel(h.c1); h.delta.release(); }
+  for (auto& l : m->cls) {
+    l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
+    l.mask.release(); l.g.release();
+  }
+  m->img.release();
+  m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
+  m->gtmp.release();
+  delete m;
+  return FRCNN_OK;
+}
+
+int frcnn_model_param_count(const frcnn_model* m, long long* total, long long* pnet) {
+  if (total) *total = m->total_params;
+  if (pnet) *pnet = m->pnet_params;
+  return FRCNN_OK;
+}
+
+int frcnn_model_param_table(const frcnn_model* m, long long* table, int cap, int* n) {
+  *n = (int)m->table.size();
+  for (int i = 0; i < *n && i < cap; ++i)
+    for (int j = 0; j < 4; ++j) table[4 * i + j] = m->table[i][j];
+  return FRCNN_OK;
+}
+
+int frcnn_model_localizer_layers(const frcnn_model* m, int output_index, int* layers, int cap, int* n_out) {
+  const frcnn_model_desc& d = m->d;
+  FR_CHECK(output_index >= 1 && output_index <= d.nheads + 1, "localizer: output index %d out of range", output_index);
+  int nb = output_index <= d.nheads ? d.head_input[output_index - 1] : d.nblocks;
+  int n = 0;
+  auto push = [&](int kW, int kH, int dW, int dH, int pW, int pH) {
+    if (n < cap) { int* l = layers + 6 * n; l[0] = kW; l[1] = kH; l[2] = dW; l[3] = dH; l[4] = pW; l[5] = pH; }
+    ++n;
+  };
+  for (int b = 0; b < nb; ++b) {
+    for (int s = 0; s < d.conv_steps[b]; ++s) push(d.ksize[b], d.ksize[b], 1, 1, d.pad[b], d.pad[b]);
+    push(2, 2, 2, 2, 0, 0);
+  }
+  if (output_index <= d.nheads) {
+    int k = d.head_k[output_index - 1];
+    push(k, k, 1, 1, 0, 0);
+    push(1, 1, 1, 1, 0, 0);
+  }
+  *n_out = n;
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------ pnet
+int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
+                       const float* const* drop_masks, unsigned long long seed, void* stream) {
+  hipStream_t s = S(stream);
+  if (H != m->H || W != m->W) FR_TRY(ensure_shapes(m, H, W));
+  m->training = training;
+  // SpatialDropout scales
+  for (size_t b = 0; b < m->blocks.size(); ++b) {
+    Block& blk = m->blocks[b];
+    if (!blk.has_drop) continue;
+    int C = m->d.filters[b];
+    if (!training) {
+      FR_TRY(fill_value(blk.scale.f(), C, 1.0f - blk.p_drop, s));  // evaluate(): x(1-p) [ext]
+    } else if (drop_masks && drop_masks[b]) {
+      FR_HIP(hipMemcpyAsync(blk.scale.p, drop_masks[b], (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+      FR_TRY(dropout_channel_mask(blk.scale.f(), C, blk.p_drop, seed * 131 + b, s));
+    }
+  }
+  // weights change every optimiser step: refresh the packed copies
+  for (auto& c : m->convs)
+    FR_TRY(conv_pack_weights(w + c.w_off, c.Cout, c.Cin, c.k, c.wf.f(),
+                             (training && !(c.block == 0 && c.step == 0)) ? c.wd.f() : nullptr, s));
+  for (auto& h : m->heads) {
+    FR_TRY(conv_pack_weights(w + h.c3.w_off, h.c3.Cout, h.c3.Cin, h.c3.k, h.c3.wf.f(), training ? h.c3.wd.f() : nullptr, s));
+    FR_TRY(conv_pack_weights(w + h.c1.w_off, h.c1.Cout, h.c1.Cin, h.c1.k, h.c1.wf.f(), training ? h.c1.wd.f() : nullptr, s));
+  }
+  FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
+  FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
+  const float* cur = m->img.f();
+  const float* cur_slope = nullptr;
+  const float* cur_scale = nullptr;
+  for (size_t b = 0; b < m->blocks.size(); ++b) {
+    Block& blk = m->blocks[b];
+    for (int st = 0; st < blk.nconv; ++st) {
+      Conv& c = m->convs[blk.first_conv + st];
+      FR_TRY(conv_igemm(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wf.f(), w + c.b_off, c.Cout, c.k, c.pad,
+                        c.x.f(), OUT_STORE, 0, s));
+      cur = c.x.f();
+      cur_slope = w + c.a_off;
+      cur_scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;  // model_utilities.lua:20
+    }
+    const Conv& lc = m->convs[blk.first_conv + blk.nconv - 1];
+    FR_TRY(maxpool_act_forward(cur, lc.Cout, lc.Ho, lc.Wo, cur_slope, cur_scale, blk.pooled.f(),
+                               (unsigned char*)blk.pidx.p, s));
+    cur = blk.pooled.f();
+    cur_slope = nullptr;
+    cur_scale = nullptr;
+  }
+  for (auto& h : m->heads) {
+    const Block& in = m->blocks[h.input];
+    FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
+                      h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s));
+    FR_TRY(conv_igemm(h.c3.x.f(), h.c1.Cin, h.c1.H, h.c1.W, w + h.c3.a_off, nullptr, h.c1.wf.f(), w + h.c1.b_off,
+                      HEAD_OUT, 1, 0, h.c1.x.f(), OUT_STORE, 0, s));
+  }
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_output(frcnn_model* m, int i, float** ptr, int* C, int* H, int* W) {
+  FR_CHECK(m->H > 0, "pnet_output: call frcnn_pnet_forward first");
+  FR_CHECK(i >= 1 && i <= (int)m->heads.size() + 1, "pnet_output: index %d out of range", i);
+  if (i <= (int)m->heads.size()) {
+    Head& h = m->heads[i - 1];
+    *ptr = h.c1.x.f(); *C = HEAD_OUT; *H = h.c1.Ho; *W = h.c1.Wo;
+  } else {
+    Block& b = m->blocks.back();
+    *ptr = b.pooled.f(); *C = m->d.filters[m->d.nblocks - 1]; *H = b.Hp; *W = b.Wp;
+  }
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_delta(frcnn_model* m, int i, float** ptr) {
+  FR_CHECK(m->H > 0, "pnet_delta: call frcnn_pnet_forward first");
+  FR_CHECK(i >= 1 && i <= (int)m->heads.size() + 1, "pnet_delta: index %d out of range", i);
+  *ptr = i <= (int)m->heads.size() ? m->heads[i - 1].delta.f() : m->delta_last.f();
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_zero_deltas(frcnn_model* m, void* stream) {
+  FR_CHECK(m->H > 0, "pnet_zero_deltas: call frcnn_pnet_forward first");
+  for (auto& h : m->heads) FR_TRY(fill_zero(h.delta.p, (size_t)HEAD_OUT * h.c1.Ho * h.c1.Wo * 4, S(stream)));
+  const Block& last = m->blocks.back();
+  FR_TRY(fill_zero(m->delta_last.p, (size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4, S(stream)));
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
+                                    "(nn.SpatialDropout: backprop only defined while training)");
+  const int nb = (int)m->blocks.size();
+  for (int b = 0; b < nb; ++b) {
+    Block& blk = m->blocks[b];
+    FR_TRY(fill_zero(blk.gpooled.p, (size_t)m->d.filters[b] * blk.Hp * blk.Wp * 4, s));
+  }
+  {  // output nheads+1 is the last pooled map itself (model_utilities.lua:55)
+    Block& last = m->blocks.back();
+    FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
+  }
+  for (auto& h : m->heads) {
+    Block& in = m->blocks[h.input];
+    Conv &a = h.c3, &c = h.c1;
+    const long hw1 = (long)c.Ho * c.Wo;
+    // 1x1 conv: accGradParameters + updateGradInput
+    FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, s));
+    FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));
+    double f1 = 2.0 * HEAD_OUT * c.Cin * (double)hw1;
+    FR_TRY(conv_igemm(h.delta.f(), HEAD_OUT, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, 1, 0, a.gx.f(),
+                      OUT_STORE, f1, s));
+    // PReLU backward of the head (+ bias gradient of the k x k conv)
+    FR_TRY(act_backward(a.gx.f(), a.x.f(), a.Cout, (long)a.Ho * a.Wo, w + a.a_off, nullptr, a.gx.f(),
+                        grad + a.b_off, grad + a.a_off, s));
+    FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, s));
+    double f3 = 2.0 * a.Cout * a.Cin * a.k * a.k * (double)a.Ho * a.Wo;
+    FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
+                      in.gpooled.f(), OUT_ADD, f3, s));  // nngraph fan-out: gradients add up
+  }
+  for (int b = nb - 1; b >= 0; --b) {
+    Block& blk = m->blocks[b];
+    for (int st = blk.nconv - 1; st >= 0; --st) {
+      Conv& c = m->convs[blk.first_conv + st];
+      const float* scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;
+      if (st == blk.nconv - 1) {
+        FR_TRY(maxpool_act_backward(blk.gpooled.f(), (const unsigned char*)blk.pidx.p, c.x.f(), c.Cout, c.Ho, c.Wo,
+                                    w + c.a_off, scale, c.gx.f(), grad + c.b_off, grad + c.a_off, s));
+      } else {
+        FR_TRY(act_backward(c.gx.f(), c.x.f(), c.Cout, (long)c.Ho * c.Wo, w + c.a_off, scale, c.gx.f(),
+                            grad + c.b_off, grad + c.a_off, s));
+      }
+      // accGradParameters: the input is the previous conv's x (activation fused) or a pooled map / image
+      const float* in; const float* in_slope = nullptr; const float* in_scale = nullptr;
+      if (st > 0) {
+        Conv& pc = m->convs[blk.first_conv + st - 1];
+        in = pc.x.f(); in_slope = w + pc.a_off;
+        in_scale = (st - 1 == 0 && blk.has_drop) ? blk.scale.f() : nullptr;
+      } else {
+        in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
+      }
+      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, s));
+      if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
+      double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
+      if (st > 0) {
+        Conv& pc = m->convs[blk.first_conv + st - 1];
+        FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
+                          c.k - 1 - c.pad, pc.gx.f(), OUT_STORE, fl, s));
+      } else {
+        FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
+                          c.k - 1 - c.pad, m->blocks[b - 1].gpooled.f(), OUT_ADD, fl, s));
+      }
+    }
+  }
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------ cnet
+static int ensure_cnet(frcnn_model* m, int R) {
+  for (auto& L : m->cls) {
+    size_t n = (size_t)R * L.n * 4;
+    FR_TRY(L.lin.ensure(n));
+    if (L.bn) { FR_TRY(L.pre.ensure(n)); FR_TRY(L.xhat.ensure(n)); FR_TRY(L.invstd.ensure((size_t)L.n * 4)); }
+    FR_TRY(L.post.ensure(n));
+    FR_TRY(L.g.ensure(n));
+    if (L.p_drop > 0.f) FR_TRY(L.mask.ensure(n));
+  }
+  int nc = m->d.class_count + 1;
+  int nf = m->cls.empty() ? m->D : m->cls.back().n;
+  FR_TRY(m->feat_g.ensure((size_t)R * nf * 4));
+  FR_TRY(m->logits.ensure((size_t)R * nc * 4));
+  FR_TRY(m->lsm.ensure((size_t)R * nc * 4));
+  FR_TRY(m->glog.ensure((size_t)R * nc * 4));
+  return FRCNN_OK;
+}
+
+int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int R, int training,
+                       const float* const* drop_masks, unsigned long long seed, float* bn_running,
+                       float* bbox_out, float* cls_out, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(R > 0, "cnet_forward: empty batch");
+  FR_TRY(ensure_cnet(m, R));
+  m->R = R; m->cnet_x = x; m->training = training;
+  const float* w = weights;
+  const float* cur = x;
+  float* bnr = bn_running;
+  for (size_t l = 0; l < m->cls.size(); ++l) {
+    ClsLayer& L = m->cls[l];
+    FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s));
+    const float* pre = L.lin.f();
+    if (L.bn) {
+      FR_CHECK(training || bnr, "cnet_forward: evaluate mode needs bn_running");
+      FR_TRY(bn_forward(L.lin.f(), R, L.n, w + L.bnw_off, w + L.bnb_off, bnr, training, L.xhat.f(), L.invstd.f(),
+                        L.pre.f(), s));
+      if (bnr) bnr += 2 * L.n;
+      pre = L.pre.f();
+    }
+    const float* mask = nullptr;
+    float inv_keep = 1.f;
+    if (training && L.p_drop > 0.f) {  // nn.Dropout v2: train = mask/(1-p), evaluate = identity [ext]
+      inv_keep = 1.0f / (1.0f - L.p_drop);
+      if (drop_masks && drop_masks[l])
+        FR_HIP(hipMemcpyAsync(L.mask.p, drop_masks[l], (size_t)R * L.n * 4, hipMemcpyDeviceToDevice, s));
+      else
+        FR_TRY(dropout_mask(L.mask.f(), (long)R * L.n, L.p_drop, seed * 977 + l + 17, s));
+      mask = L.mask.f();
+    }
+    FR_TRY(prelu_dropout_forward(pre, (long)R * L.n, w + L.a_off, mask, inv_keep, L.post.f(), s));
+    cur = L.post.f();
+  }
+  const int nf = m->cls.empty() ? m->D : m->cls.back().n;
+  const int nc = m->d.class_count + 1;
+  FR_TRY(gemm_f32(cur, nf, 1, w + m->bbox_w_off, 1, nf, bbox_out, 4, R, 4, nf, OUT_STORE, w + m->bbox_b_off, s));
+  FR_TRY(gemm_f32(cur, nf, 1, w + m->clsw_off, 1, nf, m->logits.f(), nc, R, nc, nf, OUT_STORE, w + m->clsb_off, s));
+  FR_TRY(log_softmax_rows(m->logits.f(), R, nc, m->lsm.f(), s));
+  FR_HIP(hipMemcpyAsync(cls_out, m->lsm.p, (size_t)R * nc * 4, hipMemcpyDeviceToDevice, s));
+  return FRCNN_OK;
+}
+
+int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbox, const float* g_cls, float* gx,
+                        float* grad, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(m->R > 0, "cnet_backward: call frcnn_cnet_forward first");
+  const int R = m->R;
+  const float* w = weights;
+  const int nf = m->cls.empty() ? m->D : m->cls.back().n;
+  const int nc = m->d.class_count + 1;
+  const float* feat = m->cls.empty() ? m->cnet_x : m->cls.back().post.f();
+  // bbox head
+  FR_TRY(gemm_f32(g_bbox, 4, 1, w + m->bbox_w_off, nf, 1, m->feat_g.f(), nf, R, nf, 4, OUT_STORE, nullptr, s));
+  FR_TRY(gemm_f32(g_bbox, 1, 4, feat, nf, 1, grad + m->bbox_w_off, nf, 4, nf, R, OUT_ADD, nullptr, s));
+  FR_TRY(channel_sum_cols(g_bbox, R, 4, grad + m->bbox_b_off, s));
+  // class head (LogSoftMax backward first)
+  FR_TRY(log_softmax_backward(g_cls, m->lsm.f(), R, nc, m->glog.f(), s));
+  FR_TRY(gemm_f32(m->glog.f(), nc, 1, w + m->clsw_off, nf, 1, m->feat_g.f(), nf, R, nf, nc, OUT_ADD, nullptr, s));
+  FR_TRY(gemm_f32(m->glog.f(), 1, nc, feat, nf, 1, grad + m->clsw_off, nf, nc, nf, R, OUT_ADD, nullptr, s));
+  FR_TRY(channel_sum_cols(m->glog.f(), R, nc, grad + m->clsb_off, s));
+  const float* g = m->feat_g.f();
+  for (int l = (int)m->cls.size() - 1; l >= 0; --l) {
+    ClsLayer& L = m->cls[l];
+    const float* pre = L.bn ? L.pre.f() : L.lin.f();
+    const bool drop = m->training && L.p_drop > 0.f;
+    FR_TRY(prelu_dropout_backward(g, pre, (long)R * L.n, w + L.a_off, drop ? L.mask.f() : nullptr,
+                                  drop ? 1.0f / (1.0f - L.p_drop) : 1.f, L.g.f(), grad + L.a_off, s));
+    if (L.bn)
+      FR_TRY(bn_backward(L.g.f(), L.xhat.f(), L.invstd.f(), w + L.bnw_off, R, L.n, m->training, L.g.f(),
+                         grad + L.bnw_off, grad + L.bnb_off, s));
+    const float* in = l == 0 ? m->cnet_x : m->cls[l - 1].post.f();
+    float* gin = l == 0 ? gx : m->cls[l - 1].post.f();  // post[l-1] is dead after this point: reuse as gradient
+    if (l > 0) {
+      // gradient wrt post[l-1] must not overwrite `in` before the weight gradient used it
+      FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
+      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
+      FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
+    } else {
+      FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
+      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
+      if (gin) FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
+    }
+    g = gin;
+  }
+  if (m->cls.empty() && gx) FR_HIP(hipMemcpyAsync(gx, g, (size_t)R * m->D * 4, hipMemcpyDeviceToDevice, s));
+  return FRCNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// nms.hip -- nms(boxes, overlap, scores) of the reference (nms.lua:23-102; callers
+// Detector.lua:82,133) as coalesced-HBM, wavefront-ballot kernels (no MFMA: this is compare /
+// gather work).  Survivor ids are BIT-EXACT with the reference's fp32 CPU arithmetic:
+//   area  = (x2 - x1 + 1) * (y2 - y1 + 1)                      nms.lua:35
+//   w     = max(0, (xx2 + (-1)*xx1) + 1), h likewise           nms.lua:85-86
+//   IoU   = (w*h) / ((area_j + area_i) - w*h), keep IoU <= t   nms.lua:89-96
+// every operation individually rounded to fp32 -- so FMA contraction is switched off for this
+// translation unit.  Sort key dispatch (nms.lua:37-43): column / 'area' / otherwise y2.
+// Tie rule (TH's quicksort is unstable, tie order unpinned by the reference): ascending key,
+// ties by ascending row id, picks taken from the end.
+//
+// Pipeline: (1) area+key, (2) O(n^2) rank sort (exact, stable, n <= ~64K), (3) 64x64 suppression
+// bit-matrix, upper triangle only, one wave per tile row-block, (4) single-workgroup scan that
+// resolves each 64-row group sequentially with readlane and ORs kept rows into the removed set.
+#pragma clang fp contract(off)
+#include "kernels.h"
+
+namespace frcnn {
+
+__global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, int ncols, int key_mode,
+                                int key_col, float* __restrict__ area, float* __restrict__ key) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* b = boxes + (size_t)i * ncols;
+  float dx = b[2] - b[0];
+  float dy = b[3] - b[1];
+  dx = dx + 1.0f;
+  dy = dy + 1.0f;
+  float a = dx * dy;
+  area[i] = a;
+  key[i] = key_mode == 2 ? b[key_col - 1] : (key_mode == 1 ? a : b[3]);
+}
+
+// rank[i] = #{ j : key[j] < key[i]  or (key[j] == key[i] and j < i) }; sorted[n-1-rank] = i
+__global__ void nms_rank_kernel(const float* __restrict__ key, int n, int* __restrict__ sorted) {
+  __shared__ float sk[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float ki = i < n ? key[i] : 0.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    int j = j0 + threadIdx.x;
+    sk[threadIdx.x] = j < n ? key[j] : 0.f;
+    __syncthreads();
+    int lim = min(256, n - j0);
+    for (int t = 0; t < lim; ++t) {
+      float kj = sk[t];
+      rank += (kj < ki || (kj == ki && (j0 + t) < i)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (i < n) sorted[n - 1 - rank] = i;
+}
+
+// mask[a][w] bit b: box at sorted position a suppresses box at sorted position w*64+b (b > a)
+__global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, const float* __restrict__ area,
+                                const int* __restrict__ sorted, int n, int nw, float thr,
+                                unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], car[64];
+  const int t = threadIdx.x;  // 64 threads = one wave
+  const int cpos = cb * 64 + t;
+  if (cpos < n) {
+    int j = sorted[cpos];
+    const float* b = boxes + (size_t)j * ncols;
+    cx1[t] = b[0]; cy1[t] = b[1]; cx2[t] = b[2]; cy2[t] = b[3]; car[t] = area[j];
+  }
+  __syncthreads();
+  const int rpos = rb * 64 + t;
+  if (rpos >= n) return;
+  const int i = sorted[rpos];
+  const float* bi = boxes + (size_t)i * ncols;
+  const float ix1 = bi[0], iy1 = bi[1], ix2 = bi[2], iy2 = bi[3], iar = area[i];
+  unsigned long long bits = 0ull;
+  const int lim = min(64, n - cb * 64);
+  for (int c = 0; c < lim; ++c) {
+    if (cb * 64 + c <= rpos) continue;
+    float xx1 = cx1[c] > ix1 ? cx1[c] : ix1;  // cmax, nms.lua:78
+    float yy1 = cy1[c] > iy1 ? cy1[c] : iy1;
+    float xx2 = cx2[c] < ix2 ? cx2[c] : ix2;  // cmin, nms.lua:80
+    float yy2 = cy2[c] < iy2 ? cy2[c] : iy2;
+    float w = xx2 + (-1.0f) * xx1;
+    w = w + 1.0f;
+    w = w > 0.0f ? w : 0.0f;
+    float h = yy2 + (-1.0f) * yy1;
+    h = h + 1.0f;
+    h = h > 0.0f ? h : 0.0f;
+    float inter = w * h;
+    float denom = car[c] + iar;
+    denom = denom - inter;
+    float iou = inter / denom;
+    if (!(iou <= thr)) bits |= 1ull << c;
+  }
+  mask[(size_t)rpos * nw + cb] = bits;
+}
+
+__global__ void nms_reduce_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ sorted,
+                                  int n, int nw, long long* __restrict__ pick, int* __restrict__ count) {
+  extern __shared__ unsigned long long removed[];  // [nw]
+  __shared__ unsigned long long kept_bits;
+  __shared__ int cnt;
+  for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int g = 0; g < nw; ++g) {
+    if (threadIdx.x < 64) {  // wave 0 resolves the diagonal block sequentially
+      const int row = g * 64 + threadIdx.x;
+      unsigned long long diag = row < n ? mask[(size_t)row * nw + g] : 0ull;
+      unsigned long long word = removed[g];
+      unsigned long long kept = 0ull;
+      const int lim = min(64, n - g * 64);
+      for (int t = 0; t < lim; ++t) {
+        unsigned long long dt = __shfl(diag, t, 64);
+        if (!((word >> t) & 1ull)) {
+          kept |= 1ull << t;
+          word |= dt;
+        }
+      }
+      // emit picks in order
+      int base = cnt;
+      if ((kept >> threadIdx.x) & 1ull) {
+        int before = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
+        pick[base + before] = (long long)sorted[row] + 1;  // 1-based like the Lua surface
+      }
+      if (threadIdx.x == 0) {
+        kept_bits = kept;
+        cnt = base + __popcll(kept);
+      }
+    }
+    __syncthreads();
+    const unsigned long long kept = kept_bits;
+    if (kept) {
+      for (int w = g + 1 + threadIdx.x; w < nw; w += blockDim.x) {
+        unsigned long long acc = removed[w];
+        unsigned long long k = kept;
+        while (k) {
+          int t = __ffsll((long long)k) - 1;
+          k &= k - 1;
+          acc |= mask[(size_t)(g * 64 + t) * nw + w];
+        }
+        removed[w] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = cnt;
+}
+
+size_t nms_workspace_bytes(int n) {
+  size_t nw = (size_t)cdiv(n, 64);
+  size_t b = 0;
+  b += (size_t)n * 4 * 3;          // area, key, sorted
+  b = (b + 255) / 256 * 256;
+  b += (size_t)n * nw * 8;         // mask
+  return b + 256;
+}
+
+int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (n <= 0) {  // nms.lua:26-28
+    FR_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+    return FRCNN_OK;
+  }
+  FR_CHECK(ncols >= 4, "nms: boxes need >= 4 columns (got %d)", ncols);
+  FR_CHECK(key_mode >= 0 && key_mode <= 2, "nms: bad key_mode %d", key_mode);
+  FR_CHECK(key_mode != 2 || (key_col >= 1 && key_col <= ncols), "nms: key column %d out of range", key_col);
+  FR_CHECK(ws_bytes >= nms_workspace_bytes(n), "nms: workspace too small (%zu < %zu)", ws_bytes,
+           nms_workspace_bytes(n));
+  const int nw = cdiv(n, 64);
+  FR_CHECK((size_t)nw * 8 <= 64 * 1024, "nms: n=%d too large (max 524288)", n);
+  char* base = (char*)(((uintptr_t)ws + 255) / 256 * 256);
+  float* area = (float*)base;
+  float* key = area + n;
+  int* sorted = (int*)(key + n);
+  size_t off = ((size_t)n * 12 + 255) / 256 * 256;
+  unsigned long long* mask = (unsigned long long*)(base + off);
+  double pair_bytes = 20.0 * n;
+  FR_LAUNCH(KC_NMS, 0, pair_bytes, s, nms_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, boxes, n, ncols,
+            key_mode, key_col, area, key);
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, key, n, sorted);
+  FR_LAUNCH(KC_NMS, 3.5 * n * (double)n, 8.0 * n * nw / 2, s, nms_mask_kernel, dim3(nw, nw), dim3(64), 0,
+            boxes, ncols, area, sorted, n, nw, overlap, mask);
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(256), (size_t)nw * 8, mask,
+            sorted, n, nw, pick, count);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn

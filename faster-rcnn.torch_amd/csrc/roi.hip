@@ -1,0 +1,77 @@
+// roi.hip -- nn.SpatialAdaptiveMaxPooling(kw,kh) applied to the strided sub-window that
+// extract_roi_pooling_input() cuts out of the last feature map (objective.lua:5-13,117-118,
+// 137-138,182-185; Detector.lua:96-97), batched: ONE launch pools every ROI of an image instead
+// of the reference's per-ROI module call.  Gather/argmax work, no MFMA; reads hit the 2.2 MB map
+// in L2, writes are R x C*kh*kw contiguous rows (the cnet input batch).
+#include "kernels.h"
+
+namespace frcnn {
+
+// wins[r] = {row_lo,row_hi,col_lo,col_hi}: 1-based inclusive, exactly the idx table of
+// objective.lua:11.  Cell (i,j) covers rows [floor(i*h/kh), ceil((i+1)*h/kh)) of the window;
+// first max wins (strict >) in row-major scan order.  idx = flat y*W+x in map coordinates.
+__global__ void roi_pool_forward_kernel(const float* __restrict__ fmap, int C, int H, int W,
+                                        const int* __restrict__ wins, int R, int kh, int kw,
+                                        float* __restrict__ out, int* __restrict__ idx) {
+  const long total = (long)R * C * kh * kw;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int j = (int)(t % kw);
+    long q = t / kw;
+    int i = (int)(q % kh);
+    q /= kh;
+    int c = (int)(q % C);
+    int r = (int)(q / C);
+    const int* wn = wins + 4 * r;
+    const int r0 = wn[0] - 1, c0 = wn[2] - 1;
+    const int h = wn[1] - wn[0] + 1, w = wn[3] - wn[2] + 1;
+    const int ys = (i * h) / kh, ye = ((i + 1) * h + kh - 1) / kh;
+    const int xs = (j * w) / kw, xe = ((j + 1) * w + kw - 1) / kw;
+    const float* ip = fmap + (size_t)c * H * W;
+    float best = -3.402823466e+38f;
+    int bi = -1;
+    for (int y = ys; y < ye; ++y)
+      for (int x = xs; x < xe; ++x) {
+        float v = ip[(size_t)(r0 + y) * W + (c0 + x)];
+        if (v > best) { best = v; bi = (r0 + y) * W + (c0 + x); }
+      }
+    out[t] = best;
+    idx[t] = bi;
+  }
+}
+
+int roi_pool_forward(const float* fmap, int C, int H, int W, const int* wins, int R, int kh, int kw,
+                     float* out, int* idx, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  long total = (long)R * C * kh * kw;
+  int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+  FR_LAUNCH(KC_ROI, 0, total * 8.0, s, roi_pool_forward_kernel, dim3(grid), dim3(256), 0, fmap, C, H, W,
+            wins, R, kh, kw, out, idx);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// delta_outputs[5][idx]:add(amp:backward(...))  (objective.lua:182-185): windows of different
+// ROIs overlap, so this is a scatter-ADD; fp32 atomics in L2.
+__global__ void roi_pool_backward_kernel(float* __restrict__ gmap, int C, long HW,
+                                         const float* __restrict__ gout, const int* __restrict__ idx,
+                                         long total, int cell) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int c = (int)((t / cell) % C);
+    int bi = idx[t];
+    float g = gout[t];
+    if (bi >= 0 && g != 0.f) unsafeAtomicAdd(gmap + (size_t)c * HW + bi, g);
+  }
+}
+
+int roi_pool_backward(float* gmap, int C, int H, int W, const float* gout, const int* idx, int R,
+                      int kh, int kw, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  long total = (long)R * C * kh * kw;
+  int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+  FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_kernel, dim3(grid), dim3(256), 0, gmap, C,
+            (long)H * W, gout, idx, total, kh * kw);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn

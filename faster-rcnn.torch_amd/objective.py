@@ -1,0 +1,200 @@
+"""extract_roi_pooling_input and create_objective -- host-side mirror of objective.lua.
+
+lossAndGradient(w) keeps the structure of objective.lua:45-218 (per image: pnet forward, sparse RPN
+loss on the sampled anchors, ROI adaptive max-pooling, cnet forward/backward, ROI-pool backward,
+pnet backward; then normalise and log), but every per-example Lua loop that touched the device one
+scalar at a time is ONE batched kernel here (frcnn_rpn_loss, frcnn_roi_pool_forward/backward,
+frcnn_cnet_losses), and the eight statistics of objective.lua:52-58 stay in a device-side fp64
+vector until the single read-back at the end of the call.
+
+Data parallelism (not in the reference): when torch.distributed is initialised, every
+rank processes its own images and the flat gradient + the 8 accumulators are all-reduced (sum) just
+before `gradient:div(cls_count)` (objective.lua:200), so the result equals the single-process result
+on the concatenated batch."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .Anchors import Anchors
+from .Localizer import Localizer
+from .Rect import Rect
+from .tensor import DeviceTensor, ptr, stream_ptr, to_device
+
+
+def roi_window(input_rect, localizer, fm_h, fm_w):
+    """The index table of objective.lua:11: rows {min(minY+1,maxY), maxY}, cols {min(minX+1,maxX), maxX}
+    (1-based inclusive) of the feature map covered by input_rect."""
+    r = localizer.inputToFeatureRect(input_rect)
+    r = r.clip(Rect(0, 0, fm_w, fm_h))
+    return (int(min(r.minY + 1, r.maxY)), int(r.maxY), int(min(r.minX + 1, r.maxX)), int(r.maxX))
+
+
+def extract_roi_pooling_input(input_rect, localizer, feature_layer_output):  # objective.lua:5-13
+    """Returns (window, idx): idx = {{}, {row_lo,row_hi}, {col_lo,col_hi}} like the reference; the strided
+    view itself is never materialised -- the batched ROI-pool kernel reads the window in place."""
+    s = feature_layer_output.shape
+    win = roi_window(input_rect, localizer, s[1], s[2])
+    idx = ((), (win[0], win[1]), (win[2], win[3]))
+    return win, idx
+
+
+class _Scratch(object):
+    """Per-objective device scratch that grows on demand (no allocation in the steady state)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=np.float32):
+        need = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        b = self.bufs.get(name)
+        if b is None or b.nbytes < need:
+            b = DeviceTensor.empty((max(need, 256),), np.uint8)
+            self.bufs[name] = b
+        return DeviceTensor(b.ptr, shape, dtype, owner=b)
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def create_objective(model, weights, gradient, batch_iterator, stats):  # objective.lua:15
+    cfg = model["cfg"]
+    pnet = model["pnet"]
+    cnet = model["cnet"]
+    native = model["native"]
+    bgclass = cfg["class_count"] + 1  # :20
+    localizer = Localizer(pnet.outnode.children[4] if len(pnet.outnode.children) == 5
+                          else pnet.outnode.children[-1])  # :22 children[5]
+    kh, kw = cfg["roi_pooling"]["kh"], cfg["roi_pooling"]["kw"]
+    cnet_input_planes = model["layers"][-1]["filters"]
+    D = kh * kw * cnet_input_planes
+    ncls = cfg["class_count"] + 1
+    scratch = _Scratch()
+    acc_dev = DeviceTensor.zeros((8,), np.float64)
+    L = _lib.load()
+
+    def cleanAnchors(examples, outputs):  # objective.lua:32-43
+        return [e for e in examples
+                if not (e[0].index[1] > outputs[e[0].layer - 1].shape[1] or e[0].index[2] > outputs[e[0].layer - 1].shape[2])]
+
+    def lossAndGradient(w):
+        import torch
+        if w is not weights:  # :46-48
+            weights.copy_(w)
+        s = stream_ptr()
+        _lib.call("frcnn_zero", ptr(gradient), gradient.numel() * 4, s)  # :49
+        acc_dev.zero_()
+        cls_count = reg_count = creg_count = ccls_count = 0
+        pnet.training()  # :61-62
+        cnet.training()
+        batch = batch_iterator.nextTraining()  # :64
+        for x in batch:
+            img = to_device(x["img"])  # :66
+            outputs = pnet.forward(img)  # :71
+            p = cleanAnchors(x["positive"], outputs)  # :74-75
+            n = cleanAnchors(x["negative"], outputs)
+            delta_outputs = pnet.delta_outputs(zero=True)  # :78-84
+            npos, nneg = len(p), len(n)
+            E = npos + nneg
+            fm = outputs[-1]
+            fmC, fmH, fmW = fm.shape
+            if E > 0:
+                # ---- host: pack the example tables (one H2D copy) ----------------------------
+                ex_idx = np.zeros((E, 4), dtype=np.int32)
+                ex_anchor = np.zeros((E, 4), dtype=np.float64)
+                ex_roi = np.zeros((max(npos, 1), 4), dtype=np.float64)
+                ex_class = np.zeros(max(npos, 1), dtype=np.int32)
+                wins = np.zeros((E, 4), dtype=np.int32)
+                for i, e in enumerate(p):
+                    a, roi = e[0], e[1]
+                    ex_idx[i] = (a.layer, a.aspect, a.index[1], a.index[2])
+                    ex_anchor[i] = (a.minX, a.minY, a.maxX, a.maxY)
+                    ex_roi[i] = (roi.rect.minX, roi.rect.minY, roi.rect.maxX, roi.rect.maxY)
+                    ex_class[i] = roi.class_index
+                    wins[i] = roi_window(roi.rect, localizer, fmH, fmW)  # :117 positives pool the GT rect
+                for j, e in enumerate(n):
+                    a = e[0]
+                    i = npos + j
+                    ex_idx[i] = (a.layer, a.aspect, a.index[1], a.index[2])
+                    ex_anchor[i] = (a.minX, a.minY, a.maxX, a.maxY)
+                    wins[i] = roi_window(a, localizer, fmH, fmW)  # :137 negatives pool the anchor rect
+                blob = np.concatenate([ex_anchor.view(np.uint8).ravel(), ex_roi.view(np.uint8).ravel(),
+                                       ex_idx.view(np.uint8).ravel(), ex_class.view(np.uint8).ravel(),
+                                       wins.view(np.uint8).ravel()])
+                dblob = scratch.get("blob", (blob.size,), np.uint8)
+                dblob.copy_from_numpy(blob)
+                o = 0
+                d_anchor = dblob.ptr + o; o += ex_anchor.nbytes
+                d_roi = dblob.ptr + o; o += ex_roi.nbytes
+                d_idx = dblob.ptr + o; o += ex_idx.nbytes
+                d_class = dblob.ptr + o; o += ex_class.nbytes
+                d_wins = dblob.ptr + o
+                # ---- RPN loss on the sampled anchors (objective.lua:91-140) ------------------
+                maps = (C.c_void_p * 4)(*[outputs[i].ptr for i in range(4)])
+                deltas = (C.c_void_p * 4)(*[delta_outputs[i].ptr for i in range(4)])
+                Hs = (C.c_int * 4)(*[outputs[i].shape[1] for i in range(4)])
+                Ws = (C.c_int * 4)(*[outputs[i].shape[2] for i in range(4)])
+                ex_loss = scratch.get("ex_loss", (E, 2), np.float64)
+                crtarget = scratch.get("crtarget", (E, 4))
+                cctarget = scratch.get("cctarget", (E,))
+                _lib.call("frcnn_rpn_loss", maps, deltas, Hs, Ws, C.c_void_p(d_idx), C.c_void_p(d_anchor),
+                          C.c_void_p(d_roi), C.c_void_p(d_class), npos, nneg, bgclass, ptr(ex_loss), ptr(crtarget),
+                          ptr(cctarget), s)
+                _accumulate_losses(ex_loss, E, acc_dev, s)
+                # ---- ROI pooling of every example in one launch (:117-119, :137-139) ---------
+                cinput = scratch.get("cinput", (E, D))
+                pidx = scratch.get("pidx", (E, D), np.int32)
+                _lib.call("frcnn_roi_pool_forward", ptr(fm), fmC, fmH, fmW, C.c_void_p(d_wins), E, kh, kw,
+                          ptr(cinput), ptr(pidx), s)
+                # ---- fine-tuning stage (:146-186) --------------------------------------------
+                coutputs = cnet.forward(cinput)  # :164
+                crout, ccout = coutputs
+                crdelta = scratch.get("crdelta", (E, 4))
+                ccdelta = scratch.get("ccdelta", (E, ncls))
+                _lib.call("frcnn_cnet_losses", ptr(crout), ptr(crtarget), ptr(ccout), ptr(cctarget), E, npos, ncls,
+                          ptr(crdelta), ptr(ccdelta), C.c_void_p(acc_dev.ptr + 4 * 8), s)  # :170-177
+                post_roi_delta = cnet.backward(cinput, [crdelta, ccdelta])  # :179
+                _lib.call("frcnn_roi_pool_backward", ptr(delta_outputs[4]), fmC, fmH, fmW, ptr(post_roi_delta),
+                          ptr(pidx), E, kh, kw, s)  # :182-185
+            pnet.backward(img, delta_outputs)  # :189
+            reg_count += npos  # :194-198
+            cls_count += npos + nneg
+            creg_count += npos
+            ccls_count += 1
+
+        # ---- statistics: one read-back per call ------------------------------------------
+        a = acc_dev.numpy()
+        tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
+        dist = _dist()
+        if dist is not None:  # DP: sum the flat gradient and the 8 accumulators over ranks
+            t = torch.from_numpy(tot).to(gradient.device)
+            dist.all_reduce(gradient)
+            dist.all_reduce(t)
+            tot = t.cpu().numpy()
+        cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
+        if cls_count > 0:
+            _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pcls = float(np.float64(cls_loss) / cls_count)  # :202-205
+            preg = float(np.float64(reg_loss) / reg_count)
+            dcls = float(np.float64(ccls_loss) / ccls_count)
+            dreg = float(np.float64(creg_loss) / creg_count)
+        if stats.get("verbose"):
+            print("prop: cls: %f (%d), reg: %f (%d); det: cls: %f, reg: %f" % (pcls, cls_count, preg, reg_count, dcls, dreg))
+        stats["pcls"].append(pcls); stats["preg"].append(preg)  # :211-214
+        stats["dcls"].append(dcls); stats["dreg"].append(dreg)
+        return pcls + preg, gradient  # :216-217
+
+    return lossAndGradient
+
+
+def _accumulate_losses(ex_loss, E, acc_dev, s):
+    """acc[0] += sum cls, acc[1] += sum reg (objective.lua:104,112,132), on device, fixed order."""
+    _lib.call("frcnn_loss_accumulate", ptr(ex_loss), E, ptr(acc_dev), s)

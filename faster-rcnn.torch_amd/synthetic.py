@@ -1,0 +1,95 @@
+"""Synthetic stand-in for BatchIterator (BatchIterator.lua is a file-IO data loader and out of
+scope): produces batches with the structure objective.lua:64-69 consumes --
+{img, positive, negative} -- from seeded synthetic frames and ground-truth boxes, running the same
+example assembly as BatchIterator.lua:198-225 (findPositive, 16 sampled negatives, nearby_aversion)
+through the host-side Anchors mirror.  Inputs follow SURVEY 8d: image iid N(0,1) with seed
+1000+index; 4 boxes per image drawn from the config's scales x {1:1, 2:1, 1:2} with +-20% jitter,
+fully inside the image, class uniform in 1..class_count, seed 7."""
+import math
+
+import numpy as np
+
+from .Anchors import Anchors, MT19937
+from .Rect import Rect
+
+
+class Roi(object):
+    def __init__(self, rect, class_index):
+        self.rect = rect
+        self.class_index = class_index
+
+
+def synthetic_rois(cfg, W, H, count=4, seed=7, index=0):
+    rng = np.random.RandomState(seed + 7919 * index)
+    rois = []
+    scales = [s for s in cfg["scales"] if s * 1.2 * math.sqrt(2) < min(W, H)] or [min(cfg["scales"])]
+    for _ in range(count):
+        s = scales[rng.randint(len(scales))]
+        a = s / math.sqrt(2)
+        bw, bh = [(s, s), (2 * a, a), (a, 2 * a)][rng.randint(3)]
+        bw *= rng.uniform(0.8, 1.2); bh *= rng.uniform(0.8, 1.2)
+        bw = min(bw, W - 2); bh = min(bh, H - 2)
+        x = rng.uniform(0, W - bw); y = rng.uniform(0, H - bh)
+        r = Rect(math.floor(x), math.floor(y), math.floor(x + bw), math.floor(y + bh))
+        rois.append(Roi(r, int(rng.randint(1, cfg["class_count"] + 1))))
+    return rois
+
+
+def synthetic_image(H, W, index=0):
+    return np.random.RandomState(1000 + index).randn(3, H, W).astype(np.float32)
+
+
+def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16):
+    """BatchIterator.lua:198-225 for one image."""
+    img_rect = Rect(0, 0, W, H)
+    positive = anchors.findPositive(rois, img_rect, cfg["positive_threshold"], cfg["negative_threshold"], cfg["best_match"])
+    negative = anchors.sampleNegative(img_rect, rois, cfg["negative_threshold"], negatives, rng)
+    count = len(positive) + len(negative)
+    if cfg.get("nearby_aversion"):
+        nearby = []
+        for p in positive:
+            cx, cy = p[0].center()
+            for a in anchors.findNearby(cx, cy):
+                if Rect.IoU(p[0], a) < cfg["negative_threshold"]:
+                    nearby.append((a,))
+        c = min(len(positive), count)
+        c = min(c, len(nearby))
+        # shuffle_n (utilities.lua:31-42) with the MT19937 stream instead of LuaJIT's math.random
+        r = len(nearby)
+        for i in range(c):
+            j = rng.random() % r + i
+            nearby[i], nearby[j] = nearby[j], nearby[i]
+            r -= 1
+        negative.extend(nearby[:c])
+    return positive, negative
+
+
+class SyntheticBatchIterator(object):
+    """nextTraining() -> list of {img, positive, negative}.  `images_per_batch` images per call; with
+    data parallelism rank r of world_size W takes images r, r+W, ... of the step's list."""
+
+    def __init__(self, model, H=450, W=800, images_per_batch=1, rank=0, world_size=1, pool=4, device_images=True):
+        self.cfg = model["cfg"]
+        self.anchors = Anchors(model["pnet"], self.cfg["scales"])
+        self.H, self.W = H, W
+        self.images_per_batch = images_per_batch
+        self.rank, self.world_size = rank, world_size
+        self.i = 0
+        self.pool = []
+        rng = MT19937(7)
+        for k in range(pool):
+            idx = rank * pool + k
+            rois = synthetic_rois(self.cfg, W, H, 4, 7, idx)
+            pos, neg = assemble_examples(self.anchors, self.cfg, rois, W, H, rng)
+            img = synthetic_image(H, W, idx)
+            if device_images:
+                from .tensor import DeviceTensor
+                img = DeviceTensor.from_numpy(img)
+            self.pool.append(dict(img=img, positive=pos, negative=neg, rois=rois))
+
+    def nextTraining(self, count=None):
+        batch = []
+        for _ in range(self.images_per_batch):
+            batch.append(self.pool[self.i % len(self.pool)])
+            self.i += 1
+        return batch

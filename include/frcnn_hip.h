@@ -1,0 +1,237 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) Faster R-CNN detection/training
+ * hot path of andreaskoepf/faster-rcnn.torch.
+ *
+ * The reference has no FFI of its own: its hot path reaches its arithmetic through the Torch7
+ * Lua object protocol (nn.Module:forward/backward, nn.SpatialAdaptiveMaxPooling, criteria,
+ * nms(), optim.rmsprop) implemented by the un-vendored cunn/cutorch packages.  This header is
+ * the boundary a LuaJIT `ffi.cdef` -- or any other host -- binds in their
+ * place.  Each entry point names the reference call site it replaces (file:line in the
+ * reference tree).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *  - Every function returns FRCNN_OK (0) or an FRCNN_ERR_* code; frcnn_last_error() returns a
+ *    thread-local message that a Lua wrapper turns into error().
+ *  - Pointers are DEVICE pointers unless the parameter name ends in _host.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All work is
+ *    asynchronous on that stream unless a function says it synchronises.
+ *  - Tensors are fp32, CHW (or row-major R x D), contiguous, exactly like the reference's
+ *    CudaTensors.  Index values exchanged through this ABI are 1-based like the Lua surface
+ *    wherever the reference's own tables are 1-based (anchor indices, NMS ids, ROI windows,
+ *    class ids); this is stated per function.
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_ERR_ARG 1
+#define FRCNN_ERR_HIP 2
+#define FRCNN_ERR_STATE 3
+
+/* ---- library / device --------------------------------------------------------------- */
+int frcnn_version(void);
+const char *frcnn_last_error(void);
+int frcnn_device_count(int *n);
+int frcnn_set_device(int device);            /* cutorch.setDevice, main.lua:52 (0-based here) */
+int frcnn_device_name(char *buf_host, int len);
+
+/* ---- device buffers (torch.CudaTensor storage; main.lua:86-89, objective.lua:66,147-149) */
+int frcnn_malloc(void **ptr_out_host, size_t bytes);
+int frcnn_free(void *ptr);
+int frcnn_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
+int frcnn_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
+int frcnn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int frcnn_stream_sync(void *stream);
+int frcnn_zero(void *ptr, size_t bytes, void *stream);            /* gradient:zero(), objective.lua:49 */
+int frcnn_scale(float *x, long long n, float s, void *stream);    /* gradient:div(n), objective.lua:200 */
+
+/* ---- per-kernel-class HIP-event profile (bench.py roofline leg) ---------------------- */
+#define FRCNN_KC_CONV_IGEMM_K3 0
+#define FRCNN_KC_CONV_IGEMM_OTHER 1
+#define FRCNN_KC_CONV_WGRAD_K3 2
+#define FRCNN_KC_CONV_WGRAD_OTHER 3
+#define FRCNN_KC_GEMM 4
+#define FRCNN_KC_ELEMWISE 5
+#define FRCNN_KC_ROI 6
+#define FRCNN_KC_RPN 7
+#define FRCNN_KC_NMS 8
+#define FRCNN_KC_OPTIM 9
+#define FRCNN_KC_COUNT 10
+int frcnn_prof_enable(int on);   /* brackets every kernel launch with hipEvents on its stream */
+/* Synchronises the device; per class: launches, total ms, algorithmic flops, algorithmic bytes.
+ * Arrays of FRCNN_KC_COUNT entries (host).  Resets the profile. */
+int frcnn_prof_collect(long long *launches_host, double *ms_host, double *flops_host,
+                       double *bytes_host);
+
+/* ---- nms(boxes, overlap, scores): nms.lua:23-102 ------------------------------------- */
+/* key_mode: 0 = y2 (what every reference call site gets, Detector.lua:82,133: a tensor/nil
+ * `scores` falls through to nms.lua:42), 1 = 'area' (nms.lua:39-40), 2 = column key_col
+ * (1-based; nms.lua:37-38).  pick: int64[n] of 1-based row ids in pick order; *count = number
+ * picked.  Bit-exact with the reference's fp32 CPU arithmetic. */
+size_t frcnn_nms_workspace_bytes(int n);
+int frcnn_nms_device(const float *boxes, int n, int ncols, float overlap, int key_mode,
+                     int key_col, long long *pick, int *count, void *workspace,
+                     size_t workspace_bytes, void *stream);
+/* Host-pointer variant (the reference's nms runs on CPU FloatTensors): uploads, runs the same
+ * kernels, downloads, synchronises. */
+int frcnn_nms_host(const float *boxes_host, int n, int ncols, float overlap, int key_mode,
+                   int key_col, long long *pick_host, int *count_host);
+
+/* ---- nn.SpatialConvolution (models/model_utilities.lua:8,31,33) ---------------------- */
+/* out[O][Ho][Wo] = bias + W (*) act(in), Ho = H + 2*pad - k + 1.  act(x) = in_scale[c] *
+ * prelu(x, *in_slope) is the producing layer's nn.PReLU + nn.SpatialDropout fused into the
+ * load (pass NULL for identity).  weight is the canonical [O][C][k][k] tensor.  k in {1,3,5,7},
+ * stride 1.  :updateOutput, reached from objective.lua:71 / Detector.lua:33. */
+int frcnn_conv2d_forward(const float *in, int C, int H, int W, const float *in_slope,
+                         const float *in_scale, const float *weight, const float *bias, int O,
+                         int k, int pad, float *out, void *stream);
+/* :updateGradInput (objective.lua:189): gin[C][H][W] = W^T (*) gout. accumulate!=0 -> += */
+int frcnn_conv2d_backward_input(const float *gout, int O, int Ho, int Wo, const float *weight,
+                                int C, int k, int pad, float *gin, int accumulate, void *stream);
+/* :accGradParameters (objective.lua:189): gweight += gout (x) act(in); gbias += sum gout. */
+int frcnn_conv2d_backward_weight(const float *in, int C, int H, int W, const float *in_slope,
+                                 const float *in_scale, const float *gout, int O, int k, int pad,
+                                 float *gweight, float *gbias, void *stream);
+
+/* ---- nn.PReLU + nn.SpatialDropout + nn.SpatialMaxPooling(2,2,2,2):ceil()
+ *      (models/model_utilities.lua:9-12,23) -------------------------------------------- */
+/* out = maxpool2x2_ceil(in_scale[c]*prelu(x)); idx[c][oy][ox] = dy*2+dx of the (first) max. */
+int frcnn_maxpool_act_forward(const float *x, int C, int H, int W, const float *slope,
+                              const float *scale, float *out, unsigned char *idx, void *stream);
+/* gx = unpool(gpool) * scale[c] * prelu'(x); gbias[c] += sum gx; *gslope += sum_{x<=0} x*g. */
+int frcnn_maxpool_act_backward(const float *gpool, const unsigned char *idx, const float *x, int C,
+                               int H, int W, const float *slope, const float *scale, float *gx,
+                               float *gbias, float *gslope, void *stream);
+int frcnn_act_forward(const float *x, int C, long long hw, const float *slope, const float *scale,
+                      float *y, void *stream);
+int frcnn_act_backward(const float *gy, const float *x, int C, long long hw, const float *slope,
+                       const float *scale, float *gx, float *gbias, float *gslope, void *stream);
+
+/* ---- extract_roi_pooling_input + nn.SpatialAdaptiveMaxPooling, batched over ROIs
+ *      (objective.lua:5-13,117-118,137-138,182-185; Detector.lua:96-97) ----------------- */
+/* wins: int[R][4] = {row_lo,row_hi,col_lo,col_hi}, 1-based inclusive (objective.lua:11).
+ * out: [R][C*kh*kw] (row r = amp:forward(view):view(kh*kw*C)); idx: int[R][C*kh*kw], flat
+ * 0-based y*W+x position of each max inside the full map (amp.indices equivalent). */
+int frcnn_roi_pool_forward(const float *fmap, int C, int H, int W, const int *wins, int R, int kh,
+                           int kw, float *out, int *idx, void *stream);
+/* gmap[C][H][W] += scatter(gout) -- delta_outputs[5][idx]:add(amp:backward(...)) */
+int frcnn_roi_pool_backward(float *gmap, int C, int H, int W, const float *gout, const int *idx,
+                            int R, int kh, int kw, void *stream);
+
+/* ---- RPN anchor scan: Detector.lua:39-66 --------------------------------------------- */
+/* maps_host: 4 device pointers to the [18][H_l][W_l] head outputs (pnet outputs 1..4).
+ * anchor_w / anchor_h: the fp32 tables of Anchors.lua:18-19, [4][3][200][2].
+ * Outputs in scan order (layer, y, x, aspect), at most cap entries:
+ *   match_p[i]    = c[1] (log-prob of foreground)
+ *   match_idx[i]  = {layer, aspect, y, x} 1-based (Anchors:get arguments)
+ *   match_rect[i] = decoded rect as doubles (Lua numbers), {minX,minY,maxX,maxY}
+ *   match_box[i]  = the same as fp32 (the FloatTensor row of Detector.lua:74-79, NMS input)
+ *   *count        = number of matches found (may exceed cap; only cap are written) */
+size_t frcnn_rpn_scan_workspace_bytes(const int *H_host, const int *W_host);
+int frcnn_rpn_scan(const float *const *maps_host, const int *H_host, const int *W_host,
+                   const float *anchor_w, const float *anchor_h, double img_w, double img_h,
+                   double p_threshold, int cap, float *match_p, int *match_idx,
+                   double *match_rect, float *match_box, int *count, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ---- sparse RPN loss: objective.lua:91-140 (+ cnet targets, objective.lua:149-159) ---- */
+/* Examples: positives first (npos) then negatives (nneg).  ex_idx int[E][4] {layer,aspect,y,x}
+ * 1-based; ex_anchor double[E][4]; ex_roi double[npos][4] (roi.rect of each positive);
+ * ex_class int[npos] (roi.class_index).  deltas_host: 4 device pointers to delta_outputs[1..4]
+ * (gradients are ADDED).  ex_loss double[E][2] = {cls, reg*10}; crtarget float[E][4];
+ * cctarget float[E] (class index, bgclass for negatives). */
+int frcnn_rpn_loss(const float *const *maps_host, float *const *deltas_host, const int *H_host,
+                   const int *W_host, const int *ex_idx, const double *ex_anchor,
+                   const double *ex_roi, const int *ex_class, int npos, int nneg, int bgclass,
+                   double *ex_loss, float *crtarget, float *cctarget, void *stream);
+
+/* acc[0] += sum_e ex_loss[e][0]; acc[1] += sum_e ex_loss[e][1] (device fp64; the Lua accumulators
+ * cls_loss / reg_loss of objective.lua:52, summed in example order). */
+int frcnn_loss_accumulate(const double *ex_loss, int E, double *acc, void *stream);
+
+/* ---- nn.Linear (models/model_utilities.lua:82,99,103) -------------------------------- */
+int frcnn_linear_forward(const float *x, int R, int I, const float *weight, const float *bias,
+                         int O, float *y, void *stream);
+/* gx (may be NULL) = gy W ; gweight += gy^T x ; gbias += colsum(gy) (either may be NULL) */
+int frcnn_linear_backward(const float *x, const float *gy, int R, int I, const float *weight,
+                          int O, float *gx, float *gweight, float *gbias, void *stream);
+
+/* ---- optim.rmsprop (main.lua:122,133): m = a*m + (1-a)*g^2 ; x -= lr*g/(sqrt(m)+eps) -- */
+int frcnn_rmsprop(float *x, const float *g, float *m, long long n, float lr, float alpha,
+                  float eps, void *stream);
+
+/* ---- model runtime: models/model_utilities.lua:3-136 --------------------------------- */
+typedef struct {
+  int nblocks;                      /* vgg_small.lua:5-10 `layers` */
+  int filters[8], ksize[8], pad[8], conv_steps[8];
+  float dropout[8];
+  int nheads;                       /* vgg_small.lua:12-17 `anchor_nets` */
+  int head_k[8], head_n[8], head_input[8]; /* head_input 1-based */
+  int ncls;                         /* vgg_small.lua:19-22 `class_layers` */
+  int cls_n[8], cls_bn[8];
+  float cls_dropout[8];
+  int class_count;                  /* cfg.class_count (excluding background) */
+  int kh, kw;                       /* cfg.roi_pooling */
+} frcnn_model_desc;
+
+typedef struct frcnn_model frcnn_model;
+
+int frcnn_model_create(const frcnn_model_desc *desc_host, frcnn_model **out_host);
+int frcnn_model_destroy(frcnn_model *);
+/* Flat parameter vector (utilities.lua:136-147): total and pnet-only element counts. */
+int frcnn_model_param_count(const frcnn_model *, long long *total_host, long long *pnet_host);
+/* Parameter table, one row per tensor in flat order: {offset, count, kind, aux}.
+ * kind: 0 conv weight (aux = kW*kH*nOutputPlane, model_utilities.lua:63-64), 1 conv bias,
+ * 2 PReLU slope, 3 Linear weight (aux = fan_in), 4 Linear bias (aux = fan_in),
+ * 5 BatchNorm weight, 6 BatchNorm bias. */
+int frcnn_model_param_table(const frcnn_model *, long long *table_host, int cap, int *n_host);
+/* Localizer.lua:6-39 for output node i (1..nheads = anchor heads, nheads+1 = last feature map):
+ * int[n][6] = {kW,kH,dW,dH,padW,padH}, input first. */
+int frcnn_model_localizer_layers(const frcnn_model *, int output_index, int *layers_host, int cap,
+                                 int *n_host);
+
+/* pnet:forward(img) (objective.lua:71, Detector.lua:33).  training!=0: SpatialDropout masks are
+ * drop_masks_host[b] (device float[filters_b] of 0/1, for parity runs) or, when NULL, drawn on
+ * device from `seed`.  training==0: x(1-p) (pnet:evaluate(), Detector.lua:31). */
+int frcnn_pnet_forward(frcnn_model *, const float *weights, const float *img, int H, int W,
+                       int training, const float *const *drop_masks_host, unsigned long long seed,
+                       void *stream);
+/* outputs[i], i = 1..nheads+1; the buffers are owned by the model and reused by the next
+ * forward (callers that keep results must copy: objective.lua:119). */
+int frcnn_pnet_output(frcnn_model *, int i, float **ptr_host, int *C_host, int *H_host,
+                      int *W_host);
+/* delta_outputs[i] (objective.lua:78-84): gradient buffers with the shapes of the outputs. */
+int frcnn_pnet_delta(frcnn_model *, int i, float **ptr_host);
+int frcnn_pnet_zero_deltas(frcnn_model *, void *stream);
+/* pnet:backward(img, delta_outputs) (objective.lua:189): accumulates into the flat gradient.
+ * The (unused) input gradient of the first convolution is not computed. */
+int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *stream);
+
+/* cnet:forward(cinput) (objective.lua:164, Detector.lua:101).  weights/grad point at the START
+ * of the flat vectors.  bn_running: float[2*n] {mean,var} per BatchNorm layer (updated when
+ * training).  drop_masks_host[l]: device float[R][n_l] keep masks or NULL (seeded RNG). */
+int frcnn_cnet_forward(frcnn_model *, const float *weights, const float *x, int R, int training,
+                       const float *const *drop_masks_host, unsigned long long seed,
+                       float *bn_running, float *bbox_out, float *cls_out, void *stream);
+/* cnet:backward(cinput, {crdelta, ccdelta}) (objective.lua:179) -> gx [R][D] */
+int frcnn_cnet_backward(frcnn_model *, const float *weights, const float *g_bbox,
+                        const float *g_cls, float *gx, float *grad, void *stream);
+/* objective.lua:170-177: zero negative rows of crout, SmoothL1*10 and ClassNLL with gradients.
+ * loss2 (device double[2]) += {creg_loss, ccls_loss}. */
+int frcnn_cnet_losses(float *crout, const float *crtarget, const float *ccout,
+                      const float *cctarget, int R, int npos, int ncls, float *crdelta,
+                      float *ccdelta, double *loss2, void *stream);
+/* Detector.lua:110-113: class (1-based argmax) and confidence (max log-prob) per row */
+int frcnn_cnet_decode(const float *cls_out, int R, int ncls, int *cls, float *conf, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

@@ -1,0 +1,111 @@
+"""nn.SpatialConvolution forward / updateGradInput / accGradParameters: HIP implicit-GEMM kernels
+(fp32 MFMA) through the C ABI vs the CPU oracle (fp64 accumulation).  Tolerance:
+|a-b| <= 1e-4 * max(1, |b|)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # C, H, W, O, k, pad
+    (3, 37, 53, 64, 3, 1),      # first layer shape class (Cin = 3, M = 64)
+    (16, 29, 50, 40, 3, 1),     # 29x50 map (block-4 geometry), M not a multiple of 32
+    (64, 57, 100, 128, 3, 1),
+    (24, 19, 23, 18, 1, 0),     # 1x1 head (M = 18)
+    (20, 29, 50, 32, 3, 0),     # valid 3x3 head
+    (10, 29, 50, 24, 5, 0),     # valid 5x5 head
+    (6, 29, 50, 24, 7, 0),      # valid 7x7 head
+    (130, 15, 17, 130, 3, 1),   # channel counts that are not multiples of the chunk / tile
+]
+
+
+def _dev(F, a):
+    return F.DeviceTensor.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+@pytest.mark.parametrize("C_,H,W,O_,k,pad", CASES)
+def test_conv_forward(F, O, C_, H, W, O_, k, pad):
+    rng = np.random.RandomState(C_ * 1000 + k)
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) * np.sqrt(2.0 / (k * k * O_))).astype(np.float32)
+    b = rng.randn(O_).astype(np.float32)
+    want = O.conv2d_fwd(x, w, b, pad)
+    out = F.DeviceTensor.empty(want.shape)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(_dev(F, w)), F.ptr(_dev(F, b)),
+                O_, k, pad, F.ptr(out), F.stream_ptr())
+    assert_close(out.numpy(), want, 1e-4, "conv fwd")
+
+
+def test_conv_forward_fused_activation(F, O):
+    """The producing layer's PReLU + SpatialDropout scale are applied by the consumer's loader."""
+    rng = np.random.RandomState(1)
+    C_, H, W, O_, k, pad = 12, 21, 34, 20, 3, 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) * 0.2).astype(np.float32)
+    b = rng.randn(O_).astype(np.float32)
+    a = np.float32(0.25)
+    scale = (rng.rand(C_) > 0.4).astype(np.float32)
+    act = np.where(x > 0, x, a * x) * scale[:, None, None]
+    want = O.conv2d_fwd(act, w, b, pad)
+    out = F.DeviceTensor.empty(want.shape)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, F.ptr(_dev(F, [a])), F.ptr(_dev(F, scale)),
+                F.ptr(_dev(F, w)), F.ptr(_dev(F, b)), O_, k, pad, F.ptr(out), F.stream_ptr())
+    assert_close(out.numpy(), want, 1e-4, "conv fwd + act")
+
+
+@pytest.mark.parametrize("C_,H,W,O_,k,pad", CASES[1:])
+def test_conv_backward_input(F, O, C_, H, W, O_, k, pad):
+    rng = np.random.RandomState(C_ * 77 + k)
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    g = rng.randn(O_, Ho, Wo).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) * np.sqrt(2.0 / (k * k * O_))).astype(np.float32)
+    want = O.conv2d_bwd_input(g, w, pad, H, W)
+    gin = F.DeviceTensor.empty((C_, H, W))
+    F._lib.call("frcnn_conv2d_backward_input", F.ptr(_dev(F, g)), O_, Ho, Wo, F.ptr(_dev(F, w)), C_, k, pad, F.ptr(gin), 0,
+                F.stream_ptr())
+    assert_close(gin.numpy(), want, 1e-4, "conv dgrad")
+    # accumulate flag: gin += ...
+    F._lib.call("frcnn_conv2d_backward_input", F.ptr(_dev(F, g)), O_, Ho, Wo, F.ptr(_dev(F, w)), C_, k, pad, F.ptr(gin), 1,
+                F.stream_ptr())
+    assert_close(gin.numpy(), 2 * want, 2e-4, "conv dgrad accumulate")
+
+
+@pytest.mark.parametrize("C_,H,W,O_,k,pad", CASES)
+def test_conv_backward_weight(F, O, C_, H, W, O_, k, pad):
+    rng = np.random.RandomState(C_ * 13 + k)
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    g = (rng.randn(O_, Ho, Wo) / np.sqrt(Ho * Wo)).astype(np.float32)
+    gw_want, gb_want = O.conv2d_bwd_weight(x, g, k, k, pad)
+    gw = F.DeviceTensor.zeros((O_, C_, k, k)); gb = F.DeviceTensor.zeros((O_,))
+    F._lib.call("frcnn_conv2d_backward_weight", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(_dev(F, g)), O_, k, pad,
+                F.ptr(gw), F.ptr(gb), F.stream_ptr())
+    assert_close(gw.numpy(), gw_want, 1e-4, "conv wgrad")
+    assert_close(gb.numpy(), gb_want, 1e-4, "conv bias grad")
+
+
+def test_conv_full_size_linearity(F):
+    """b2c1 geometry at full size (64->128 @ 225x400): conv(2x) == 2*conv(x) exactly and a delta
+    image reproduces the filter taps -- properties that need no oracle run at this size."""
+    rng = np.random.RandomState(0)
+    C_, H, W, O_, k, pad = 64, 225, 400, 128, 3, 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) * 0.05).astype(np.float32)
+    dw = _dev(F, w)
+    o1 = F.DeviceTensor.empty((O_, H, W)); o2 = F.DeviceTensor.empty((O_, H, W))
+    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
+    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, 2 * x)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o2), F.stream_ptr())
+    a1, a2 = o1.numpy(), o2.numpy()
+    assert np.array_equal(a2, 2 * a1)
+    d = np.zeros((C_, H, W), np.float32); d[5, 100, 200] = 1.0
+    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, d)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
+    r = o1.numpy()
+    for ky in range(3):
+        for kx in range(3):
+            assert np.array_equal(r[:, 100 + 1 - ky, 200 + 1 - kx], w[:, 5, ky, kx])
+    r[:, 99:102, 199:202] = 0
+    assert not r.any()

@@ -1,0 +1,121 @@
+"""Pool / activation / ROI pooling / Linear / optimiser kernels through the C ABI vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(F, a, dt=np.float32):
+    return F.DeviceTensor.from_numpy(np.ascontiguousarray(a, dtype=dt))
+
+
+@pytest.mark.parametrize("C_,H,W", [(5, 9, 13), (8, 57, 100), (3, 450, 800), (4, 2, 2), (2, 3, 2)])
+def test_maxpool_act_forward_backward(F, O, C_, H, W):
+    rng = np.random.RandomState(H * W)
+    x = rng.randn(C_, H, W).astype(np.float32)
+    a = np.float32(0.25)
+    scale = (rng.rand(C_) > 0.3).astype(np.float32) if C_ > 3 else None
+    act = np.where(x > 0, x, a * x) * (scale[:, None, None] if scale is not None else 1)
+    want, widx = O.maxpool_fwd(act)
+    Ho, Wo = want.shape[1:]
+    out = F.DeviceTensor.empty(want.shape); idx = F.DeviceTensor.empty(want.shape, np.uint8)
+    ds = _dev(F, scale) if scale is not None else None
+    da = _dev(F, [a])
+    dx = _dev(F, x)
+    F._lib.call("frcnn_maxpool_act_forward", F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds), F.ptr(out), F.ptr(idx), F.stream_ptr())
+    got = out.numpy()
+    assert np.array_equal(got, want)
+    code = idx.numpy().astype(np.int64)
+    oy, ox = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing="ij")
+    flat = (oy[None] * 2 + code // 2) * W + (ox[None] * 2 + code % 2)
+    dropped = np.zeros(C_, bool) if scale is None else scale == 0
+    assert np.array_equal(flat[~dropped], widx[~dropped])   # argmax (no ties in random data)
+    # backward: gx = unpool(g) * scale * prelu'(x), bias/slope gradients
+    g = rng.randn(*want.shape).astype(np.float32)
+    gact = O.maxpool_bwd(g, flat.astype(np.int32), H, W) * (scale[:, None, None] if scale is not None else 1)
+    gx_want = np.where(x > 0, gact, a * gact).astype(np.float32)
+    gb_want = gx_want.reshape(C_, -1).astype(np.float64).sum(1)
+    ga_want = float((np.where(x > 0, 0, x.astype(np.float64) * gact)).sum())
+    gx = F.DeviceTensor.empty(x.shape); gb = F.DeviceTensor.zeros((C_,)); ga = F.DeviceTensor.zeros((1,))
+    F._lib.call("frcnn_maxpool_act_backward", F.ptr(_dev(F, g)), F.ptr(idx), F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds),
+                F.ptr(gx), F.ptr(gb), F.ptr(ga), F.stream_ptr())
+    assert np.array_equal(gx.numpy(), gx_want)
+    assert_close(gb.numpy(), gb_want, 1e-4, "bias grad")
+    assert_close(ga.numpy()[0], ga_want, 1e-4, "slope grad")
+
+
+def test_act_backward(F):
+    rng = np.random.RandomState(2)
+    C_, hw = 7, 1234
+    x = rng.randn(C_, hw).astype(np.float32); g = rng.randn(C_, hw).astype(np.float32)
+    a = np.float32(-0.3)  # negative slope: the sign of x cannot be recovered from y, x itself must be used
+    gx_want = np.where(x > 0, g, a * g).astype(np.float32)
+    dg = _dev(F, g)
+    gb = F.DeviceTensor.zeros((C_,)); ga = F.DeviceTensor.zeros((1,))
+    F._lib.call("frcnn_act_backward", F.ptr(dg), F.ptr(_dev(F, x)), C_, hw, F.ptr(_dev(F, [a])), None, F.ptr(dg), F.ptr(gb),
+                F.ptr(ga), F.stream_ptr())
+    assert np.array_equal(dg.numpy(), gx_want)
+    assert_close(gb.numpy(), gx_want.astype(np.float64).sum(1), 1e-4)
+    assert_close(ga.numpy()[0], float(np.where(x > 0, 0, x.astype(np.float64) * g).sum()), 1e-4)
+
+
+def test_roi_pool_forward_backward(F, O):
+    rng = np.random.RandomState(4)
+    C_, H, W, kh, kw = 24, 29, 50, 6, 6
+    fmap = rng.randn(C_, H, W).astype(np.float32)
+    wins = np.array([[1, 29, 1, 50], [5, 15, 5, 15], [1, 12, 1, 7], [26, 29, 48, 50], [1, 3, 1, 3], [7, 7, 9, 9],
+                     [2, 4, 10, 30], [29, 29, 1, 50]], dtype=np.int32)  # incl. windows smaller than 6x6
+    R = len(wins)
+    out = F.DeviceTensor.empty((R, C_ * kh * kw)); idx = F.DeviceTensor.empty((R, C_ * kh * kw), np.int32)
+    dfm = _dev(F, fmap)
+    F._lib.call("frcnn_roi_pool_forward", F.ptr(dfm), C_, H, W, F.ptr(_dev(F, wins, np.int32)), R, kh, kw, F.ptr(out),
+                F.ptr(idx), F.stream_ptr())
+    got, gidx = out.numpy(), idx.numpy()
+    gmap_want = np.zeros((C_, H, W), dtype=np.float32)
+    gout = rng.randn(R, C_ * kh * kw).astype(np.float32)
+    for r in range(R):
+        wo, wi = O.adaptive_max_pool_fwd(fmap, wins[r], kh, kw)
+        assert np.array_equal(got[r], wo.ravel())
+        assert np.array_equal(gidx[r], wi.ravel())
+        O.adaptive_max_pool_bwd(gmap_want, gout[r].reshape(C_, kh, kw), wi)
+    gmap = F.DeviceTensor.zeros((C_, H, W))
+    F._lib.call("frcnn_roi_pool_backward", F.ptr(gmap), C_, H, W, F.ptr(_dev(F, gout)), F.ptr(idx), R, kh, kw, F.stream_ptr())
+    assert_close(gmap.numpy(), gmap_want, 1e-5, "roi pool bwd")
+
+
+@pytest.mark.parametrize("R,I,Oo", [(7, 100, 33), (96, 864, 48), (130, 13824, 64), (1, 512, 17)])
+def test_linear_forward_backward(F, O, R, I, Oo):
+    rng = np.random.RandomState(R)
+    x = rng.randn(R, I).astype(np.float32)
+    w = (rng.randn(Oo, I) / np.sqrt(I)).astype(np.float32); b = rng.randn(Oo).astype(np.float32)
+    want = O.linear_fwd(x, w, b)
+    y = F.DeviceTensor.empty((R, Oo))
+    dx, dw = _dev(F, x), _dev(F, w)
+    F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(_dev(F, b)), Oo, F.ptr(y), F.stream_ptr())
+    assert_close(y.numpy(), want, 1e-4, "linear fwd")
+    gy = rng.randn(R, Oo).astype(np.float32)
+    gx = F.DeviceTensor.empty((R, I)); gw = F.DeviceTensor.zeros((Oo, I)); gb = F.DeviceTensor.zeros((Oo,))
+    F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(_dev(F, gy)), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb),
+                F.stream_ptr())
+    g64, x64, w64 = gy.astype(np.float64), x.astype(np.float64), w.astype(np.float64)
+    assert_close(gx.numpy(), g64 @ w64, 1e-4, "linear dgrad")
+    assert_close(gw.numpy(), g64.T @ x64, 1e-4, "linear wgrad")
+    assert_close(gb.numpy(), g64.sum(0), 1e-4, "linear bias grad")
+
+
+def test_rmsprop_and_scale(F, O):
+    rng = np.random.RandomState(9)
+    n = 100003
+    x = rng.randn(n).astype(np.float32); g = rng.randn(n).astype(np.float32); m = rng.rand(n).astype(np.float32)
+    import torch
+    tx, tg, tm = [torch.from_numpy(v.copy()).cuda() for v in (x, g, m)]
+    F._lib.call("frcnn_rmsprop", F.ptr(tx), F.ptr(tg), F.ptr(tm), n, 1e-4, 0.9, 1e-8, F.stream_ptr())
+    O.rmsprop(x, g, m, 1e-4, 0.9, 1e-8)
+    assert_close(tx.cpu().numpy(), x, 1e-6, "rmsprop x")
+    assert_close(tm.cpu().numpy(), m, 1e-6, "rmsprop m")
+    F._lib.call("frcnn_scale", F.ptr(tg), n, 1.0 / 37.0, F.stream_ptr())
+    assert_close(tg.cpu().numpy(), g * np.float32(1.0 / 37.0), 1e-6, "scale")

@@ -1,0 +1,222 @@
+"""Model-level parity on the GPU: pnet / cnet forward+backward, one full lossAndGradient
+(objective.lua:45-218) and Detector:detect (Detector.lua:17-141) against the CPU oracle, at an
+image size the oracle finishes in seconds (3x128x176, real vgg_small topology)."""
+import numpy as np
+import pytest
+
+from util import VGG_SMALL_CLS, VGG_SMALL_HEADS, VGG_SMALL_LAYERS, assert_close, oracle_model
+
+pytestmark = pytest.mark.gpu
+H, W = 128, 176
+
+
+@pytest.fixture(scope="module")
+def setup(F, O):
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)
+    weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
+    om = oracle_model(O, cfg)
+    w_host = weights.cpu().numpy().copy()
+    assert O.param_count(om) == (model["native"].total_params, model["native"].pnet_params)
+    assert model["native"].total_params == 26784106
+    return dict(cfg=cfg, model=model, weights=weights, gradient=gradient, om=om, w=w_host)
+
+
+def _masks(rng, model):
+    return [None if l["dropout"] <= 0 else (rng.rand(l["filters"]) > l["dropout"]).astype(np.float32)
+            for l in model["layers"]]
+
+
+def test_pnet_forward_backward(F, O, setup):
+    s = setup
+    rng = np.random.RandomState(0)
+    img = F.synthetic_image(H, W, 0)
+    masks = _masks(rng, s["model"])
+    pnet = s["model"]["pnet"]
+    pnet.training()
+    pnet.drop_masks = masks
+    outs = pnet.forward(img)
+    want, st = O.pnet_forward(s["om"], s["w"], img, True, masks)
+    assert [o.shape for o in outs] == [w.shape for w in want]
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert_close(o.numpy(), w, 1e-4, "pnet output %d" % (i + 1))
+    # backward with dense random deltas
+    deltas = [(rng.randn(*w.shape) / np.sqrt(w.size)).astype(np.float32) for w in want]
+    g_want = np.zeros_like(s["w"])
+    O.pnet_backward(s["om"], s["w"], st, deltas, g_want)
+    s["gradient"].zero_()
+    dev_deltas = pnet.delta_outputs(zero=True)
+    for d, h in zip(dev_deltas, deltas):
+        d.copy_from_numpy(h)
+    pnet.backward(img, dev_deltas)
+    g = s["gradient"].cpu().numpy()
+    _compare_gradient(s["model"]["native"], g, g_want, lo=0, hi=s["model"]["native"].pnet_params)
+    pnet.drop_masks = None
+    # evaluate(): SpatialDropout scales by (1-p)
+    pnet.evaluate()
+    outs = pnet.forward(img)
+    want, _ = O.pnet_forward(s["om"], s["w"], img, False, None)
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert_close(o.numpy(), w, 1e-4, "pnet eval output %d" % (i + 1))
+
+
+def _compare_gradient(native, g, g_want, lo, hi, tol_l2=1e-3):
+    """1e-3 relative on the L2 norm per tensor + 1e-4 abs-or-relative elementwise."""
+    for off, cnt, kind, aux in native.param_table:
+        if not (lo <= off < hi):
+            continue
+        a, b = g[off:off + cnt].astype(np.float64), g_want[off:off + cnt].astype(np.float64)
+        nb = np.linalg.norm(b)
+        err = np.linalg.norm(a - b)
+        assert err <= tol_l2 * max(nb, 1e-6), "tensor @%d kind %d: |a-b|=%.3e |b|=%.3e" % (off, kind, err, nb)
+        scale = max(1e-30, np.abs(b).max())
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, scale) + 1e-3 * scale, "tensor @%d kind %d elementwise" % (off, kind)
+
+
+def test_cnet_forward_backward(F, O, setup):
+    s = setup
+    rng = np.random.RandomState(1)
+    R, D = 37, 6 * 6 * 384
+    x = rng.randn(R, D).astype(np.float32)
+    cmasks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+    cnet = s["model"]["cnet"]
+    native = s["model"]["native"]
+    bn0 = native.bn_running.cpu().numpy().copy()
+    cnet.training()
+    cnet.drop_masks = cmasks
+    bbox, cls = cnet.forward(x)
+    bn_o = bn0.copy()
+    wb, wc, st = O.cnet_forward(s["om"], s["w"], x, True, cmasks, bn_o)
+    assert_close(bbox.numpy(), wb, 1e-4, "cnet bbox")
+    assert_close(cls.numpy(), wc, 1e-4, "cnet cls")
+    assert_close(native.bn_running.cpu().numpy(), bn_o, 1e-5, "bn running stats")
+    gb = rng.randn(R, 4).astype(np.float32); gc = (rng.randn(R, 17) / R).astype(np.float32)
+    g_want = np.zeros_like(s["w"])
+    gx_want = O.cnet_backward(s["om"], s["w"], st, gb, gc, g_want, D)
+    s["gradient"].zero_()
+    gx = cnet.backward(x, [F.DeviceTensor.from_numpy(gb), F.DeviceTensor.from_numpy(gc)])
+    assert_close(gx.numpy(), gx_want, 1e-4, "cnet gradInput")
+    _compare_gradient(native, s["gradient"].cpu().numpy(), g_want, lo=native.pnet_params, hi=native.total_params)
+    cnet.drop_masks = None
+    cnet.evaluate()
+    bbox, cls = cnet.forward(x)
+    wb, wc, _ = O.cnet_forward(s["om"], s["w"], x, False, None, bn_o.copy())
+    assert_close(bbox.numpy(), wb, 1e-4, "cnet eval bbox")
+    assert_close(cls.numpy(), wc, 1e-4, "cnet eval cls")
+    import torch
+    native.bn_running.copy_(torch.from_numpy(bn0))
+
+
+class _OneBatch(object):
+    def __init__(self, batch, anchors):
+        self.batch, self.anchors = batch, anchors
+
+    def nextTraining(self, count=None):
+        return self.batch
+
+
+def test_loss_and_gradient(F, O, setup):
+    """objective.lua:45-218 on two images: losses within 1e-5 relative, gradient per SURVEY 8d."""
+    s = setup
+    model, cfg = s["model"], s["cfg"]
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rng_m = np.random.RandomState(3)
+    mt = F.MT19937(7)
+    batch, oracle_in = [], []
+    for k in range(2):
+        rois = F.synthetic_rois(cfg, W, H, 3, 7, k)
+        pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, mt, negatives=8)
+        img = F.synthetic_image(H, W, k)
+        batch.append(dict(img=img, positive=pos, negative=neg))
+        oracle_in.append((img, rois, pos, neg))
+    assert sum(len(b["positive"]) for b in batch) > 0
+    pm = _masks(rng_m, model)
+    model["pnet"].drop_masks = pm
+    nat = model["native"]
+    bn0 = nat.bn_running.cpu().numpy().copy()
+    # the oracle needs explicit cnet masks per image (R differs): draw them and hand the same to both
+    g_want = np.zeros_like(s["w"]); acc = np.zeros(8); bn_o = bn0.copy()
+    stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+    cm_per_image = []
+    for (img, rois, pos, neg) in oracle_in:
+        fm_shapes = None
+        R = len(pos) + len(neg)
+        cm = [(rng_m.rand(R, 1024) > 0.5).astype(np.float32), (rng_m.rand(R, 512) > 0.5).astype(np.float32)]
+        cm_per_image.append(cm)
+        pos_idx = np.array([[a.layer, a.aspect, a.index[1], a.index[2], rois.index(r) + 1] for a, r in pos], dtype=np.int32).reshape(-1, 5)
+        pos_rect = np.array([[a.minX, a.minY, a.maxX, a.maxY] for a, r in pos], dtype=np.float64).reshape(-1, 4)
+        neg_idx = np.array([[e[0].layer, e[0].aspect, e[0].index[1], e[0].index[2]] for e in neg], dtype=np.int32).reshape(-1, 4)
+        neg_rect = np.array([[e[0].minX, e[0].minY, e[0].maxX, e[0].maxY] for e in neg], dtype=np.float64).reshape(-1, 4)
+        roi_rect = np.array([[r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY] for r in rois], dtype=np.float64)
+        roi_cls = np.array([r.class_index for r in rois], dtype=np.int32)
+        O.train_image(s["om"], s["w"], g_want, img, pos_idx, pos_rect, roi_rect, roi_cls, neg_idx, neg_rect, pm, cm, bn_o, acc)
+    g_want /= acc[2]
+    want = dict(pcls=acc[0] / acc[2], preg=acc[1] / acc[3], dcls=acc[6] / acc[7], dreg=acc[4] / acc[5])
+
+    class _Cnet(object):  # per-image explicit masks: wrap cnet.forward to install them in order
+        pass
+    cnet = model["cnet"]
+    orig_forward = cnet.forward
+    it = iter(cm_per_image)
+
+    def fwd(x):
+        cnet.drop_masks = next(it)
+        return orig_forward(x)
+    cnet.forward = fwd
+    try:
+        f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+        loss, grad = f(s["weights"])
+    finally:
+        cnet.forward = orig_forward
+        cnet.drop_masks = None
+        model["pnet"].drop_masks = None
+    for k in ("pcls", "preg", "dcls", "dreg"):
+        assert abs(stats[k][-1] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, stats[k][-1], want[k])
+    assert abs(loss - (want["pcls"] + want["preg"])) <= 1e-5 * max(1.0, abs(loss))
+    _compare_gradient(nat, grad.cpu().numpy(), g_want, 0, nat.total_params)
+    assert_close(nat.bn_running.cpu().numpy(), bn_o, 1e-5, "bn running")
+    import torch
+    nat.bn_running.copy_(torch.from_numpy(bn0))
+
+
+def test_detect(F, O, setup):
+    """Detector:detect vs the oracle.  Head logits are amplified so that the p > 0.95 test fires."""
+    s = setup
+    import torch
+    model = s["model"]
+    nat = model["native"]
+    w = s["w"].copy()
+    for off, cnt, kind, aux in nat.param_table:
+        if kind == 0 and aux == 18:  # the 1x1 head convs (kW*kH*nOutputPlane = 18)
+            w[off:off + cnt] *= 60.0
+    s["weights"].copy_(torch.from_numpy(w))
+    try:
+        img = F.synthetic_image(H, W, 5)
+        d = F.Detector(model)
+        winners = d.detect(img)
+        bn = nat.bn_running.cpu().numpy()
+        ref = O.detect(s["om"], w, bn, img)
+        m = d.last_scan
+        gp, gidx, grect = m["p"].numpy(), m["idx"].numpy(), m["rect"].numpy()
+        # matches: identical anchor indices except those within 1e-4 of the 0.95 threshold
+        def key(a):
+            return set(map(tuple, a.tolist()))
+        border_ref = np.abs(np.exp(ref["match_p"].astype(np.float64)) - 0.95) < 1e-4
+        border_got = np.abs(np.exp(gp.astype(np.float64)) - 0.95) < 1e-4
+        assert key(gidx[~border_got]) - key(ref["match_idx"]) == set()
+        assert key(ref["match_idx"][~border_ref]) - key(gidx) == set()
+        assert len(gidx) > 10, "test image produced too few matches to be meaningful"
+        if len(gidx) == len(ref["match_idx"]) and np.array_equal(gidx, ref["match_idx"]):
+            assert_close(gp, ref["match_p"], 1e-4, "match log-prob")
+            assert_close(grect, ref["match_rect"], 1e-3, "decoded rects")
+        # NMS ids: bit-exact when the oracle NMS is fed the boxes the GPU produced
+        boxes = m["box"].numpy()
+        assert d.last_pick.tolist() == O.nms(boxes, 0.25).tolist()
+        if len(gidx) == len(ref["match_idx"]) and d.last_pick.tolist() == ref["cand_ids"].tolist():
+            assert_close(d.last_cnet["bbox"], ref["cand_bbox"], 1e-3, "cnet bbox (eval)")
+            assert_close(d.last_cnet["cls"], ref["cand_cls"], 1e-3, "cnet log-probs (eval)")
+            got = [(x["class"], round(x["confidence"], 3)) for x in winners]
+            want = [(int(r[0]), round(float(r[1]), 3)) for r in ref["winners"]]
+            assert got == want
+    finally:
+        s["weights"].copy_(torch.from_numpy(s["w"]))
