@@ -10,9 +10,9 @@ from .Detector import Detector
 from .Localizer import Localizer
 from .model_utilities import create_model
 from .nms import nms
-from .objective import create_objective, extract_roi_pooling_input, roi_window
+from .objective import allreduce_gradient_and_stats, create_objective, extract_roi_pooling_input, roi_window
 from .Rect import Rect
-from .synthetic import Roi, SyntheticBatchIterator, assemble_examples, synthetic_image, synthetic_rois
+from .synthetic import Roi, SyntheticBatchIterator, assemble_examples, clean_examples, output_map_sizes, synthetic_image, synthetic_rois
 from .tensor import DeviceTensor, ptr, stream_ptr, to_device
 from .utilities import combine_and_flatten_parameters, rmsprop
 from .vgg_large import vgg_large

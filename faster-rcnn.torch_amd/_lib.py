@@ -99,6 +99,15 @@ def load():
         raise FrcnnError(
             "libfrcnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the product path)" % SO_PATH)
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).
+    # Importing torch first makes the dynamic loader satisfy our NEEDED libamdhip64.so.7 with that copy,
+    # so device pointers, streams and RCCL communicators are shared with torch.  (A host without torch,
+    # e.g. the LuaJIT shim, simply gets the system runtime.)  Loading in the other order creates two
+    # runtimes in one process and the second one fails with "no ROCm-capable device is detected".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     for name, (args, res) in _SIGS.items():
         fn = getattr(L, name)

@@ -64,6 +64,22 @@ def _dist():
     return None
 
 
+def allreduce_gradient_and_stats(gradient, tot):
+    """Data-parallel exchange step: sum the flat gradient (in place) and the 8 fp64
+    accumulators {cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss,
+    ccls_count} (objective.lua:52-58) over all ranks.  `gradient` is a torch tensor (CUDA: RCCL over
+    xGMI through torch.distributed's "nccl" backend; CPU: gloo, used by the tests).  No-op without an
+    initialised process group."""
+    dist = _dist()
+    if dist is None:
+        return tot
+    import torch
+    t = torch.from_numpy(np.asarray(tot, dtype=np.float64)).to(gradient.device)
+    dist.all_reduce(gradient)
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
 def create_objective(model, weights, gradient, batch_iterator, stats):  # objective.lua:15
     cfg = model["cfg"]
     pnet = model["pnet"]
@@ -172,12 +188,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         # ---- statistics: one read-back per call ------------------------------------------
         a = acc_dev.numpy()
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
-        dist = _dist()
-        if dist is not None:  # DP: sum the flat gradient and the 8 accumulators over ranks
-            t = torch.from_numpy(tot).to(gradient.device)
-            dist.all_reduce(gradient)
-            dist.all_reduce(t)
-            tot = t.cpu().numpy()
+        tot = allreduce_gradient_and_stats(gradient, tot)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
         if cls_count > 0:
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200

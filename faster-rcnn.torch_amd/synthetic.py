@@ -64,6 +64,29 @@ def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16):
     return positive, negative
 
 
+def output_map_sizes(model, H, W):
+    """(h, w) of the pnet outputs 1..nheads for an HxW input: ceil-mode 2x2 pooling per block
+    (model_utilities.lua:23) then the valid kxk head convolution (:31)."""
+    sizes = []
+    h, w = H, W
+    per_block = []
+    for l in model["layers"]:
+        for _ in range(l["conv_steps"]):
+            h = h + 2 * l["padH"] - l["kH"] + 1; w = w + 2 * l["padW"] - l["kW"] + 1
+        h = int(math.ceil((h - 2) / 2.0)) + 1; w = int(math.ceil((w - 2) / 2.0)) + 1
+        per_block.append((h, w))
+    for a in model["anchor_nets"]:
+        bh, bw = per_block[a["input"] - 1]
+        sizes.append((bh - a["kW"] + 1, bw - a["kW"] + 1))
+    return sizes
+
+
+def clean_examples(examples, sizes):
+    """cleanAnchors (objective.lua:32-43) as a pure function: drops examples whose anchor index lies
+    outside its head map."""
+    return [e for e in examples if not (e[0].index[1] > sizes[e[0].layer - 1][0] or e[0].index[2] > sizes[e[0].layer - 1][1])]
+
+
 class SyntheticBatchIterator(object):
     """nextTraining() -> list of {img, positive, negative}.  `images_per_batch` images per call; with
     data parallelism rank r of world_size W takes images r, r+W, ... of the step's list."""

@@ -1,0 +1,50 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol include/frcnn_hip.h
+declares; the ctypes table of the host mirror covers exactly that set."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(F):
+    names = _header_symbols()
+    assert len(names) >= 45
+    lib = ctypes.CDLL(F._lib.SO_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header(F):
+    assert sorted(F._lib.exported_symbols()) == _header_symbols()
+
+
+def test_host_only_entry_points(F):
+    lib = F._lib.load()
+    assert lib.frcnn_version() >= 100
+    assert lib.frcnn_nms_workspace_bytes(300) > 300 * 12
+    m = F.vgg_small(dict(F.duplo_cfg))
+    nat = m["native"]
+    assert (nat.total_params, nat.pnet_params) == (26784106, 12089683)
+    assert [len(nat.localizer_layers(i)) for i in range(1, 6)] == [10, 13, 13, 13, 11]
+    large = F.vgg_large(dict(F.imgnet_cfg))
+    assert large["native"].total_params > 38_000_000   # 38.6 M with 6x6 ROI pooling
+    # errors surface as exceptions carrying frcnn_last_error()
+    import pytest
+    with pytest.raises(F.FrcnnError):
+        F._lib.call("frcnn_model_localizer_layers", nat.h, 99, None, 0, ctypes.byref(ctypes.c_int()))
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "faster-rcnn.torch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "pyoracle" not in txt and "frcnn_oracle" not in txt and "naive_np" not in txt, fn

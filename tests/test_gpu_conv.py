@@ -35,7 +35,8 @@ def test_conv_forward(F, O, C_, H, W, O_, k, pad):
     b = rng.randn(O_).astype(np.float32)
     want = O.conv2d_fwd(x, w, b, pad)
     out = F.DeviceTensor.empty(want.shape)
-    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(_dev(F, w)), F.ptr(_dev(F, b)),
+    dx, dw, db = _dev(F, x), _dev(F, w), _dev(F, b)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), F.ptr(db),
                 O_, k, pad, F.ptr(out), F.stream_ptr())
     assert_close(out.numpy(), want, 1e-4, "conv fwd")
 
@@ -52,8 +53,9 @@ def test_conv_forward_fused_activation(F, O):
     act = np.where(x > 0, x, a * x) * scale[:, None, None]
     want = O.conv2d_fwd(act, w, b, pad)
     out = F.DeviceTensor.empty(want.shape)
-    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, F.ptr(_dev(F, [a])), F.ptr(_dev(F, scale)),
-                F.ptr(_dev(F, w)), F.ptr(_dev(F, b)), O_, k, pad, F.ptr(out), F.stream_ptr())
+    dx, da, ds, dw, db = _dev(F, x), _dev(F, [a]), _dev(F, scale), _dev(F, w), _dev(F, b)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds),
+                F.ptr(dw), F.ptr(db), O_, k, pad, F.ptr(out), F.stream_ptr())
     assert_close(out.numpy(), want, 1e-4, "conv fwd + act")
 
 
@@ -65,11 +67,12 @@ def test_conv_backward_input(F, O, C_, H, W, O_, k, pad):
     w = (rng.randn(O_, C_, k, k) * np.sqrt(2.0 / (k * k * O_))).astype(np.float32)
     want = O.conv2d_bwd_input(g, w, pad, H, W)
     gin = F.DeviceTensor.empty((C_, H, W))
-    F._lib.call("frcnn_conv2d_backward_input", F.ptr(_dev(F, g)), O_, Ho, Wo, F.ptr(_dev(F, w)), C_, k, pad, F.ptr(gin), 0,
+    dg, dw = _dev(F, g), _dev(F, w)
+    F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, k, pad, F.ptr(gin), 0,
                 F.stream_ptr())
     assert_close(gin.numpy(), want, 1e-4, "conv dgrad")
     # accumulate flag: gin += ...
-    F._lib.call("frcnn_conv2d_backward_input", F.ptr(_dev(F, g)), O_, Ho, Wo, F.ptr(_dev(F, w)), C_, k, pad, F.ptr(gin), 1,
+    F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, k, pad, F.ptr(gin), 1,
                 F.stream_ptr())
     assert_close(gin.numpy(), 2 * want, 2e-4, "conv dgrad accumulate")
 
@@ -82,7 +85,8 @@ def test_conv_backward_weight(F, O, C_, H, W, O_, k, pad):
     g = (rng.randn(O_, Ho, Wo) / np.sqrt(Ho * Wo)).astype(np.float32)
     gw_want, gb_want = O.conv2d_bwd_weight(x, g, k, k, pad)
     gw = F.DeviceTensor.zeros((O_, C_, k, k)); gb = F.DeviceTensor.zeros((O_,))
-    F._lib.call("frcnn_conv2d_backward_weight", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(_dev(F, g)), O_, k, pad,
+    dx, dg = _dev(F, x), _dev(F, g)
+    F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, None, None, F.ptr(dg), O_, k, pad,
                 F.ptr(gw), F.ptr(gb), F.stream_ptr())
     assert_close(gw.numpy(), gw_want, 1e-4, "conv wgrad")
     assert_close(gb.numpy(), gb_want, 1e-4, "conv bias grad")
@@ -97,12 +101,14 @@ def test_conv_full_size_linearity(F):
     w = (rng.randn(O_, C_, k, k) * 0.05).astype(np.float32)
     dw = _dev(F, w)
     o1 = F.DeviceTensor.empty((O_, H, W)); o2 = F.DeviceTensor.empty((O_, H, W))
-    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, x)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
-    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, 2 * x)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o2), F.stream_ptr())
+    dx1, dx2 = _dev(F, x), _dev(F, 2 * x)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx1), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx2), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o2), F.stream_ptr())
     a1, a2 = o1.numpy(), o2.numpy()
     assert np.array_equal(a2, 2 * a1)
     d = np.zeros((C_, H, W), np.float32); d[5, 100, 200] = 1.0
-    F._lib.call("frcnn_conv2d_forward", F.ptr(_dev(F, d)), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
+    dd = _dev(F, d)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dd), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(o1), F.stream_ptr())
     r = o1.numpy()
     for ky in range(3):
         for kx in range(3):

@@ -41,7 +41,8 @@ def test_maxpool_act_forward_backward(F, O, C_, H, W):
     gb_want = gx_want.reshape(C_, -1).astype(np.float64).sum(1)
     ga_want = float((np.where(x > 0, 0, x.astype(np.float64) * gact)).sum())
     gx = F.DeviceTensor.empty(x.shape); gb = F.DeviceTensor.zeros((C_,)); ga = F.DeviceTensor.zeros((1,))
-    F._lib.call("frcnn_maxpool_act_backward", F.ptr(_dev(F, g)), F.ptr(idx), F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds),
+    dg = _dev(F, g)
+    F._lib.call("frcnn_maxpool_act_backward", F.ptr(dg), F.ptr(idx), F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds),
                 F.ptr(gx), F.ptr(gb), F.ptr(ga), F.stream_ptr())
     assert np.array_equal(gx.numpy(), gx_want)
     assert_close(gb.numpy(), gb_want, 1e-4, "bias grad")
@@ -56,7 +57,8 @@ def test_act_backward(F):
     gx_want = np.where(x > 0, g, a * g).astype(np.float32)
     dg = _dev(F, g)
     gb = F.DeviceTensor.zeros((C_,)); ga = F.DeviceTensor.zeros((1,))
-    F._lib.call("frcnn_act_backward", F.ptr(dg), F.ptr(_dev(F, x)), C_, hw, F.ptr(_dev(F, [a])), None, F.ptr(dg), F.ptr(gb),
+    dx, da = _dev(F, x), _dev(F, [a])
+    F._lib.call("frcnn_act_backward", F.ptr(dg), F.ptr(dx), C_, hw, F.ptr(da), None, F.ptr(dg), F.ptr(gb),
                 F.ptr(ga), F.stream_ptr())
     assert np.array_equal(dg.numpy(), gx_want)
     assert_close(gb.numpy(), gx_want.astype(np.float64).sum(1), 1e-4)
@@ -72,7 +74,8 @@ def test_roi_pool_forward_backward(F, O):
     R = len(wins)
     out = F.DeviceTensor.empty((R, C_ * kh * kw)); idx = F.DeviceTensor.empty((R, C_ * kh * kw), np.int32)
     dfm = _dev(F, fmap)
-    F._lib.call("frcnn_roi_pool_forward", F.ptr(dfm), C_, H, W, F.ptr(_dev(F, wins, np.int32)), R, kh, kw, F.ptr(out),
+    dwins = _dev(F, wins, np.int32)
+    F._lib.call("frcnn_roi_pool_forward", F.ptr(dfm), C_, H, W, F.ptr(dwins), R, kh, kw, F.ptr(out),
                 F.ptr(idx), F.stream_ptr())
     got, gidx = out.numpy(), idx.numpy()
     gmap_want = np.zeros((C_, H, W), dtype=np.float32)
@@ -83,7 +86,8 @@ def test_roi_pool_forward_backward(F, O):
         assert np.array_equal(gidx[r], wi.ravel())
         O.adaptive_max_pool_bwd(gmap_want, gout[r].reshape(C_, kh, kw), wi)
     gmap = F.DeviceTensor.zeros((C_, H, W))
-    F._lib.call("frcnn_roi_pool_backward", F.ptr(gmap), C_, H, W, F.ptr(_dev(F, gout)), F.ptr(idx), R, kh, kw, F.stream_ptr())
+    dgout = _dev(F, gout)
+    F._lib.call("frcnn_roi_pool_backward", F.ptr(gmap), C_, H, W, F.ptr(dgout), F.ptr(idx), R, kh, kw, F.stream_ptr())
     assert_close(gmap.numpy(), gmap_want, 1e-5, "roi pool bwd")
 
 
@@ -95,11 +99,13 @@ def test_linear_forward_backward(F, O, R, I, Oo):
     want = O.linear_fwd(x, w, b)
     y = F.DeviceTensor.empty((R, Oo))
     dx, dw = _dev(F, x), _dev(F, w)
-    F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(_dev(F, b)), Oo, F.ptr(y), F.stream_ptr())
+    db = _dev(F, b)
+    F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(db), Oo, F.ptr(y), F.stream_ptr())
     assert_close(y.numpy(), want, 1e-4, "linear fwd")
     gy = rng.randn(R, Oo).astype(np.float32)
     gx = F.DeviceTensor.empty((R, I)); gw = F.DeviceTensor.zeros((Oo, I)); gb = F.DeviceTensor.zeros((Oo,))
-    F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(_dev(F, gy)), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb),
+    dgy = _dev(F, gy)
+    F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(dgy), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb),
                 F.stream_ptr())
     g64, x64, w64 = gy.astype(np.float64), x.astype(np.float64), w.astype(np.float64)
     assert_close(gx.numpy(), g64 @ w64, 1e-4, "linear dgrad")
