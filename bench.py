@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the reference's training step (objective.lua lossAndGradient +
+optim.rmsprop, main.lua:133) on vgg_small with synthetic 800x450 frames, one image per GPU per
+step, data-parallel over N GPUs of one node (gradient all-reduce on RCCL).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying
+  "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_igemm 3x3: forward + input-gradient
+                    of every 3x3 convolution) = algorithmic FLOPs of its launches / their HIP-event
+                    durations, measured live over the timed steps, vs the fp32-MFMA peak;
+  "cpu_baseline" -- the CPU restatement of the reference (oracle/, "port") timed on this host on a
+                    bounded sample (one full training step on a 1/16-area frame), N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+FULL_H, FULL_W = 450, 800
+
+
+def conv_flops_per_image(model, H, W):
+    """Algorithmic conv FLOPs of one training step: fwd + dgrad + wgrad, first-layer dgrad skipped."""
+    fwd = 0.0
+    first = None
+    h, w, cin = H, W, 3
+    import math
+    per_block = []
+    for l in model["layers"]:
+        for _ in range(l["conv_steps"]):
+            f = 2.0 * l["filters"] * cin * l["kW"] * l["kH"] * h * w
+            if first is None:
+                first = f
+            fwd += f
+            cin = l["filters"]
+        h = int(math.ceil((h - 2) / 2.0)) + 1; w = int(math.ceil((w - 2) / 2.0)) + 1
+        per_block.append((h, w, cin))
+    for a in model["anchor_nets"]:
+        bh, bw, bc = per_block[a["input"] - 1]
+        oh, ow = bh - a["kW"] + 1, bw - a["kW"] + 1
+        fwd += 2.0 * a["n"] * bc * a["kW"] * a["kW"] * oh * ow + 2.0 * 18 * a["n"] * oh * ow
+    return fwd, 3 * fwd - first
+
+
+def cpu_baseline(cfg):
+    """Oracle (CPU restatement, all host cores via OpenMP) on a bounded sample: ONE training step on a
+    3x113x200 frame (1/16 of the 450x800 pixels, same network, same example assembly); the rate is scaled
+    by the pixel ratio to the metric's unit (conv work is proportional to pixels)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pyoracle as O
+    import frcnn_amd as F
+    from util import oracle_model
+    H, W = 113, 200
+    model = F.vgg_small(cfg)
+    om = oracle_model(O, cfg)
+    w = model["native"].init_parameters(42)
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rois = F.synthetic_rois(cfg, W, H, 4, 7, 0)
+    pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(7))
+    sizes = F.output_map_sizes(model, H, W)
+    pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
+    img = F.synthetic_image(H, W, 0)
+    pos_idx = np.array([[a.layer, a.aspect, a.index[1], a.index[2], rois.index(r) + 1] for a, r in pos], dtype=np.int32).reshape(-1, 5)
+    pos_rect = np.array([[a.minX, a.minY, a.maxX, a.maxY] for a, r in pos], dtype=np.float64).reshape(-1, 4)
+    neg_idx = np.array([[e[0].layer, e[0].aspect, e[0].index[1], e[0].index[2]] for e in neg], dtype=np.int32).reshape(-1, 4)
+    neg_rect = np.array([[e[0].minX, e[0].minY, e[0].maxX, e[0].maxY] for e in neg], dtype=np.float64).reshape(-1, 4)
+    roi_rect = np.array([[r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY] for r in rois], dtype=np.float64)
+    roi_cls = np.array([r.class_index for r in rois], dtype=np.int32)
+    R = len(pos) + len(neg)
+    rng = np.random.RandomState(0)
+    pm = [None if l["dropout"] <= 0 else (rng.rand(l["filters"]) > l["dropout"]).astype(np.float32) for l in model["layers"]]
+    cm = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+    bn = np.concatenate([np.zeros(1024, np.float32), np.ones(1024, np.float32)])
+    g = np.zeros_like(w); m = np.zeros_like(w); acc = np.zeros(8)
+    t0 = time.time()
+    O.train_image(om, w, g, img, pos_idx, pos_rect, roi_rect, roi_cls, neg_idx, neg_rect, pm, cm, bn, acc)
+    g /= max(acc[2], 1.0)
+    O.rmsprop(w, g, m, 1e-4, 0.9, 1e-8)
+    dt = time.time() - t0
+    ratio = (H * W) / float(FULL_H * FULL_W)
+    return dict(value=round(ratio / dt, 5), unit="images/sec", cores=O.get_threads(), kind="port",
+                sample="1 training step (pnet fwd/bwd, RPN loss, ROI pool, cnet fwd/bwd, rmsprop) of the CPU restatement "
+                       "(oracle/, fp64 accumulation, OpenMP) on a 3x%dx%d frame = %.4f of the 800x450 pixels, %d examples; "
+                       "%.2f s wall; rate scaled by the pixel ratio" % (H, W, ratio, R, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=FULL_H)
+    ap.add_argument("--width", type=int, default=FULL_W)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL over xGMI
+
+    import frcnn_amd as F
+    L = F._lib.load()
+    F._lib.call("frcnn_set_device", local_rank)
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)
+    weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)  # same seed on every rank
+    H, W = args.height, args.width
+    it = F.SyntheticBatchIterator(model, H=H, W=W, images_per_batch=1, rank=rank, world_size=world, pool=4)
+    stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+    f = F.create_objective(model, weights, gradient, it, stats)
+    state = dict(learningRate=1e-4, alpha=0.9)  # main.lua:122
+
+    def step():
+        F.rmsprop(f, weights, state)  # main.lua:133
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    mask = 0x3FF if args.profile_all else 0xF   # conv kernel classes only by default
+    barrier()
+    F._lib.call("frcnn_prof_enable", mask)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    F._lib.call("frcnn_prof_enable", 0)
+    nk = len(F._lib.KC_NAMES)
+    launches = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
+    F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        fwd_flops, train_flops = conv_flops_per_image(model, H, W)
+        k = 0  # conv_igemm_k3
+        ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_igemm_k3_bytes_per_launch")
+            except Exception:
+                traffic = None
+        classes = {}
+        for i, name in enumerate(F._lib.KC_NAMES):
+            if launches[i]:
+                classes[name] = dict(launches_per_step=launches[i] / args.steps, ms_per_step=round(ms[i] / args.steps, 4),
+                                     tflops=round((fl[i] / 1e12) / (ms[i] / 1e3), 2) if fl[i] > 0 and ms[i] > 0 else None)
+        conv_ms = sum(ms[i] for i in range(4)) / args.steps
+        out = dict(
+            metric="images/sec (vgg_small 800x450 fwd+bwd)", value=round(world * args.steps / dt, 3), unit="images/sec",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="vgg_small %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
+                                 "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/duplo.lua values" % (W, H),
+                        images_per_gpu_per_step=1, global_batch=world, parallelism="dp%d" % world,
+                        conv_gflop_per_image=round(train_flops / 1e9, 2),
+                        whole_step_conv_tflops=round(train_flops / 1e12 / (dt / args.steps), 2),
+                        conv_kernel_ms_per_step=round(conv_ms, 3), kernel_classes=classes,
+                        last_loss=stats["pcls"][-1] + stats["preg"][-1] if stats["pcls"] else None),
+            roofline=dict(bound="mfma", kernel="conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)",
+                          achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                          frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                          launches_per_step=launches[k] / args.steps, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4)),
+        )
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,27 @@ class Localizer(object):
                 maxY = max(math.ceil((maxY - kH) / dH) + 1, minY + 1)
         return Rect(minX, minY, maxX, maxY).snapToInt()  # :66
 
+    def inputToFeatureRectBatch(self, rects):
+        """inputToFeatureRect for an (n, 4) float64 array of rects at once -- the same double-precision
+        operations in the same order, elementwise (used by the per-step example assembly)."""
+        import numpy as np
+        r = np.array(rects, dtype=np.float64).reshape(-1, 4)
+        minX, minY, maxX, maxY = r[:, 0].copy(), r[:, 1].copy(), r[:, 2].copy(), r[:, 3].copy()
+        for l in self.layers:
+            kW, kH, dW, dH = l["kW"], l["kH"], l["dW"], l["dH"]
+            if dW < kW:
+                minX -= kW - dW; minY -= kH - dH; maxX += kW - dW; maxY += kH - dH
+            minX += l["padW"]; minY += l["padH"]; maxX += l["padW"]; maxY += l["padH"]
+            minX = minX / dH
+            minY = minY / dH
+            ax = maxX - kW
+            exact = (ax - np.floor(ax / dW) * dW) == 0
+            maxX = np.maximum(np.where(exact, ax / dW + 1, np.ceil(ax / dW) + 1), minX + 1)
+            ay = maxY - kH
+            exact = (ay - np.floor(ay / dH) * dH) == 0
+            maxY = np.maximum(np.where(exact, ay / dW + 1, np.ceil(ay / dH) + 1), minY + 1)
+        return np.stack([np.floor(minX), np.floor(minY), np.ceil(maxX), np.ceil(maxY)], 1)
+
     def featureToInputRect(self, minX, minY, maxX, maxY, layer_index=None):  # Localizer.lua:69-79
         n = layer_index or len(self.layers)
         for l in reversed(self.layers[:n]):

@@ -20,13 +20,13 @@ void set_error(const char* fmt, ...) {
 
 // ---------------------------------------------------------------- profiler
 struct ProfRec { int klass; double flops, bytes; hipEvent_t a, b; };
-static bool g_prof = false;
+static unsigned g_prof_mask = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static hipEvent_t g_pending;
 static std::mutex g_mu;
 
-bool prof_enabled() { return g_prof; }
+bool prof_enabled(int klass) { return (g_prof_mask >> klass) & 1u; }
 static hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e;
@@ -97,8 +97,8 @@ int frcnn_stream_sync(void* stream) {
 int frcnn_zero(void* ptr, size_t bytes, void* stream) { return fill_zero(ptr, bytes, S(stream)); }
 int frcnn_scale(float* x, long long n, float s, void* stream) { return scale_inplace(x, n, s, S(stream)); }
 
-int frcnn_prof_enable(int on) {
-  g_prof = on != 0;
+int frcnn_prof_enable(int class_mask) {
+  g_prof_mask = (unsigned)class_mask;
   return FRCNN_OK;
 }
 int frcnn_prof_collect(long long* launches, double* ms, double* flops, double* bytes) {

@@ -59,15 +59,15 @@ enum KClass {
   KC_COUNT
 };
 
-bool prof_enabled();
+bool prof_enabled(int klass);
 void prof_before(int klass, hipStream_t s);
 void prof_after(int klass, double flops, double bytes, hipStream_t s);
 
 #define FR_LAUNCH(klass, flops, bytes, stream, kernel, grid, block, shmem, ...)        \
   do {                                                                                 \
-    if (frcnn::prof_enabled()) frcnn::prof_before((klass), (stream));                  \
+    if (frcnn::prof_enabled(klass)) frcnn::prof_before((klass), (stream));                  \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
-    if (frcnn::prof_enabled()) frcnn::prof_after((klass), (flops), (bytes), (stream)); \
+    if (frcnn::prof_enabled(klass)) frcnn::prof_after((klass), (flops), (bytes), (stream)); \
   } while (0)
 
 #define FR_LAUNCH_CHECK()                                                          \

@@ -33,9 +33,9 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 // ---------------------------------------------------------------- flat buffer ops
 int fill_zero(void* p, size_t bytes, hipStream_t s) {
-  if (prof_enabled()) prof_before(KC_ELEMWISE, s);
+  if (prof_enabled(KC_ELEMWISE)) prof_before(KC_ELEMWISE, s);
   FR_HIP(hipMemsetAsync(p, 0, bytes, s));
-  if (prof_enabled()) prof_after(KC_ELEMWISE, 0, (double)bytes, s);
+  if (prof_enabled(KC_ELEMWISE)) prof_after(KC_ELEMWISE, 0, (double)bytes, s);
   return FRCNN_OK;
 }
 

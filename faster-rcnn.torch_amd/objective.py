@@ -30,6 +30,14 @@ def roi_window(input_rect, localizer, fm_h, fm_w):
     return (int(min(r.minY + 1, r.maxY)), int(r.maxY), int(min(r.minX + 1, r.maxX)), int(r.maxX))
 
 
+def roi_windows(rects, localizer, fm_h, fm_w):
+    """roi_window() for an (n, 4) array of input rects -> int32 (n, 4), vectorised."""
+    r = localizer.inputToFeatureRectBatch(rects)
+    minX = np.minimum(np.maximum(r[:, 0], 0), fm_w); minY = np.minimum(np.maximum(r[:, 1], 0), fm_h)   # Rect.clip
+    maxX = np.maximum(np.minimum(r[:, 2], fm_w), 0); maxY = np.maximum(np.minimum(r[:, 3], fm_h), 0)
+    return np.stack([np.minimum(minY + 1, maxY), maxY, np.minimum(minX + 1, maxX), maxX], 1).astype(np.int32)
+
+
 def extract_roi_pooling_input(input_rect, localizer, feature_layer_output):  # objective.lua:5-13
     """Returns (window, idx): idx = {{}, {row_lo,row_hi}, {col_lo,col_hi}} like the reference; the strided
     view itself is never materialised -- the batched ROI-pool kernel reads the window in place."""
@@ -123,29 +131,22 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             fmC, fmH, fmW = fm.shape
             if E > 0:
                 # ---- host: pack the example tables (one H2D copy) ----------------------------
-                ex_idx = np.zeros((E, 4), dtype=np.int32)
-                ex_anchor = np.zeros((E, 4), dtype=np.float64)
+                anch = [e[0] for e in p] + [e[0] for e in n]
+                ex_idx = np.array([(a.layer, a.aspect, a.index[1], a.index[2]) for a in anch], dtype=np.int32)
+                ex_anchor = np.array([(a.minX, a.minY, a.maxX, a.maxY) for a in anch], dtype=np.float64)
                 ex_roi = np.zeros((max(npos, 1), 4), dtype=np.float64)
                 ex_class = np.zeros(max(npos, 1), dtype=np.int32)
-                wins = np.zeros((E, 4), dtype=np.int32)
-                for i, e in enumerate(p):
-                    a, roi = e[0], e[1]
-                    ex_idx[i] = (a.layer, a.aspect, a.index[1], a.index[2])
-                    ex_anchor[i] = (a.minX, a.minY, a.maxX, a.maxY)
-                    ex_roi[i] = (roi.rect.minX, roi.rect.minY, roi.rect.maxX, roi.rect.maxY)
-                    ex_class[i] = roi.class_index
-                    wins[i] = roi_window(roi.rect, localizer, fmH, fmW)  # :117 positives pool the GT rect
-                for j, e in enumerate(n):
-                    a = e[0]
-                    i = npos + j
-                    ex_idx[i] = (a.layer, a.aspect, a.index[1], a.index[2])
-                    ex_anchor[i] = (a.minX, a.minY, a.maxX, a.maxY)
-                    wins[i] = roi_window(a, localizer, fmH, fmW)  # :137 negatives pool the anchor rect
+                if npos:
+                    ex_roi[:npos] = [(e[1].rect.minX, e[1].rect.minY, e[1].rect.maxX, e[1].rect.maxY) for e in p]
+                    ex_class[:npos] = [e[1].class_index for e in p]
+                # positives pool the GT rect (:117), negatives pool the anchor rect itself (:137)
+                wins = roi_windows(np.concatenate([ex_roi[:npos], ex_anchor[npos:]], 0), localizer, fmH, fmW)
                 blob = np.concatenate([ex_anchor.view(np.uint8).ravel(), ex_roi.view(np.uint8).ravel(),
                                        ex_idx.view(np.uint8).ravel(), ex_class.view(np.uint8).ravel(),
                                        wins.view(np.uint8).ravel()])
                 dblob = scratch.get("blob", (blob.size,), np.uint8)
-                dblob.copy_from_numpy(blob)
+                scratch.keep = blob  # the host array must outlive the (possibly still queued) copy
+                _lib.call("frcnn_memcpy_h2d", ptr(dblob), blob.ctypes.data_as(C.c_void_p), blob.nbytes, s)
                 o = 0
                 d_anchor = dblob.ptr + o; o += ex_anchor.nbytes
                 d_roi = dblob.ptr + o; o += ex_roi.nbytes

@@ -64,7 +64,9 @@ int frcnn_scale(float *x, long long n, float s, void *stream);    /* gradient:di
 #define FRCNN_KC_NMS 8
 #define FRCNN_KC_OPTIM 9
 #define FRCNN_KC_COUNT 10
-int frcnn_prof_enable(int on);   /* brackets every kernel launch with hipEvents on its stream */
+/* class_mask: bit k set -> every launch of kernel class k is bracketed by two hipEvents on its
+ * launch stream (0 = profiling off). */
+int frcnn_prof_enable(int class_mask);
 /* Synchronises the device; per class: launches, total ms, algorithmic flops, algorithmic bytes.
  * Arrays of FRCNN_KC_COUNT entries (host).  Resets the profile. */
 int frcnn_prof_collect(long long *launches_host, double *ms_host, double *flops_host,
