@@ -171,7 +171,13 @@ int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const 
 int frcnn_conv2d_backward_weight(const float* in, int C, int H, int W, const float* in_slope,
                                  const float* in_scale, const float* gout, int O, int k, int pad,
                                  float* gweight, float* gbias, void* stream) {
-  FR_TRY(conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, S(stream)));
+  size_t wsb = conv_wgrad_workspace_bytes(C, H, W, O, k, pad);
+  void* ws = nullptr;
+  FR_HIP(hipMalloc(&ws, wsb));
+  int rc = conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, ws, wsb, S(stream));
+  (void)hipStreamSynchronize(S(stream));
+  (void)hipFree(ws);
+  FR_TRY(rc);
   if (gbias) {
     int Ho = H + 2 * pad - k + 1, Wo = W + 2 * pad - k + 1;
     FR_TRY(channel_sum(gout, O, (long)Ho * Wo, gbias, S(stream)));

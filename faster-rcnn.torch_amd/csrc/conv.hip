@@ -11,6 +11,8 @@
 //
 // updateGradInput is the same kernel: a "full" correlation of gradOutput with the flipped,
 // transposed filter bank (pad' = k-1-pad), fed by the second packed matrix.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace frcnn {
@@ -333,30 +335,40 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
 // ------------------------------------------------------------------------------------------
 // weight gradient: gw[o][c][ky][kx] += sum_pix g[o][pix] * act(in)[c][pix + (ky,kx) - pad]
 // GEMM view per tap: M = o (32/wave), N = c (32/wave), K = pixels.  One block = 64 o x 64 c x
-// (TYS x KS taps), looping over its share of pixel tiles, then one atomic add per element.
+// (TYS x KS taps) = 2x2 waves, each wave keeping all its taps in the accumulator file (3x3: nine
+// 32x32 tiles = 144 AGPRs).  A block walks its share of <=64-pixel tiles (gradient tile + input
+// patch with halo staged in LDS, odd pitches -> both operand reads conflict-free); two blocks per
+// CU overlap one block's staging with the other's MFMAs.
+// Split-K over pixel tiles: every block writes its partial tile to a slab [split][tap][o][c]
+// with coalesced plain stores (fp32 atomics to the shared result serialise in the memory-side
+// atomic units: measured 450-650 us per launch), then wgrad_reduce_kernel folds the slabs into the
+// accumulating gradient tensor.
 // ------------------------------------------------------------------------------------------
 struct WgradArgs {
   const float* in;
   const float* in_slope;
   const float* in_scale;
   const float* g;
-  float* gw;
+  float* slab;   // [nSplit][KS*KS][O][Cin]
   int Cin, H, W, O, Ho, Wo, pad;
   int TH, TW, tilesX, tilesY;
   int oTiles, cTiles, kyGroups, nSplit;
+  int dbg;  // tuning knobs (tools/bench_conv.py): bit0 skip epilogue, bit1 skip MFMA loop, bit2 skip staging
 };
 
-#define WG_NT 64    // staged gradient pixels per tile (TH*TW <= 64)
-#define WG_NTP 65   // odd pitch -> conflict-free column reads
-#define WG_MAXIT 4
+#define WG_NT 64     // staged gradient pixels per tile (TH*TW <= 64)
+#define WG_NTP 65    // odd pitch -> conflict-free column reads
+#define WG_PM 3      // patch slots per lane (patch plane <= 192)
+#define WG_PP 193    // LDS pitch of a patch channel: odd (conflict-free) and >= 64*WG_PM (unconditional stores)
 
 template <int KS, int TYS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int NTAP = TYS * KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gs = smem;                  // [64][WG_NTP]
   float* ps = smem + 64 * WG_NTP;    // [64][PP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave >> 1, wc = wave & 1;
   const int h = lane >> 5, li = lane & 31;
 
@@ -368,9 +380,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   const int o0 = ot * 64, c0 = ct * 64, ky0 = kyg * TYS;
   const int PW = p.TW + KS - 1, PHs = p.TH + TYS - 1;
   const int pplane = PHs * PW;
-  const int PP = pplane | 1;
+  constexpr int PP = WG_PP;
   const int NT = p.TH * p.TW, halfrows = p.TH >> 1;
-  const long HW = (long)p.H * p.W, HoWo = (long)p.Ho * p.Wo;
+  const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
   const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
   const float slope = has_slope ? *p.in_slope : 1.f;
   const bool wave_active = (c0 + wc * 32 < p.Cin) && (o0 + wo * 32 < p.O);
@@ -381,62 +393,79 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // staging geometry of this thread
-  const int gq = lane;                                   // gradient pixel slot
-  const int gty = gq / p.TW, gtx = gq - gty * p.TW;
+  // ---- per-lane staging geometry (fixed for the whole launch)
+  const int g_ty = lane / p.TW, g_tx = lane - g_ty * p.TW;
+  const bool g_in = lane < NT;
+  int p_r[WG_PM], p_c[WG_PM];
+  bool p_in[WG_PM];
+#pragma unroll
+  for (int m = 0; m < WG_PM; ++m) {
+    const int e = lane + 64 * m;
+    p_r[m] = e / PW; p_c[m] = e - p_r[m] * PW;
+    p_in[m] = e < pplane;
+  }
+  // the 16 channels / gradient rows this wave stages
+  const int so0 = o0 + wave * 16, sc0 = c0 + wave * 16;
+
   const int nPix = p.tilesX * p.tilesY;
   for (int t = split; t < nPix; t += p.nSplit) {
     const int oy0 = (t / p.tilesX) * p.TH, ox0 = (t % p.tilesX) * p.TW;
-    // ---- stage gradient tile gs[o][q]
-    {
-      const int oy = oy0 + gty, ox = ox0 + gtx;
-      const bool ok = gq < NT && oy < p.Ho && ox < p.Wo;
-      const long pofs = (long)oy * p.Wo + ox;
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int o = wave + it * 4;
-        float v = 0.f;
-        if (ok && o0 + o < p.O) v = p.g[(size_t)(o0 + o) * HoWo + pofs];
-        gs[o * WG_NTP + gq] = v;
-      }
-    }
-    // ---- stage input patch ps[c][r][col] with the producer's activation fused
-    {
+    if (!(p.dbg & 4)) {
+      // Staging = two batches of 8 rows/channels.  Every batch issues ALL its global loads first
+      // (unconditional, offsets clamped into the tensor -> no divergent branches, one latency
+      // exposure per batch), then selects the zero fill and writes LDS.
+      const int goy = oy0 + g_ty, gox = ox0 + g_tx;
+      const bool gok = g_in && goy < p.Ho && gox < p.Wo;
+      const int gofs = gok ? goy * p.Wo + gox : 0;
+      int pofs[WG_PM];
+      bool pok[WG_PM];
 #pragma unroll
-      for (int it = 0; it < WG_MAXIT; ++it) {
-        if (it * 256 < pplane) {
-          const int e = tid + it * 256;
-          if (e < pplane) {
-            const int r = e / PW, col = e - r * PW;
-            const int iy = oy0 - p.pad + ky0 + r, ix = ox0 - p.pad + col;
-            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const long gofs = (long)iy * p.W + ix;
-            for (int c = 0; c < 64; ++c) {
-              float v = 0.f;
-              if (ok && c0 + c < p.Cin) {
-                v = p.in[(size_t)(c0 + c) * HW + gofs];
-                if (has_slope) v = v > 0.f ? v : slope * v;
-                if (has_scale) v *= p.in_scale[c0 + c];
-              }
-              ps[c * PP + e] = v;
-            }
+      for (int m = 0; m < WG_PM; ++m) {
+        const int iy = oy0 - p.pad + ky0 + p_r[m], ix = ox0 - p.pad + p_c[m];
+        pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pofs[m] = pok[m] ? iy * p.W + ix : 0;
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float vg[8], vp[8][WG_PM];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = so0 + b * 8 + j, c = sc0 + b * 8 + j;
+          vg[j] = p.g[(size_t)(o < p.O ? o : 0) * HoWo + gofs];
+          const float* ip = p.in + (size_t)(c < p.Cin ? c : 0) * HW;
+#pragma unroll
+          for (int m = 0; m < WG_PM; ++m) vp[j][m] = ip[pofs[m]];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = so0 + b * 8 + j, c = sc0 + b * 8 + j;
+          const bool cok = c < p.Cin;
+          const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
+          gs[(wave * 16 + b * 8 + j) * WG_NTP + lane] = (gok && o < p.O) ? vg[j] : 0.f;
+#pragma unroll
+          for (int m = 0; m < WG_PM; ++m) {
+            float v = vp[j][m];
+            if (has_slope) v = v > 0.f ? v : slope * v;
+            if (has_scale) v *= sc;
+            ps[(wave * 16 + b * 8 + j) * WG_PP + lane + 64 * m] = (pok[m] && cok) ? v : 0.f;
           }
         }
       }
     }
     __syncthreads();
-    if (wave_active) {
+    if (wave_active && !(p.dbg & 2)) {
       const float* ga = gs + (wo * 32 + li) * WG_NTP + h * halfrows * p.TW;
       const float* pb = ps + (wc * 32 + li) * PP + h * halfrows * PW;
       for (int r = 0; r < halfrows; ++r) {
+        const float* gar = ga + r * p.TW;
+        const float* pbr = pb + r * PW;
         for (int x = 0; x < p.TW; ++x) {
-          const float a = ga[r * p.TW + x];
-          const float* pbx = pb + r * PW + x;
+          const float a = gar[x];
 #pragma unroll
           for (int ty = 0; ty < TYS; ++ty)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
-              const float b = pbx[ty * PW + kx];
+              const float b = pbr[x + ty * PW + kx];
               acc[ty * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ty * KS + kx], 0, 0, 0);
             }
         }
@@ -444,9 +473,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
     __syncthreads();
   }
-  // ---- epilogue: D col = lane&31 -> c, row -> o
-  if (wave_active) {
+  // ---- epilogue: D col = lane&31 -> c (contiguous in the slab), row -> o
+  if (wave_active && !(p.dbg & 1)) {
     const int c = c0 + wc * 32 + li;
+    const size_t OC = (size_t)p.O * p.Cin;
+    float* sl = p.slab + (size_t)split * KS * KS * OC;
 #pragma unroll
     for (int ty = 0; ty < TYS; ++ty) {
       const int ky = ky0 + ty;
@@ -455,22 +486,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (o < p.O && c < p.Cin && ky < KS)
-            unsafeAtomicAdd(p.gw + (((size_t)o * p.Cin + c) * KS + ky) * KS + kx, acc[ty * KS + kx][r]);
+          if (o < p.O && c < p.Cin && ky < KS) sl[(size_t)(ky * KS + kx) * OC + (size_t)o * p.Cin + c] = acc[ty * KS + kx][r];
         }
       }
     }
   }
 }
 
-static void choose_wgrad_tile(int Ho, int Wo, int* TH, int* TW) {
+// gw[o][c][tap] += sum_s slab[s][tap][o][c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nSplit, int taps, int OC, float* __restrict__ gw) {
+  const long total = (long)taps * OC;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(t / OC);
+    const int oc = (int)(t - (long)tap * OC);
+    float s0 = 0.f, s1 = 0.f;
+    int s = 0;
+    for (; s + 1 < nSplit; s += 2) {
+      s0 += slab[(size_t)s * total + t];
+      s1 += slab[(size_t)(s + 1) * total + t];
+    }
+    if (s < nSplit) s0 += slab[(size_t)s * total + t];
+    gw[(size_t)oc * taps + tap] += s0 + s1;
+  }
+}
+
+static void choose_wgrad_tile(int Ho, int Wo, int k, int tys, int* TH, int* TW) {
   long best = -1;
   int bth = 2, btw = 1;
   for (int th = 2; th <= 8; th += 2) {
     for (int tw = 1; tw <= std::min(Wo, WG_NT / th); ++tw) {
       if (tw < 8 && Wo >= 8) continue;
+      if ((th + tys - 1) * (tw + k - 1) > 64 * WG_PM) continue;
       long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
-      long cost = tiles * th * tw + tiles * 24;  // K-steps + per-tile staging overhead
+      long cost = tiles * th * tw * (long)(k * tys) + tiles * 64;  // MFMA K-steps + per-tile staging/barrier overhead
       if (best < 0 || cost < best || (cost == best && tw > btw)) {
         best = cost; bth = th; btw = tw;
       }
@@ -479,10 +527,34 @@ static void choose_wgrad_tile(int Ho, int Wo, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
+static void wgrad_plan(WgradArgs& a, int k) {
+  const int tys = k == 3 ? 3 : 1;
+  choose_wgrad_tile(a.Ho, a.Wo, k, tys, &a.TH, &a.TW);
+  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
+  a.oTiles = cdiv(a.O, 64); a.cTiles = cdiv(a.Cin, 64);
+  a.kyGroups = k / tys;
+  long base = (long)a.oTiles * a.cTiles * a.kyGroups;
+  long npix = (long)a.tilesX * a.tilesY;
+  // two blocks per CU: aim for ~512 blocks
+  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (512 + base / 2) / base));
+  a.dbg = 0;
+  if (const char* e = getenv("FRCNN_WG_DBG")) a.dbg = atoi(e);
+  if (const char* e = getenv("FRCNN_WG_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
+}
+
+size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad) {
+  WgradArgs a;
+  a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
+  a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
+  wgrad_plan(a, k);
+  return (size_t)a.nSplit * k * k * O * Cin * 4 + 256;
+}
+
 template <int KS, int TYS>
-static int launch_wgrad(WgradArgs& a, int klass, double flops, hipStream_t s) {
+static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStream_t s) {
   int pplane = (a.TH + TYS - 1) * (a.TW + KS - 1);
-  size_t lds = ((size_t)64 * WG_NTP + (size_t)64 * (pplane | 1)) * 4;
+  (void)pplane;
+  size_t lds = ((size_t)64 * WG_NTP + (size_t)64 * WG_PP) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, TYS>),
@@ -491,32 +563,36 @@ static int launch_wgrad(WgradArgs& a, int klass, double flops, hipStream_t s) {
   }
   int grid = a.oTiles * a.cTiles * a.kyGroups * a.nSplit;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
-  FR_LAUNCH(klass, flops, bytes, s, (conv_wgrad_kernel<KS, TYS>), dim3(grid), dim3(256), lds, a);
+  if (frcnn::prof_enabled(klass)) frcnn::prof_before(klass, s);
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS, TYS>), dim3(grid), dim3(256), lds, s, a);
+  const int OC = a.O * a.Cin;
+  long total = (long)KS * KS * OC;
+  int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
+  if (!(a.dbg & 1))
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)a.slab, a.nSplit, KS * KS, OC, gw);
+  if (frcnn::prof_enabled(klass)) frcnn::prof_after(klass, flops, bytes, s);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
-               const float* g, int O, int k, int pad, float* gw, hipStream_t s) {
+               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s) {
   WgradArgs a;
-  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g; a.gw = gw;
+  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
-  choose_wgrad_tile(a.Ho, a.Wo, &a.TH, &a.TW);
-  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
-  a.oTiles = cdiv(O, 64); a.cTiles = cdiv(Cin, 64);
-  const int tys = k == 3 ? 3 : 1;
-  a.kyGroups = k / tys;
-  long base = (long)a.oTiles * a.cTiles * a.kyGroups;
-  long npix = (long)a.tilesX * a.tilesY;
-  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, cdivl(1024, base)));
+  FR_CHECK((long)Cin * H * W < (1L << 31) && (long)O * a.Ho * a.Wo < (1L << 31), "conv_wgrad: tensor too large for 32-bit offsets");
+  wgrad_plan(a, k);
+  size_t need = (size_t)a.nSplit * k * k * O * Cin * 4 + 256;
+  FR_CHECK(ws && ws_bytes >= need, "conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  a.slab = (float*)(((uintptr_t)ws + 255) / 256 * 256);
   double flops = 2.0 * O * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_WGRAD_K3 : KC_CONV_WGRAD_OTHER;
-  if (k == 3) return launch_wgrad<3, 3>(a, klass, flops, s);
-  if (k == 1) return launch_wgrad<1, 1>(a, klass, flops, s);
-  if (k == 5) return launch_wgrad<5, 1>(a, klass, flops, s);
-  return launch_wgrad<7, 1>(a, klass, flops, s);
+  if (k == 3) return launch_wgrad<3, 3>(a, klass, flops, gw, s);
+  if (k == 1) return launch_wgrad<1, 1>(a, klass, flops, gw, s);
+  if (k == 5) return launch_wgrad<5, 1>(a, klass, flops, gw, s);
+  return launch_wgrad<7, 1>(a, klass, flops, gw, s);
 }
 
 }  // namespace frcnn

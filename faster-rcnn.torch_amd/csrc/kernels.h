@@ -25,8 +25,10 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
                double algo_flops, hipStream_t s);
 
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (atomic accumulation)
+// `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.
+size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
-               const float* g, int O, int k, int pad, float* gw, hipStream_t s);
+               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s);
 
 // ---------------------------------------------------------------- elementwise (elem.hip)
 int fill_zero(void* p, size_t bytes, hipStream_t s);

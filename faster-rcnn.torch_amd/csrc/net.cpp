@@ -85,6 +85,7 @@ struct frcnn_model {
   int H = 0, W = 0;            // current image size
   int training = 0;
   DevBuf delta_last;           // delta_outputs[nheads+1]
+  DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
   int R = 0, D = 0;
@@ -214,6 +215,13 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
   }
   const Block& last = m->blocks.back();
   FR_TRY(m->delta_last.ensure((size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4));
+  size_t wsb = 0;
+  for (auto& c : m->convs) wsb = std::max(wsb, conv_wgrad_workspace_bytes(c.Cin, c.H, c.W, c.Cout, c.k, c.pad));
+  for (auto& hd : m->heads) {
+    wsb = std::max(wsb, conv_wgrad_workspace_bytes(hd.c3.Cin, hd.c3.H, hd.c3.W, hd.c3.Cout, hd.c3.k, 0));
+    wsb = std::max(wsb, conv_wgrad_workspace_bytes(hd.c1.Cin, hd.c1.H, hd.c1.W, hd.c1.Cout, 1, 0));
+  }
+  FR_TRY(m->wg_ws.ensure(wsb));
   m->H = H; m->W = W;
   return FRCNN_OK;
 }
@@ -252,7 +260,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
-  m->img.release();
+  m->img.release(); m->wg_ws.release();
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
   delete m;
@@ -399,7 +407,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     Conv &a = h.c3, &c = h.c1;
     const long hw1 = (long)c.Ho * c.Wo;
     // 1x1 conv: accGradParameters + updateGradInput
-    FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, s));
+    FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
     FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));
     double f1 = 2.0 * HEAD_OUT * c.Cin * (double)hw1;
     FR_TRY(conv_igemm(h.delta.f(), HEAD_OUT, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, 1, 0, a.gx.f(),
@@ -407,7 +415,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     // PReLU backward of the head (+ bias gradient of the k x k conv)
     FR_TRY(act_backward(a.gx.f(), a.x.f(), a.Cout, (long)a.Ho * a.Wo, w + a.a_off, nullptr, a.gx.f(),
                         grad + a.b_off, grad + a.a_off, s));
-    FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, s));
+    FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
     double f3 = 2.0 * a.Cout * a.Cin * a.k * a.k * (double)a.Ho * a.Wo;
     FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
                       in.gpooled.f(), OUT_ADD, f3, s));  // nngraph fan-out: gradients add up
@@ -433,7 +441,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
-      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, s));
+      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
       if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       if (st > 0) {

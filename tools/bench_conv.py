@@ -1,0 +1,55 @@
+"""Micro-benchmark of the conv kernels on the vgg_small 800x450 layer shapes (HIP-event timing through the
+library's per-class profiler).  usage: python tools/bench_conv.py [wgrad|fwd|dgrad] [layer ...]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import frcnn_amd as F
+
+LAYERS = {  # name: (Cin, H, W, Cout, k, pad)
+    "b1c1": (3, 450, 800, 64, 3, 1), "b2c1": (64, 225, 400, 128, 3, 1), "b2c2": (128, 225, 400, 128, 3, 1),
+    "b3c1": (128, 113, 200, 256, 3, 1), "b3c2": (256, 113, 200, 256, 3, 1), "b4c1": (256, 57, 100, 384, 3, 1),
+    "b4c2": (384, 57, 100, 384, 3, 1), "a1": (256, 57, 100, 256, 3, 0), "a2": (384, 29, 50, 256, 3, 0),
+    "a3": (384, 29, 50, 256, 5, 0), "a4": (384, 29, 50, 256, 7, 0), "a1x": (256, 55, 98, 18, 1, 0),
+}
+
+
+def run(kind, name, reps=5):
+    Cin, H, W, O, k, pad = LAYERS[name]
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    rng = np.random.RandomState(0)
+    x = F.DeviceTensor.from_numpy(rng.randn(Cin, H, W).astype(np.float32))
+    g = F.DeviceTensor.from_numpy(rng.randn(O, Ho, Wo).astype(np.float32))
+    w = F.DeviceTensor.from_numpy((rng.randn(O, Cin, k, k) * 0.05).astype(np.float32))
+    gw = F.DeviceTensor.zeros((O, Cin, k, k)); out = F.DeviceTensor.empty((O, Ho, Wo)); gin = F.DeviceTensor.empty((Cin, H, W))
+    s = F.stream_ptr()
+    nk = len(F._lib.KC_NAMES)
+    la = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
+
+    def once():
+        if kind == "wgrad":
+            F._lib.call("frcnn_conv2d_backward_weight", F.ptr(x), Cin, H, W, None, None, F.ptr(g), O, k, pad, F.ptr(gw), None, s)
+        elif kind == "fwd":
+            F._lib.call("frcnn_conv2d_forward", F.ptr(x), Cin, H, W, None, None, F.ptr(w), None, O, k, pad, F.ptr(out), s)
+        else:
+            F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O, Ho, Wo, F.ptr(w), Cin, k, pad, F.ptr(gin), 0, s)
+    once()
+    F._lib.call("frcnn_prof_enable", 0xF)
+    for _ in range(reps):
+        once()
+    F._lib.call("frcnn_prof_enable", 0)
+    F._lib.call("frcnn_prof_collect", la, ms, fl, by)
+    t = sum(ms[i] for i in range(4)) / reps
+    flops = 2.0 * O * Cin * k * k * Ho * Wo
+    print("%-6s %-5s %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)" % (kind, name, t * 1e3, flops / t / 1e9, flops / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    kind = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
+    names = sys.argv[2:] or list(LAYERS)
+    for n in names:
+        run(kind, n)
