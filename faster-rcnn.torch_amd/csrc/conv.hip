@@ -91,19 +91,18 @@ struct IgemmArgs {
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 2 atomic add
+  int dbg;                // tuning knobs: bit0 skip epilogue, bit1 skip MFMA, bit2 skip staging, bit3 skip barriers
 };
 
 #define IG_MAXIT 4  // patch plane <= 1024 positions
 
-template <int KS, int CC, int BM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
+template <int KS, int CC, int BM, bool DB, int NIT>
+__global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(IgemmArgs p) {
   constexpr int KC = CC * KS * KS;   // K rows per chunk
   constexpr int WM = BM / 2;         // 2x2 waves
   constexpr int MT = WM / 32;        // 32x32 tiles per wave along M
   constexpr int NTW = 2;             // ... along N (wave covers 64 pixels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;            // [KC][BM]
-  float* Bs = smem + KC * BM;  // [CC][plane]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -118,31 +117,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
   const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
   const int m0 = mt_id * BM;
   const int PW = p.TW + KS - 1, PH = p.TH + KS - 1, plane = PH * PW;
+  constexpr int planeP = NIT * 256;          // LDS stride of one patch channel (stores are unconditional)
   const int NT = p.TH * p.TW;
-  const long HW = (long)p.H * p.W;
+  const int HW = p.H * p.W;
+  constexpr int bufFloats = KC * BM + CC * planeP;  // one LDS buffer: As[KC][BM] then Bs[CC][planeP]
 
   // this thread's patch positions (same for every channel and chunk)
-  int gofs[IG_MAXIT];
+  int gofs[NIT];
+  bool gok[NIT];
 #pragma unroll
-  for (int it = 0; it < IG_MAXIT; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     int e = tid + it * 256;
     int r = e / PW, col = e - r * PW;
     int gy = ty0 - p.pad + r, gx = tx0 - p.pad + col;
-    bool ok = e < plane && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    gofs[it] = ok ? gy * p.W + gx : -1;
+    gok[it] = e < plane && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    gofs[it] = gok[it] ? gy * p.W + gx : 0;   // clamped: loads are unconditional, zero fill by select
   }
   const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
   const float slope = has_slope ? *p.in_slope : 1.f;
 
-  // lane bases for the MFMA operand reads
-  const float* Abase = As + h * BM + wm * WM + li;
+  // lane offsets of the MFMA operand reads inside a buffer
+  const int aoff = h * BM + wm * WM + li;
   int boff[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     int q = wn * 64 + nt * 32 + li;
     q = q < NT ? q : NT - 1;
     int ty = q / p.TW, tx = q - ty * p.TW;
-    boff[nt] = h * plane + ty * PW + tx;
+    boff[nt] = KC * BM + h * planeP + ty * PW + tx;
   }
 
   f32x16 acc[MT][NTW];
@@ -153,72 +155,107 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // staging registers: only the patch values; the weight rows go global -> LDS by DMA
+  float vb[CC][NIT];
+  // LDS-DMA geometry: one wave instruction moves 64 lanes x 16 B = 1 KiB = RPW consecutive rows of As
+  constexpr int RPW = 1024 / (BM * 4), NDMA = (KC + 4 * RPW - 1) / (4 * RPW);
+  const int dma_row = __builtin_amdgcn_readfirstlane(wave) * RPW + lane / (BM / 4);
+  const int dma_col = (lane % (BM / 4)) * 4;
+
+  // All global loads of a chunk are issued back to back (unconditional, clamped offsets): one
+  // latency exposure per chunk, hidden behind the previous chunk's MFMAs when DB.
+  auto stage_load = [&](int chunk, float* buf) {
+    // weights: `global_load_lds_dwordx4` (LDS destination = wave-uniform base + lane*16, i.e. the linear
+    // As[KC][BM] image); completion is covered by the vmcnt(0) that __syncthreads() carries.
+    const float* srcA = p.wp + ((size_t)chunk * KC) * p.Mpad + m0 + dma_col;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int r = dma_row + i * 4 * RPW;
+      if (r < KC)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + (size_t)r * p.Mpad),
+                                         (__attribute__((address_space(3))) void*)(buf + (__builtin_amdgcn_readfirstlane(wave) * RPW + i * 4 * RPW) * BM),
+                                         16, 0, 0);
+    }
+    const int c0 = chunk * CC;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      const int c = c0 + cc;
+      const float* src = p.in + (size_t)(c < p.Cin ? c : 0) * HW;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) vb[cc][it] = src[gofs[it]];
+    }
+  };
+  // registers -> LDS; the producing layer's PReLU / dropout scale is applied here
+  auto stage_store = [&](int chunk, float* buf) {
+    const int c0 = chunk * CC;
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc) {
+      const int c = c0 + cc;
+      const bool cok = c < p.Cin;
+      const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+          float v = vb[cc][it];
+          if (has_slope) v = v > 0.f ? v : slope * v;
+          if (has_scale) v *= sc;
+          buf[KC * BM + cc * planeP + tid + it * 256] = (cok && gok[it]) ? v : 0.f;
+        }
+    }
+  };
+  // MFMA over one staged chunk: K' order = ((cp*KS+ky)*KS+kx)*2 + h.  The operand fragments of
+  // k-pair i+1 are read from LDS BEFORE the MFMAs of k-pair i are issued (register double buffer +
+  // sched_group_barrier), so the ~100+ cycle LDS latency hides behind 4 x 64 cycles of matrix pipe.
+  auto compute = [&](const float* buf) {
+    constexpr int NKP = (CC / 2) * KS * KS;
+    float a[2][MT], b[2][NTW];
+    auto frag = [&](int kp, float* fa, float* fb) {
+      const int cp = kp / (KS * KS), ky = (kp / KS) % KS, kx = kp % KS;
+      const int rowoff = cp * 2 * planeP + ky * PW + kx;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = buf[aoff + kp * 2 * BM + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) fb[nt] = buf[boff[nt] + rowoff];
+    };
+    frag(0, a[0], b[0]);
+#pragma unroll
+    for (int kp = 0; kp < NKP; ++kp) {
+      const int cur = kp & 1;
+      if (kp + 1 < NKP) frag(kp + 1, a[cur ^ 1], b[cur ^ 1]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);  // DS reads of the next k-pair first
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);  // then this k-pair's MFMAs
+    }
+  };
+
   const int cbeg = split * p.chunksPerSplit;
   const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
-  for (int chunk = cbeg; chunk < cend; ++chunk) {
-    // ---- stage A (weights): KC rows x BM floats, 16 B per thread per pass
-    {
-      constexpr int TPR = BM / 4, RPP = 256 / TPR;
-      const int rr = tid / TPR, cq = (tid % TPR) * 4;
-      const float* src = p.wp + ((size_t)chunk * KC) * p.Mpad + m0 + cq;
-#pragma unroll 4
-      for (int r = rr; r < KC; r += RPP) {
-        float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * p.Mpad);
-        *reinterpret_cast<float4*>(As + r * BM + cq) = v;
-      }
-    }
-    // ---- stage B (input patch with halo), activation of the producing layer fused on load
-    {
-      const int c0 = chunk * CC;
-#pragma unroll
-      for (int cc = 0; cc < CC; ++cc) {
-        const int c = c0 + cc;
-        const bool cok = c < p.Cin;
-        const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
-        const float* src = p.in + (size_t)c * HW;
-#pragma unroll
-        for (int it = 0; it < IG_MAXIT; ++it) {
-          if (it * 256 < plane) {
-            int e = tid + it * 256;
-            if (e < plane) {
-              float v = 0.f;
-              if (cok && gofs[it] >= 0) {
-                v = src[gofs[it]];
-                if (has_slope) v = v > 0.f ? v : slope * v;
-                if (has_scale) v *= sc;
-              }
-              Bs[cc * plane + e] = v;
-            }
-          }
-        }
-      }
-    }
+  if (DB) {
+    // double-buffered LDS, one barrier per chunk: chunk k+1 is fetched into registers before the
+    // MFMAs of chunk k and written to the other buffer after them.
+    stage_load(cbeg, smem);
+    stage_store(cbeg, smem);
     __syncthreads();
-    // ---- MFMA: K' order inside the chunk = ((cp*KS+ky)*KS+kx)*2 + h
-#pragma unroll
-    for (int cp = 0; cp < CC / 2; ++cp) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const int rowoff = cp * 2 * plane + ky * PW;
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int kp = (cp * KS + ky) * KS + kx;
-          float a[MT], b[NTW];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = Abase[kp * 2 * BM + mt * 32];
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) b[nt] = Bs[boff[nt] + rowoff + kx];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-        }
-      }
+    int cur = 0;
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
+      const bool more = chunk + 1 < cend;
+      if (more) stage_load(chunk + 1, smem + (cur ^ 1) * bufFloats);
+      compute(smem + cur * bufFloats);
+      if (more) stage_store(chunk + 1, smem + (cur ^ 1) * bufFloats);
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
+  } else {
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
+      stage_load(chunk, smem);
+      stage_store(chunk, smem);
+      __syncthreads();
+      compute(smem);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
@@ -273,20 +310,28 @@ static void choose_tile(int Ho, int Wo, int k, int maxNT, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
-template <int KS, int CC, int BM>
-static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
-  size_t lds = ((size_t)CC * KS * KS * BM + (size_t)CC * (a.TH + KS - 1) * (a.TW + KS - 1)) * 4;
+template <int KS, int CC, int BM, bool DB, int NIT>
+static int launch_igemm_n(IgemmArgs& a, int klass, double flops, hipStream_t s) {
+  size_t lds = ((size_t)CC * KS * KS * BM + (size_t)CC * NIT * 256) * 4 * (DB ? 2 : 1);
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM, DB, NIT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM>), dim3(grid), dim3(256), lds, a);
+  FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM, DB, NIT>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+template <int KS, int CC, int BM, bool DB>
+static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
+  const int plane = (a.TH + KS - 1) * (a.TW + KS - 1);
+  if (plane <= 256) return launch_igemm_n<KS, CC, BM, DB, 1>(a, klass, flops, s);
+  if (plane <= 512) return launch_igemm_n<KS, CC, BM, DB, 2>(a, klass, flops, s);
+  return launch_igemm_n<KS, CC, BM, DB, 4>(a, klass, flops, s);
 }
 
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
@@ -307,9 +352,11 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
   int splitK = 1;
   if (blocks < 512) splitK = (int)std::min<long>(std::max<long>(1, 768 / blocks), std::max(1, a.nChunks / 2));
+  if (const char* e = getenv("FRCNN_IG_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
+  a.dbg = 0;
   if (a.splitK > 1) {
     if (out_mode == OUT_STORE) {  // initialise with the bias, then accumulate atomically
       long total = (long)M * a.Ho * a.Wo;
@@ -322,14 +369,19 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_IGEMM_K3 : KC_CONV_IGEMM_OTHER;
-  if (k == 3) return BM == 64 ? launch_igemm<3, 8, 64>(a, klass, algo_flops, s)
-                              : launch_igemm<3, 8, 128>(a, klass, algo_flops, s);
-  if (k == 1) return BM == 64 ? launch_igemm<1, 32, 64>(a, klass, algo_flops, s)
-                              : launch_igemm<1, 32, 128>(a, klass, algo_flops, s);
-  if (k == 5) return BM == 64 ? launch_igemm<5, 2, 64>(a, klass, algo_flops, s)
-                              : launch_igemm<5, 2, 128>(a, klass, algo_flops, s);
-  return BM == 64 ? launch_igemm<7, 2, 64>(a, klass, algo_flops, s)
-                  : launch_igemm<7, 2, 128>(a, klass, algo_flops, s);
+  if (k == 3 && Cin <= 4) {  // first layer: a 4-channel chunk (the packed rows are ordered by channel pair)
+    a.nChunks = 1; a.chunksPerSplit = 1; a.splitK = 1; a.out_mode = out_mode; a.bias = bias;
+    return BM == 64 ? launch_igemm<3, 4, 64, false>(a, klass, algo_flops, s)
+                    : launch_igemm<3, 4, 128, false>(a, klass, algo_flops, s);
+  }
+  if (k == 3) return BM == 64 ? launch_igemm<3, 8, 64, false>(a, klass, algo_flops, s)
+                              : launch_igemm<3, 8, 128, false>(a, klass, algo_flops, s);
+  if (k == 1) return BM == 64 ? launch_igemm<1, 32, 64, true>(a, klass, algo_flops, s)
+                              : launch_igemm<1, 32, 128, true>(a, klass, algo_flops, s);
+  if (k == 5) return BM == 64 ? launch_igemm<5, 2, 64, false>(a, klass, algo_flops, s)
+                              : launch_igemm<5, 2, 128, false>(a, klass, algo_flops, s);
+  return BM == 64 ? launch_igemm<7, 2, 64, false>(a, klass, algo_flops, s)
+                  : launch_igemm<7, 2, 128, false>(a, klass, algo_flops, s);
 }
 
 // ------------------------------------------------------------------------------------------
