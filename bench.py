@@ -186,7 +186,9 @@ def main():
             roofline=dict(bound="mfma", kernel="conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)",
                           achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                          launches_per_step=launches[k] / args.steps, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4)),
+                          launches_per_step=launches[k] / args.steps, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
+                          algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
+                          algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3)),
         )
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
