@@ -1,21 +1,22 @@
 #!/bin/bash
 # Builds faster-rcnn.torch_amd/libfrcnn_hip.so for gfx950 (hipcc cross-compiles without a GPU).
-set -e
-cd "$(dirname "$0")/faster-rcnn.torch_amd/csrc"
+cd "$(dirname "$0")/faster-rcnn.torch_amd/csrc" || exit 1
 OUT=../libfrcnn_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed"
 mkdir -p ../build
-pids=()
-for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip; do
-  if [ ! -f ../build/${f%.hip}.o ] || [ $f -nt ../build/${f%.hip}.o ] || [ kernels.h -nt ../build/${f%.hip}.o ] || [ common.h -nt ../build/${f%.hip}.o ] || [ ../../include/frcnn_hip.h -nt ../build/${f%.hip}.o ]; then
-    hipcc $FLAGS -c $f -o ../build/${f%.hip}.o &
-    pids+=($!)
+pids=(); names=()
+for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip api.cpp net.cpp; do
+  o=../build/${f%.*}.o
+  if [ "$FORCE" = "1" ] || [ ! -f $o ] || [ $f -nt $o ] || [ kernels.h -nt $o ] || [ common.h -nt $o ] || [ ../../include/frcnn_hip.h -nt $o ]; then
+    case $f in *.cpp) X="-x hip";; *) X="";; esac
+    hipcc $FLAGS $X -c $f -o $o &
+    pids+=($!); names+=($f)
   fi
 done
-for f in api.cpp net.cpp; do
-  hipcc $FLAGS -x hip -c $f -o ../build/${f%.cpp}.o &
-  pids+=($!)
+fail=0
+for i in "${!pids[@]}"; do
+  if ! wait ${pids[$i]}; then echo "build_lib.sh: error: compiling ${names[$i]} failed" >&2; fail=1; fi
 done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC ../build/*.o -o $OUT
+[ $fail = 0 ] || exit 1
+hipcc --offload-arch=gfx950 -shared -fPIC ../build/*.o -o $OUT || { echo "build_lib.sh: error: link failed" >&2; exit 1; }
 echo "built $OUT"
