@@ -10,33 +10,50 @@ namespace frcnn {
 #define BN_EPS 1e-5
 #define BN_MOM 0.1
 
-// thread per feature j; rows are read with stride n (coalesced across threads)
-__global__ void bn_forward_kernel(const float* __restrict__ x, int R, int n, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, float* running, int training,
-                                  float* __restrict__ xhat, float* __restrict__ invstd, float* __restrict__ y) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// Block = 64 features x 16 row groups (1024 threads): lanes run along the feature dimension
+// (coalesced), the 16 row groups split the R rows and meet in LDS.  fp64 partial sums.
+#define BN_RG 16
+__device__ __forceinline__ double bn_reduce(double v, double* sh, int tx, int ty) {
+  sh[ty * 64 + tx] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < BN_RG; ++g) s += sh[g * 64 + tx];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void bn_forward_kernel(const float* __restrict__ x, int R, int n,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running, int training, float* __restrict__ xhat,
+                                                          float* __restrict__ invstd, float* __restrict__ y) {
+  __shared__ double sh[BN_RG * 64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int j = blockIdx.x * 64 + tx;
+  const bool ok = j < n;
   double mean, var;
   if (training) {
-    mean = 0.0;
-    for (int r = 0; r < R; ++r) mean += x[(size_t)r * n + j];
-    mean /= R;
-    var = 0.0;
-    for (int r = 0; r < R; ++r) { double d = x[(size_t)r * n + j] - mean; var += d * d; }
+    double s = 0.0;
+    if (ok) for (int r = ty; r < R; r += BN_RG) s += x[(size_t)r * n + j];
+    mean = bn_reduce(s, sh, tx, ty) / R;
+    double q = 0.0;
+    if (ok) for (int r = ty; r < R; r += BN_RG) { double d = x[(size_t)r * n + j] - mean; q += d * d; }
+    var = bn_reduce(q, sh, tx, ty);
     const double unb = R > 1 ? var / (R - 1) : var / R;
     var /= R;
-    if (running) {
+    if (running && ok && ty == 0) {
       running[j] = (float)((1.0 - BN_MOM) * running[j] + BN_MOM * mean);
       running[n + j] = (float)((1.0 - BN_MOM) * running[n + j] + BN_MOM * unb);
     }
   } else {
-    mean = running[j];
-    var = running[n + j];
+    mean = ok ? running[j] : 0.0;
+    var = ok ? running[n + j] : 1.0;
   }
+  if (!ok) return;
   const double is = 1.0 / sqrt(var + BN_EPS);
-  invstd[j] = (float)is;
+  if (ty == 0) invstd[j] = (float)is;
   const double g = gamma[j], b = beta[j];
-  for (int r = 0; r < R; ++r) {
+  for (int r = ty; r < R; r += BN_RG) {
     const double xh = (x[(size_t)r * n + j] - mean) * is;
     xhat[(size_t)r * n + j] = (float)xh;
     y[(size_t)r * n + j] = (float)(xh * g + b);
@@ -45,27 +62,36 @@ __global__ void bn_forward_kernel(const float* __restrict__ x, int R, int n, con
 int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,
                int training, float* xhat, float* invstd, float* y, hipStream_t s) {
   FR_CHECK(training || running, "bn_forward: evaluate mode needs running statistics");
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_forward_kernel, dim3(cdiv(n, 64)), dim3(64), 0, x, R, n,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_forward_kernel, dim3(cdiv(n, 64)), dim3(64, BN_RG), 0, x, R, n,
             gamma, beta, running, training, xhat, invstd, y);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
-__global__ void bn_backward_kernel(const float* __restrict__ gy, const float* __restrict__ xhat,
-                                   const float* __restrict__ invstd, const float* __restrict__ gamma, int R,
-                                   int n, int training, float* __restrict__ gx, float* ggamma, float* gbeta) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+__global__ __launch_bounds__(1024) void bn_backward_kernel(const float* __restrict__ gy, const float* __restrict__ xhat,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           int R, int n, int training, float* __restrict__ gx, float* ggamma,
+                                                           float* gbeta) {
+  __shared__ double sh[BN_RG * 64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int j = blockIdx.x * 64 + tx;
+  const bool ok = j < n;
   double sg = 0.0, sgx = 0.0;
-  for (int r = 0; r < R; ++r) {
-    const double g = gy[(size_t)r * n + j];
-    sg += g;
-    sgx += g * xhat[(size_t)r * n + j];
+  if (ok)
+    for (int r = ty; r < R; r += BN_RG) {
+      const double g = gy[(size_t)r * n + j];
+      sg += g;
+      sgx += g * xhat[(size_t)r * n + j];
+    }
+  sg = bn_reduce(sg, sh, tx, ty);
+  sgx = bn_reduce(sgx, sh, tx, ty);
+  if (!ok) return;
+  if (ty == 0) {
+    ggamma[j] = (float)((double)ggamma[j] + sgx);
+    gbeta[j] = (float)((double)gbeta[j] + sg);
   }
-  ggamma[j] = (float)((double)ggamma[j] + sgx);
-  gbeta[j] = (float)((double)gbeta[j] + sg);
   const double is = invstd[j], gm = gamma[j];
-  for (int r = 0; r < R; ++r) {
+  for (int r = ty; r < R; r += BN_RG) {
     const double g = gy[(size_t)r * n + j];
     const double xh = xhat[(size_t)r * n + j];
     const double v = training ? (g - sg / R - xh * sgx / R) * gm * is : g * gm * is;
@@ -74,7 +100,7 @@ __global__ void bn_backward_kernel(const float* __restrict__ gy, const float* __
 }
 int bn_backward(const float* gy, const float* xhat, const float* invstd, const float* gamma, int R,
                 int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s) {
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, 64)), dim3(64), 0, gy,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, 64)), dim3(64, BN_RG), 0, gy,
             xhat, invstd, gamma, R, n, training, gx, ggamma, gbeta);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;

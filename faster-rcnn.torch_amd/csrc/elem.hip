@@ -238,16 +238,24 @@ int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s) {
   return FRCNN_OK;
 }
 
-// gb[o] += sum_r g[r][o]  (row-major R x O; nn.Linear bias gradient)
-__global__ void channel_sum_cols_kernel(const float* __restrict__ g, int R, int O, float* gb) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= O) return;
+// gb[o] += sum_r g[r][o]  (row-major R x O; nn.Linear bias gradient): 64 columns x 16 row groups per block
+__global__ __launch_bounds__(1024) void channel_sum_cols_kernel(const float* __restrict__ g, int R, int O, float* gb) {
+  __shared__ float sh[16 * 64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int o = blockIdx.x * 64 + tx;
   float sacc = 0.f;
-  for (int r = 0; r < R; ++r) sacc += g[(size_t)r * O + o];
-  gb[o] += sacc;
+  if (o < O) for (int r = ty; r < R; r += 16) sacc += g[(size_t)r * O + o];
+  sh[ty * 64 + tx] = sacc;
+  __syncthreads();
+  if (ty == 0 && o < O) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k * 64 + tx];
+    gb[o] += t;
+  }
 }
 int channel_sum_cols(const float* g, int R, int O, float* gb, hipStream_t s) {
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * O * 4.0, s, channel_sum_cols_kernel, dim3(cdiv(O, 64)), dim3(64), 0, g, R,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * O * 4.0, s, channel_sum_cols_kernel, dim3(cdiv(O, 64)), dim3(64, 16), 0, g, R,
             O, gb);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;

@@ -24,7 +24,64 @@ struct GemmArgs {
   int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 2 atomic
 };
 
-template <bool AK, bool BK_>
+// Operand tile loader: 64 (rows: m or n) x 32 (k) floats -> LDS image T[k][row] (pitch GP).
+// KC: the operand is contiguous along k (else along the row index).  VEC: 16-byte loads are legal
+// (strides multiple of 4 floats, base 16-byte aligned).  All loads of the tile are issued first with
+// clamped indices, zero fill by select, then the LDS writes: one latency exposure per k-block.
+template <bool KC, bool VEC>
+struct TileLoader {
+  float4 v4[2];
+  float v1[8];
+  __device__ __forceinline__ void load(const float* __restrict__ P, long sRow, long sK, int row0, int nRows, int k0,
+                                       int kEnd, int tid) {
+    if (VEC) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        int r, k;
+        if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
+        else    { r = (tid & 15) * 4; k = (tid >> 4) + 16 * it; }
+        const int rr = min(row0 + r, nRows - (KC ? 1 : 4)), kk = min(k0 + k, kEnd - (KC ? 4 : 1));
+        v4[it] = *reinterpret_cast<const float4*>(P + (long)rr * sRow + (long)kk * sK);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int r, k;
+        if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
+        else    { r = tid & 63; k = (tid >> 6) + 4 * it; }
+        const int rr = min(row0 + r, nRows - 1), kk = min(k0 + k, kEnd - 1);
+        v1[it] = P[(long)rr * sRow + (long)kk * sK];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ T, int row0, int nRows, int k0, int kEnd, int tid) {
+    if (VEC) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        int r, k;
+        if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
+        else    { r = (tid & 15) * 4; k = (tid >> 4) + 16 * it; }
+        const float e[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rj = KC ? r : r + j, kj = KC ? k + j : k;
+          // VEC tiles are only used when every 4-group is entirely inside or outside the matrix
+          T[kj * GP + rj] = (row0 + rj < nRows && k0 + kj < kEnd) ? e[j] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int r, k;
+        if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
+        else    { r = tid & 63; k = (tid >> 6) + 4 * it; }
+        T[k * GP + r] = (row0 + r < nRows && k0 + k < kEnd) ? v1[it] : 0.f;
+      }
+    }
+  }
+};
+
+template <bool AK, bool BK_, bool AV, bool BV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   __shared__ float As[GBK * GP];
   __shared__ float Bs[GBK * GP];
@@ -36,27 +93,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  TileLoader<AK, AV> la;
+  TileLoader<BK_, BV> lb;
 
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    // ---- stage A[64][32] -> As[k][m]
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      int m, k;
-      if (AK) { k = tid & 31; m = (tid >> 5) + 8 * it; }
-      else    { m = tid & 63; k = (tid >> 6) + 4 * it; }
-      float v = 0.f;
-      if (m0 + m < p.M && k0 + k < kend) v = p.A[(long)(m0 + m) * p.sAm + (long)(k0 + k) * p.sAk];
-      As[k * GP + m] = v;
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      int n, k;
-      if (BK_) { k = tid & 31; n = (tid >> 5) + 8 * it; }
-      else     { n = tid & 63; k = (tid >> 6) + 4 * it; }
-      float v = 0.f;
-      if (n0 + n < p.N && k0 + k < kend) v = p.B[(long)(k0 + k) * p.sBk + (long)(n0 + n) * p.sBn];
-      Bs[k * GP + n] = v;
-    }
+    la.load(p.A, p.sAm, p.sAk, m0, p.M, k0, kend, tid);
+    lb.load(p.B, p.sBn, p.sBk, n0, p.N, k0, kend, tid);
+    la.store(As, m0, p.M, k0, kend, tid);
+    lb.store(Bs, n0, p.N, k0, kend, tid);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < GBK / 2; ++kk) {
@@ -116,10 +160,27 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   double flops = 2.0 * M * N * (double)K;
   double bytes = 4.0 * ((double)M * K + (double)K * N + (double)M * N);
   const bool ak = sAk == 1, bk = sBk == 1;
-  if (ak && bk) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<true, true>), grid, dim3(256), 0, p);
-  else if (ak && !bk) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<true, false>), grid, dim3(256), 0, p);
-  else if (!ak && bk) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<false, true>), grid, dim3(256), 0, p);
-  else FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<false, false>), grid, dim3(256), 0, p);
+  // 16-byte loads need: contiguous dimension a multiple of 4 inside the matrix, strides multiple of 4, aligned base
+  auto vec_ok = [](const float* P, bool kc, long sRow, long sK, int nRows, int Kdim, int kPer) {
+    if (((uintptr_t)P & 15) != 0) return false;
+    if (kc) return sK == 1 && (sRow % 4) == 0 && (Kdim % 4) == 0 && (kPer % 4) == 0;
+    return sRow == 1 && (sK % 4) == 0 && (nRows % 4) == 0;
+  };
+  const bool av = vec_ok(A, ak, sAm, sAk, M, K, p.kPerSplit), bv = vec_ok(B, bk, sBn, sBk, N, K, p.kPerSplit);
+  const int sel = (ak ? 8 : 0) | (bk ? 4 : 0) | (av ? 2 : 0) | (bv ? 1 : 0);
+#define GEMM_CASE(AKv, BKv, AVv, BVv)                                                                        \
+  case ((AKv ? 8 : 0) | (BKv ? 4 : 0) | (AVv ? 2 : 0) | (BVv ? 1 : 0)):                                      \
+    FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<AKv, BKv, AVv, BVv>), grid, dim3(256), 0, p);           \
+    break;
+  switch (sel) {
+    GEMM_CASE(true, true, true, true) GEMM_CASE(true, true, true, false) GEMM_CASE(true, true, false, true)
+    GEMM_CASE(true, true, false, false) GEMM_CASE(true, false, true, true) GEMM_CASE(true, false, true, false)
+    GEMM_CASE(true, false, false, true) GEMM_CASE(true, false, false, false) GEMM_CASE(false, true, true, true)
+    GEMM_CASE(false, true, true, false) GEMM_CASE(false, true, false, true) GEMM_CASE(false, true, false, false)
+    GEMM_CASE(false, false, true, true) GEMM_CASE(false, false, true, false) GEMM_CASE(false, false, false, true)
+    GEMM_CASE(false, false, false, false)
+  }
+#undef GEMM_CASE
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

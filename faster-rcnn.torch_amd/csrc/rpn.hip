@@ -235,15 +235,15 @@ int rpn_loss(const RpnLayers& L, float* const* delta, const int* ex_idx, const d
   return FRCNN_OK;
 }
 
-// acc[0] += sum_e ex_loss[e][0]; acc[1] += sum_e ex_loss[e][1], summed in example order by one
-// lane (E is a few hundred): the fp64 Lua accumulators cls_loss / reg_loss of objective.lua:52.
+// acc[0] += sum_e ex_loss[e][0]; acc[1] += sum_e ex_loss[e][1], summed in a fixed order by one
+// wave (E is a few hundred): the fp64 Lua accumulators cls_loss / reg_loss of objective.lua:52.
 __global__ void loss_accumulate_kernel(const double* __restrict__ ex_loss, int E, double* acc) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double c = 0.0, r = 0.0;
-    for (int e = 0; e < E; ++e) { c += ex_loss[2 * e]; r += ex_loss[2 * e + 1]; }
-    acc[0] += c;
-    acc[1] += r;
-  }
+  // one wave: lane-strided partial sums, then a fixed-order butterfly (deterministic)
+  double c = 0.0, r = 0.0;
+  for (int e = threadIdx.x; e < E; e += 64) { c += ex_loss[2 * e]; r += ex_loss[2 * e + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o, 64); r += __shfl_down(r, o, 64); }
+  if (threadIdx.x == 0) { acc[0] += c; acc[1] += r; }
 }
 int loss_accumulate(const double* ex_loss, int E, double* acc, hipStream_t s) {
   if (E <= 0) return FRCNN_OK;
