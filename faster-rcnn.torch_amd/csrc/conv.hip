@@ -57,6 +57,47 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int C, i
   }
 }
 
+// All packs of a model in ONE launch: blockIdx.y selects the job, blockIdx.x strides over its elements.
+__global__ void pack_weights_multi_kernel(const float* __restrict__ weights, const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const float* __restrict__ w = weights + j.w_off;
+  const int k = j.k;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < j.total; t += (long)gridDim.x * blockDim.x) {
+    int m = (int)(t % j.Mpad);
+    long row = t / j.Mpad;
+    int h = (int)(row & 1);
+    long r2 = row >> 1;
+    int kx = (int)(r2 % k);
+    r2 /= k;
+    int ky = (int)(r2 % k);
+    int kc = (int)(r2 / k) * 2 + h;
+    float v = 0.f;
+    if (j.mode == 0) {
+      if (m < j.O && kc < j.C) v = w[(((long)m * j.C + kc) * k + ky) * k + kx];
+    } else {
+      if (m < j.C && kc < j.O) v = w[(((long)kc * j.C + m) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+    }
+    j.dst[t] = v;
+  }
+}
+
+PackJob conv_pack_job(long w_off, int O, int C, int k, int mode, float* dst) {
+  PackJob j;
+  const int cc = conv_cc(k);
+  const int kchan = mode == 0 ? C : O, M = mode == 0 ? O : C;
+  j.w_off = w_off; j.O = O; j.C = C; j.k = k; j.mode = mode; j.dst = dst;
+  j.Mpad = conv_mpad(M);
+  j.total = (long)cdiv(kchan, cc) * cc * k * k * j.Mpad;
+  return j;
+}
+
+int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int njobs, hipStream_t s) {
+  if (njobs <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_weights_multi_kernel, dim3(96, njobs), dim3(256), 0, weights, jobs_dev);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 int conv_pack_weights(const float* w, int O, int C, int k, float* wf, float* wd, hipStream_t s) {
   int cc = conv_cc(k);
   if (wf) {

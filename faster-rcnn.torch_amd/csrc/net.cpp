@@ -24,15 +24,18 @@ static const int HEAD_OUT = 18;  // 3 * (2 + 4), model_utilities.lua:33
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;
+  void view(void* ptr, size_t n) { p = ptr; bytes = n; owned = false; }  // slice of an arena
   int ensure(size_t need) {
     if (need <= bytes) return FRCNN_OK;
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
+    owned = true;
     p = nullptr; bytes = 0;
     FR_HIP(hipMalloc(&p, need));
     bytes = need;
     return FRCNN_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
   float* f() const { return (float*)p; }
 };
 
@@ -85,6 +88,10 @@ struct frcnn_model {
   int H = 0, W = 0;            // current image size
   int training = 0;
   DevBuf delta_last;           // delta_outputs[nheads+1]
+  DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
+  size_t delta_bytes = 0, gpool_bytes = 0;
+  DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
+  int n_pack_fwd = 0, n_pack_all = 0;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -202,7 +209,6 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     blk.Hp = pool_out(h); blk.Wp = pool_out(w);
     int C = m->d.filters[b];
     FR_TRY(blk.pooled.ensure((size_t)C * blk.Hp * blk.Wp * 4));
-    FR_TRY(blk.gpooled.ensure((size_t)C * blk.Hp * blk.Wp * 4));
     FR_TRY(blk.pidx.ensure((size_t)C * blk.Hp * blk.Wp));
     if (blk.has_drop) FR_TRY(blk.scale.ensure((size_t)C * 4));
     h = blk.Hp; w = blk.Wp;
@@ -211,10 +217,25 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     const Block& in = m->blocks[hd.input];
     FR_TRY(ensure_conv(hd.c3, in.Hp, in.Wp, true));
     FR_TRY(ensure_conv(hd.c1, hd.c3.Ho, hd.c3.Wo, true));
-    FR_TRY(hd.delta.ensure((size_t)HEAD_OUT * hd.c1.Ho * hd.c1.Wo * 4));
   }
   const Block& last = m->blocks.back();
-  FR_TRY(m->delta_last.ensure((size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4));
+  {  // one arena: [deltas of the heads | delta of the last map | gpooled of every block]
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t db = 0, gb = 0;
+    for (auto& hd : m->heads) db += al((size_t)HEAD_OUT * hd.c1.Ho * hd.c1.Wo * 4);
+    db += al((size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4);
+    for (size_t b = 0; b < m->blocks.size(); ++b) gb += al((size_t)m->d.filters[b] * m->blocks[b].Hp * m->blocks[b].Wp * 4);
+    m->zero_arena.release();
+    FR_TRY(m->zero_arena.ensure(db + gb));
+    char* q = (char*)m->zero_arena.p;
+    for (auto& hd : m->heads) { size_t n = (size_t)HEAD_OUT * hd.c1.Ho * hd.c1.Wo * 4; hd.delta.view(q, n); q += al(n); }
+    { size_t n = (size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4; m->delta_last.view(q, n); q += al(n); }
+    for (size_t b = 0; b < m->blocks.size(); ++b) {
+      size_t n = (size_t)m->d.filters[b] * m->blocks[b].Hp * m->blocks[b].Wp * 4;
+      m->blocks[b].gpooled.view(q, n); q += al(n);
+    }
+    m->delta_bytes = db; m->gpool_bytes = gb;
+  }
   size_t wsb = 0;
   for (auto& c : m->convs) wsb = std::max(wsb, conv_wgrad_workspace_bytes(c.Cin, c.H, c.W, c.Cout, c.k, c.pad));
   for (auto& hd : m->heads) {
@@ -222,6 +243,24 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     wsb = std::max(wsb, conv_wgrad_workspace_bytes(hd.c1.Cin, hd.c1.H, hd.c1.W, hd.c1.Cout, 1, 0));
   }
   FR_TRY(m->wg_ws.ensure(wsb));
+  {  // pack-job table (buffers may have been re-allocated above)
+    std::vector<PackJob> jobs;
+    for (auto& c : m->convs) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wf.f()));
+    for (auto& hd : m->heads) {
+      jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 0, hd.c3.wf.f()));
+      jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 0, hd.c1.wf.f()));
+    }
+    m->n_pack_fwd = (int)jobs.size();
+    for (auto& c : m->convs)
+      if (!(c.block == 0 && c.step == 0)) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
+    for (auto& hd : m->heads) {
+      jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 1, hd.c3.wd.f()));
+      jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 1, hd.c1.wd.f()));
+    }
+    m->n_pack_all = (int)jobs.size();
+    FR_TRY(m->pack_jobs.ensure(jobs.size() * sizeof(PackJob)));
+    FR_HIP(hipMemcpy(m->pack_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  }
   m->H = H; m->W = W;
   return FRCNN_OK;
 }
@@ -260,7 +299,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
-  m->img.release(); m->wg_ws.release();
+  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->zero_arena.release();
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
   delete m;
@@ -321,14 +360,8 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
       FR_TRY(dropout_channel_mask(blk.scale.f(), C, blk.p_drop, seed * 131 + b, s));
     }
   }
-  // weights change every optimiser step: refresh the packed copies
-  for (auto& c : m->convs)
-    FR_TRY(conv_pack_weights(w + c.w_off, c.Cout, c.Cin, c.k, c.wf.f(),
-                             (training && !(c.block == 0 && c.step == 0)) ? c.wd.f() : nullptr, s));
-  for (auto& h : m->heads) {
-    FR_TRY(conv_pack_weights(w + h.c3.w_off, h.c3.Cout, h.c3.Cin, h.c3.k, h.c3.wf.f(), training ? h.c3.wd.f() : nullptr, s));
-    FR_TRY(conv_pack_weights(w + h.c1.w_off, h.c1.Cout, h.c1.Cin, h.c1.k, h.c1.wf.f(), training ? h.c1.wd.f() : nullptr, s));
-  }
+  // weights change every optimiser step: refresh the packed copies (one table-driven launch)
+  FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, training ? m->n_pack_all : m->n_pack_fwd, s));
   FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
   FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
   const float* cur = m->img.f();
@@ -383,9 +416,7 @@ int frcnn_pnet_delta(frcnn_model* m, int i, float** ptr) {
 
 int frcnn_pnet_zero_deltas(frcnn_model* m, void* stream) {
   FR_CHECK(m->H > 0, "pnet_zero_deltas: call frcnn_pnet_forward first");
-  for (auto& h : m->heads) FR_TRY(fill_zero(h.delta.p, (size_t)HEAD_OUT * h.c1.Ho * h.c1.Wo * 4, S(stream)));
-  const Block& last = m->blocks.back();
-  FR_TRY(fill_zero(m->delta_last.p, (size_t)m->d.filters[m->d.nblocks - 1] * last.Hp * last.Wp * 4, S(stream)));
+  FR_TRY(fill_zero(m->zero_arena.p, m->delta_bytes, S(stream)));
   return FRCNN_OK;
 }
 
@@ -394,10 +425,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
                                     "(nn.SpatialDropout: backprop only defined while training)");
   const int nb = (int)m->blocks.size();
-  for (int b = 0; b < nb; ++b) {
-    Block& blk = m->blocks[b];
-    FR_TRY(fill_zero(blk.gpooled.p, (size_t)m->d.filters[b] * blk.Hp * blk.Wp * 4, s));
-  }
+  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
   {  // output nheads+1 is the last pooled map itself (model_utilities.lua:55)
     Block& last = m->blocks.back();
     FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
