@@ -179,6 +179,17 @@ class ClassificationNet(object):
         self.train = True
         self.drop_masks = None
         self.output = None
+        self._bufs = {}
+
+    def _buf(self, name, shape):
+        """Module-owned output / gradInput buffers, reused by the next call like nn.Module's (hipMalloc /
+        hipFree inside a step would synchronise the device)."""
+        need = int(np.prod(shape)) * 4
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < need:
+            b = DeviceTensor.empty((max(need, 256),), np.uint8)
+            self._bufs[name] = b
+        return DeviceTensor(b.ptr, shape, np.float32, owner=b)
 
     def cuda(self):
         return self
@@ -194,7 +205,7 @@ class ClassificationNet(object):
         cinput = to_device(cinput)
         R, D = cinput.shape
         nc = nat.desc.class_count + 1
-        bbox = DeviceTensor.empty((R, 4)); cls = DeviceTensor.empty((R, nc))
+        bbox = self._buf("bbox", (R, 4)); cls = self._buf("cls", (R, nc))
         arr, keep = _mask_ptrs(self.drop_masks, nat.desc.ncls)
         nat.seed += 1
         self._input = cinput
@@ -207,7 +218,7 @@ class ClassificationNet(object):
     def backward(self, cinput, grad_outputs):
         nat = self.native
         R, D = self._input.shape
-        gx = DeviceTensor.empty((R, D))
+        gx = self._buf("gx", (R, D))
         _lib.call("frcnn_cnet_backward", nat.h, ptr(nat.weights), ptr(grad_outputs[0]), ptr(grad_outputs[1]), ptr(gx),
                   ptr(nat.gradient), stream_ptr())
         return gx
