@@ -319,11 +319,37 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
           float* dst = p.out + (size_t)m * HoWo + pofs;
           if (p.out_mode == 0) *dst = v;
           else if (p.out_mode == 1) *dst += v;
-          else unsafeAtomicAdd(dst, v);
+          else if (p.out_mode == 2) unsafeAtomicAdd(dst, v);
+          else dst[(size_t)split * p.M * HoWo] = v;   // split-K slab [split][M][Ho*Wo]
         }
       }
     }
   }
+}
+
+// out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw, const float* __restrict__ bias,
+                                     float* __restrict__ out, int accumulate) {
+  const long total = (long)M * hw;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    float v = bias ? bias[t / hw] : 0.f;
+    for (int s = 0; s < nSplit; ++s) v += slab[(size_t)s * total + t];
+    if (accumulate) out[t] += v; else out[t] = v;
+  }
+}
+
+// library-owned split-K workspace (grown outside the steady state)
+static void* g_ig_ws = nullptr;
+static size_t g_ig_ws_bytes = 0;
+static int ig_workspace(size_t need, float** out) {
+  if (need > g_ig_ws_bytes) {
+    if (g_ig_ws) FR_HIP(hipFree(g_ig_ws));
+    g_ig_ws = nullptr; g_ig_ws_bytes = 0;
+    FR_HIP(hipMalloc(&g_ig_ws, need));
+    g_ig_ws_bytes = need;
+  }
+  *out = (float*)g_ig_ws;
+  return FRCNN_OK;
 }
 
 __global__ void bias_fill_kernel(float* out, const float* bias, int M, long hw) {
@@ -398,7 +424,14 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
   a.dbg = 0;
-  if (a.splitK > 1) {
+  bool slab = false;
+  if (a.splitK > 2 && !(k == 3 && Cin <= 4)) {
+    // >= 3 splits: partial tiles go to slabs with plain stores and one reduce pass adds the bias
+    // (fp32 atomics from 5-8 splits cost 50-70 us per launch in the memory-side atomic units)
+    float* ws = nullptr;
+    FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws));
+    a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
+  } else if (a.splitK > 1) {
     if (out_mode == OUT_STORE) {  // initialise with the bias, then accumulate atomically
       long total = (long)M * a.Ho * a.Wo;
       int grid = (int)std::min<long>(cdivl(total, 256), 2048);
@@ -410,19 +443,33 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_IGEMM_K3 : KC_CONV_IGEMM_OTHER;
+  int rc;
   if (k == 3 && Cin <= 4) {  // first layer: a 4-channel chunk (the packed rows are ordered by channel pair)
-    a.nChunks = 1; a.chunksPerSplit = 1; a.splitK = 1; a.out_mode = out_mode; a.bias = bias;
-    return BM == 64 ? launch_igemm<3, 4, 64, false>(a, klass, algo_flops, s)
-                    : launch_igemm<3, 4, 128, false>(a, klass, algo_flops, s);
-  }
-  if (k == 3) return BM == 64 ? launch_igemm<3, 8, 64, false>(a, klass, algo_flops, s)
-                              : launch_igemm<3, 8, 128, false>(a, klass, algo_flops, s);
-  if (k == 1) return BM == 64 ? launch_igemm<1, 32, 64, true>(a, klass, algo_flops, s)
-                              : launch_igemm<1, 32, 128, true>(a, klass, algo_flops, s);
-  if (k == 5) return BM == 64 ? launch_igemm<5, 2, 64, false>(a, klass, algo_flops, s)
-                              : launch_igemm<5, 2, 128, false>(a, klass, algo_flops, s);
-  return BM == 64 ? launch_igemm<7, 2, 64, false>(a, klass, algo_flops, s)
+    a.nChunks = 1; a.chunksPerSplit = 1; a.splitK = 1; a.out_mode = out_mode; a.bias = bias; a.out = out;
+    rc = BM == 64 ? launch_igemm<3, 4, 64, false>(a, klass, algo_flops, s)
+                  : launch_igemm<3, 4, 128, false>(a, klass, algo_flops, s);
+  } else if (k == 3) {
+    rc = BM == 64 ? launch_igemm<3, 8, 64, false>(a, klass, algo_flops, s)
+                  : launch_igemm<3, 8, 128, false>(a, klass, algo_flops, s);
+  } else if (k == 1) {
+    rc = BM == 64 ? launch_igemm<1, 32, 64, true>(a, klass, algo_flops, s)
+                  : launch_igemm<1, 32, 128, true>(a, klass, algo_flops, s);
+  } else if (k == 5) {
+    rc = BM == 64 ? launch_igemm<5, 2, 64, false>(a, klass, algo_flops, s)
+                  : launch_igemm<5, 2, 128, false>(a, klass, algo_flops, s);
+  } else {
+    rc = BM == 64 ? launch_igemm<7, 2, 64, false>(a, klass, algo_flops, s)
                   : launch_igemm<7, 2, 128, false>(a, klass, algo_flops, s);
+  }
+  FR_TRY(rc);
+  if (slab) {
+    long total = (long)M * a.Ho * a.Wo;
+    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, splitk_reduce_kernel, dim3(grid), dim3(256), 0,
+              (const float*)a.out, a.splitK, M, (long)a.Ho * a.Wo, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    FR_LAUNCH_CHECK();
+  }
+  return FRCNN_OK;
 }
 
 // ------------------------------------------------------------------------------------------
