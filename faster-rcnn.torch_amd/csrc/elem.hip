@@ -261,6 +261,73 @@ int channel_sum_cols(const float* g, int R, int O, float* gb, hipStream_t s) {
   return FRCNN_OK;
 }
 
+// ---------------------------------------------------------------- sparse anchor-head backward helpers
+// delta_outputs[1..4] are non-zero only at the sampled anchors (objective.lua:91-134), so the
+// backward of an anchor head can run on P gathered positions instead of the whole map.
+// dst[c][p] = src[c][pos[p]]  (and dst_act = prelu(dst) when slope != null)
+__global__ void gather_positions_kernel(const float* __restrict__ src, int C, long hw, const int* __restrict__ pos, int P,
+                                        float* __restrict__ dst, const float* slope, float* __restrict__ dst_act) {
+  const long total = (long)C * P;
+  const float a = slope ? *slope : 1.f;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t / P), pi = (int)(t - (long)c * P);
+    const float v = src[(size_t)c * hw + pos[pi]];
+    dst[t] = v;
+    if (dst_act) dst_act[t] = v > 0.f ? v : a * v;
+  }
+}
+int gather_positions(const float* src, int C, long hw, const int* pos, int P, float* dst, const float* slope,
+                     float* dst_act, hipStream_t s) {
+  long total = (long)C * P;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, gather_positions_kernel, dim3(grid), dim3(256), 0, src, C, hw, pos, P, dst,
+            slope, dst_act);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// col[p][(c,ky,kx)] = X[c][y_p + ky][x_p + kx]   (valid convolution: always in bounds); pos = y*Wo + x
+__global__ void im2col_positions_kernel(const float* __restrict__ X, int C, int H, int W, int k, int Wo,
+                                        const int* __restrict__ pos, int P, float* __restrict__ col) {
+  const int ckk = C * k * k;
+  const long total = (long)P * ckk;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int pi = (int)(t / ckk), q = (int)(t - (long)pi * ckk);
+    const int kx = q % k, ky = (q / k) % k, c = q / (k * k);
+    const int y = pos[pi] / Wo, x = pos[pi] - y * Wo;
+    col[t] = X[((size_t)c * H + y + ky) * W + x + kx];
+  }
+}
+int im2col_positions(const float* X, int C, int H, int W, int k, int Wo, const int* pos, int P, float* col, hipStream_t s) {
+  long total = (long)P * C * k * k;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 4096);
+  FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, im2col_positions_kernel, dim3(grid), dim3(256), 0, X, C, H, W, k, Wo, pos, P, col);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// gX[c][y_p + ky][x_p + kx] += col[p][(c,ky,kx)]  (neighbourhoods of different anchors overlap: atomics)
+__global__ void col2im_positions_add_kernel(const float* __restrict__ col, int C, int H, int W, int k, int Wo,
+                                            const int* __restrict__ pos, int P, float* __restrict__ gX) {
+  const int ckk = C * k * k;
+  const long total = (long)P * ckk;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int pi = (int)(t / ckk), q = (int)(t - (long)pi * ckk);
+    const int kx = q % k, ky = (q / k) % k, c = q / (k * k);
+    const int y = pos[pi] / Wo, x = pos[pi] - y * Wo;
+    unsafeAtomicAdd(gX + ((size_t)c * H + y + ky) * W + x + kx, col[t]);
+  }
+}
+int col2im_positions_add(const float* col, int C, int H, int W, int k, int Wo, const int* pos, int P, float* gX,
+                         hipStream_t s) {
+  long total = (long)P * C * k * k;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 4096);
+  FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, col2im_positions_add_kernel, dim3(grid), dim3(256), 0, col, C, H, W, k, Wo, pos,
+            P, gX);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 // ---------------------------------------------------------------- RNG (throughput runs)
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;

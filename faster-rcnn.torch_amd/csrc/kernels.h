@@ -55,6 +55,12 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
 int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s);
 // gb[o] += sum_r g[r][o] for a row-major R x O matrix
 int channel_sum_cols(const float* g, int R, int O, float* gb, hipStream_t s);
+// sparse anchor-head backward helpers (positions = flat y*Wo+x indices into the head's output map)
+int gather_positions(const float* src, int C, long hw, const int* pos, int P, float* dst, const float* slope,
+                     float* dst_act, hipStream_t s);
+int im2col_positions(const float* X, int C, int H, int W, int k, int Wo, const int* pos, int P, float* col, hipStream_t s);
+int col2im_positions_add(const float* col, int C, int H, int W, int k, int Wo, const int* pos, int P, float* gX,
+                         hipStream_t s);
 // per-channel Bernoulli keep mask (nn.SpatialDropout, model_utilities.lua:10-12): scale[c] in {0,1}
 int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, hipStream_t s);
 int fill_value(float* x, long n, float v, hipStream_t s);

@@ -20,6 +20,7 @@
 namespace frcnn {
 
 static const int HEAD_OUT = 18;  // 3 * (2 + 4), model_utilities.lua:33
+static const int SPARSE_MAX_POS = 512;  // above this the dense head backward is used
 
 struct DevBuf {
   void* p = nullptr;
@@ -63,6 +64,8 @@ struct Head {
   Conv c1;                    // 1 x 1 conv -> 18 planes
   int input;                  // 0-based block index
   DevBuf delta;               // delta_outputs[h]
+  const int* sp_pos = nullptr; // optional one-shot hint: delta is zero outside these positions
+  int sp_count = -1;
 };
 
 struct ClsLayer {
@@ -88,6 +91,7 @@ struct frcnn_model {
   int H = 0, W = 0;            // current image size
   int training = 0;
   DevBuf delta_last;           // delta_outputs[nheads+1]
+  DevBuf spD, spHX, spHY, spGH, spCol, spDX;  // sparse head backward scratch
   DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
@@ -299,6 +303,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
+  m->spD.release(); m->spHX.release(); m->spHY.release(); m->spGH.release(); m->spCol.release(); m->spDX.release();
   m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->zero_arena.release();
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
@@ -414,6 +419,13 @@ int frcnn_pnet_delta(frcnn_model* m, int i, float** ptr) {
   return FRCNN_OK;
 }
 
+int frcnn_pnet_set_sparse_deltas(frcnn_model* m, int head, const int* positions, int count) {
+  FR_CHECK(head >= 1 && head <= (int)m->heads.size(), "pnet_set_sparse_deltas: head %d out of range", head);
+  m->heads[head - 1].sp_pos = positions;
+  m->heads[head - 1].sp_count = count;
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_zero_deltas(frcnn_model* m, void* stream) {
   FR_CHECK(m->H > 0, "pnet_zero_deltas: call frcnn_pnet_forward first");
   FR_TRY(fill_zero(m->zero_arena.p, m->delta_bytes, S(stream)));
@@ -434,6 +446,37 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     Block& in = m->blocks[h.input];
     Conv &a = h.c3, &c = h.c1;
     const long hw1 = (long)c.Ho * c.Wo;
+    if (h.sp_count >= 0 && h.sp_count <= SPARSE_MAX_POS) {
+      // ---- sparse path: the same arithmetic restricted to the P positions where delta is non-zero
+      const int P = h.sp_count;
+      const int* pos = h.sp_pos;
+      h.sp_count = -1; h.sp_pos = nullptr;   // one-shot hint
+      if (P == 0) continue;                  // no example on this head: every gradient term is zero
+      const int n = a.Cout, ckk = a.Cin * a.k * a.k;
+      FR_TRY(m->spD.ensure((size_t)HEAD_OUT * SPARSE_MAX_POS * 4));
+      FR_TRY(m->spHX.ensure((size_t)n * SPARSE_MAX_POS * 4));
+      FR_TRY(m->spHY.ensure((size_t)n * SPARSE_MAX_POS * 4));
+      FR_TRY(m->spGH.ensure((size_t)n * SPARSE_MAX_POS * 4));
+      FR_TRY(m->spCol.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
+      FR_TRY(m->spDX.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
+      float *D = m->spD.f(), *HX = m->spHX.f(), *HY = m->spHY.f(), *GH = m->spGH.f(), *COL = m->spCol.f(), *DX = m->spDX.f();
+      FR_TRY(gather_positions(h.delta.f(), HEAD_OUT, hw1, pos, P, D, nullptr, nullptr, s));
+      FR_TRY(gather_positions(a.x.f(), n, hw1, pos, P, HX, w + a.a_off, HY, s));
+      // 1x1 conv: gW1[18][n] += D[18][P] * HY[n][P]^T ; gb1 += rowsum(D)
+      FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s));
+      FR_TRY(channel_sum(D, HEAD_OUT, P, grad + c.b_off, s));
+      // GH[n][P] = W1^T[n][18] * D[18][P], then PReLU backward (+ bias / slope gradients of the k x k conv)
+      FR_TRY(gemm_f32(w + c.w_off, 1, n, D, P, 1, GH, P, n, P, HEAD_OUT, OUT_STORE, nullptr, s));
+      FR_TRY(act_backward(GH, HX, n, P, w + a.a_off, nullptr, GH, grad + a.b_off, grad + a.a_off, s));
+      // k x k conv: gW[n][ckk] += GH[n][P] * COL[P][ckk]
+      FR_TRY(im2col_positions(in.pooled.f(), a.Cin, a.H, a.W, a.k, a.Wo, pos, P, COL, s));
+      FR_TRY(gemm_f32(GH, P, 1, COL, ckk, 1, grad + a.w_off, ckk, n, ckk, P, OUT_ADD, nullptr, s));
+      // DX[P][ckk] = GH^T[P][n] * W[n][ckk], scattered back into the pooled-map gradient
+      FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s));
+      FR_TRY(col2im_positions_add(DX, a.Cin, a.H, a.W, a.k, a.Wo, pos, P, in.gpooled.f(), s));
+      continue;
+    }
+    h.sp_count = -1; h.sp_pos = nullptr;
     // 1x1 conv: accGradParameters + updateGradInput
     FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
     FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));

@@ -141,9 +141,15 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     ex_class[:npos] = [e[1].class_index for e in p]
                 # positives pool the GT rect (:117), negatives pool the anchor rect itself (:137)
                 wins = roi_windows(np.concatenate([ex_roi[:npos], ex_anchor[npos:]], 0), localizer, fmH, fmW)
+                # positions where delta_outputs[l] will be non-zero (hint for the sparse head backward)
+                sp = []
+                for l in range(4):
+                    sel = ex_idx[ex_idx[:, 0] == l + 1]
+                    sp.append(np.unique((sel[:, 2] - 1) * outputs[l].shape[2] + (sel[:, 3] - 1)).astype(np.int32))
+                sp_all = np.concatenate(sp) if E else np.zeros(0, np.int32)
                 blob = np.concatenate([ex_anchor.view(np.uint8).ravel(), ex_roi.view(np.uint8).ravel(),
                                        ex_idx.view(np.uint8).ravel(), ex_class.view(np.uint8).ravel(),
-                                       wins.view(np.uint8).ravel()])
+                                       wins.view(np.uint8).ravel(), sp_all.view(np.uint8).ravel()])
                 dblob = scratch.get("blob", (blob.size,), np.uint8)
                 scratch.keep = blob  # the host array must outlive the (possibly still queued) copy
                 _lib.call("frcnn_memcpy_h2d", ptr(dblob), blob.ctypes.data_as(C.c_void_p), blob.nbytes, s)
@@ -152,7 +158,10 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 d_roi = dblob.ptr + o; o += ex_roi.nbytes
                 d_idx = dblob.ptr + o; o += ex_idx.nbytes
                 d_class = dblob.ptr + o; o += ex_class.nbytes
-                d_wins = dblob.ptr + o
+                d_wins = dblob.ptr + o; o += wins.nbytes
+                for l in range(4):
+                    _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, C.c_void_p(dblob.ptr + o), len(sp[l]))
+                    o += sp[l].nbytes
                 # ---- RPN loss on the sampled anchors (objective.lua:91-140) ------------------
                 maps = (C.c_void_p * 4)(*[outputs[i].ptr for i in range(4)])
                 deltas = (C.c_void_p * 4)(*[delta_outputs[i].ptr for i in range(4)])
@@ -180,6 +189,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 post_roi_delta = cnet.backward(cinput, [crdelta, ccdelta])  # :179
                 _lib.call("frcnn_roi_pool_backward", ptr(delta_outputs[4]), fmC, fmH, fmW, ptr(post_roi_delta),
                           ptr(pidx), E, kh, kw, s)  # :182-185
+            if E == 0:
+                for l in range(4):
+                    _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, None, 0)
             pnet.backward(img, delta_outputs)  # :189
             reg_count += npos  # :194-198
             cls_count += npos + nneg

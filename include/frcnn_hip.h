@@ -212,6 +212,11 @@ int frcnn_pnet_output(frcnn_model *, int i, float **ptr_host, int *C_host, int *
 /* delta_outputs[i] (objective.lua:78-84): gradient buffers with the shapes of the outputs. */
 int frcnn_pnet_delta(frcnn_model *, int i, float **ptr_host);
 int frcnn_pnet_zero_deltas(frcnn_model *, void *stream);
+/* Optional one-shot hint for the next frcnn_pnet_backward: delta_outputs[head] (head = 1..nheads) is
+ * zero outside `count` positions (device int array of unique flat indices y*W_head + x, 0-based), which is
+ * how objective.lua:91-134 fills it (only the sampled anchors).  The head's backward then runs on those
+ * positions only; the result is identical.  count < 0 (default) or > 512: dense backward. */
+int frcnn_pnet_set_sparse_deltas(frcnn_model *, int head, const int *positions, int count);
 /* pnet:backward(img, delta_outputs) (objective.lua:189): accumulates into the flat gradient.
  * The (unused) input gradient of the first convolution is not computed. */
 int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *stream);

@@ -239,3 +239,43 @@ def test_detect(F, O, setup):
             assert got == want
     finally:
         s["weights"].copy_(torch.from_numpy(s["w"]))
+
+
+def test_sparse_head_backward_equals_dense(F, setup):
+    """frcnn_pnet_set_sparse_deltas: the anchor-head backward restricted to the non-zero delta positions must
+    give the gradient of the dense backward (same arithmetic on fewer pixels; fp32 summation order differs)."""
+    import ctypes as C
+    s = setup
+    rng = np.random.RandomState(5)
+    model, nat = s["model"], s["model"]["native"]
+    pnet = model["pnet"]
+    pnet.training()
+    pnet.drop_masks = _masks(rng, model)
+    img = F.synthetic_image(H, W, 2)
+    outs = pnet.forward(img)
+    deltas_h, pos = [], []
+    for l in range(4):
+        c, h, w = outs[l].shape
+        d = np.zeros((c, h * w), np.float32)
+        n = [23, 5, 0, 1][l]                         # incl. a head without any example and a single position
+        p = np.sort(rng.choice(h * w, n, replace=False)).astype(np.int32)
+        d[:, p] = rng.randn(c, n).astype(np.float32)
+        deltas_h.append(d.reshape(c, h, w)); pos.append(p)
+    deltas_h.append((rng.randn(*outs[4].shape) * 0.01).astype(np.float32))
+
+    def run(sparse):
+        s["gradient"].zero_()
+        dd = pnet.delta_outputs(zero=True)
+        for d, hst in zip(dd, deltas_h):
+            d.copy_from_numpy(hst)
+        keep = []
+        if sparse:
+            for l in range(4):
+                dp = F.DeviceTensor.from_numpy(pos[l]) if len(pos[l]) else None
+                keep.append(dp)
+                F._lib.call("frcnn_pnet_set_sparse_deltas", nat.h, l + 1, F.ptr(dp), len(pos[l]))
+        pnet.backward(img, dd)
+        return s["gradient"].cpu().numpy().copy()
+    g_dense, g_sparse = run(False), run(True)
+    pnet.drop_masks = None
+    _compare_gradient(nat, g_sparse, g_dense, 0, nat.pnet_params, tol_l2=1e-5, elementwise=False)
