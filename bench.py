@@ -178,7 +178,8 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload="vgg_small %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
                                  "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/duplo.lua values" % (W, H),
-                        images_per_gpu_per_step=1, global_batch=world, parallelism="dp%d" % world,
+                        images_per_gpu_per_step=1,
+                        examples_per_image=[len(b["positive"]) + len(b["negative"]) for b in it.pool], global_batch=world, parallelism="dp%d" % world,
                         conv_gflop_per_image=round(train_flops / 1e9, 2),
                         whole_step_conv_tflops=round(train_flops / 1e12 / (dt / args.steps), 2),
                         conv_kernel_ms_per_step=round(conv_ms, 3), kernel_classes=classes,

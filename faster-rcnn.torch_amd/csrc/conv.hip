@@ -633,20 +633,124 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
-// gw[o][c][tap] += sum_s slab[s][tap][o][c]
+// gw[o][c][tap] += sum_s slab[s][tap][o][c].  Block = 64 elements x 4 split groups (the slabs are the
+// long dimension when the result is small), 4 loads in flight per thread.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nSplit, int taps, int OC, float* __restrict__ gw) {
+  __shared__ float sh[4][64];
   const long total = (long)taps * OC;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int tap = (int)(t / OC);
-    const int oc = (int)(t - (long)tap * OC);
-    float s0 = 0.f, s1 = 0.f;
-    int s = 0;
-    for (; s + 1 < nSplit; s += 2) {
-      s0 += slab[(size_t)s * total + t];
-      s1 += slab[(size_t)(s + 1) * total + t];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (long t0 = (long)blockIdx.x * 64; t0 < total; t0 += (long)gridDim.x * 64) {
+    const long t = t0 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (t < total) {
+      int s = g;
+      for (; s + 12 < nSplit; s += 16) {
+        a0 += slab[(size_t)s * total + t];
+        a1 += slab[(size_t)(s + 4) * total + t];
+        a2 += slab[(size_t)(s + 8) * total + t];
+        a3 += slab[(size_t)(s + 12) * total + t];
+      }
+      for (; s < nSplit; s += 4) a0 += slab[(size_t)s * total + t];
     }
-    if (s < nSplit) s0 += slab[(size_t)s * total + t];
-    gw[(size_t)oc * taps + tap] += s0 + s1;
+    sh[g][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && t < total) {
+      const int tap = (int)(t / OC);
+      const int oc = (int)(t - (long)tap * OC);
+      gw[(size_t)oc * taps + tap] += (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of the FIRST layer (Cin*k*k <= 32, O <= 64: 3 -> 64 @ 450x800).  With three input
+// channels the (o, c) tiling above would leave 29 of 32 MFMA columns empty, so here the GEMM is
+// M = o (two 32-row tiles), N = (c, ky, kx) = 27 columns of ONE 32x32 tile, K = pixels.  Every wave
+// owns one row of a 4 x 64 pixel tile; the kernel is bound by streaming the gradient map once.
+// ------------------------------------------------------------------------------------------
+#define W1_TH 4
+#define W1_TW 64
+#define W1_GP 257   // odd pitch of gs[o][256]
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_first_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PW = W1_TW + KS - 1, PH = W1_TH + KS - 1, PLANE = PH * PW;
+  float* gs = smem;                   // [64][W1_GP]
+  float* ps = smem + 64 * W1_GP;      // [Cin][PH][PW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int ntap = p.Cin * KS * KS;
+  // lane li is output column j = (c, ky, kx)
+  const int jj = li < ntap ? li : 0;
+  const int jc = jj / (KS * KS), jt = jj % (KS * KS);
+  const int tapoff = jc * PLANE + (jt / KS) * PW + (jt % KS);
+  const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int nPix = p.tilesX * p.tilesY;
+  for (int t = blockIdx.x; t < nPix; t += gridDim.x) {
+    const int oy0 = (t / p.tilesX) * W1_TH, ox0 = (t % p.tilesX) * W1_TW;
+    // ---- gradient tile: 64 rows (o) x 256 pixels; thread -> pixel tid, loop over o (coalesced along x)
+    {
+      const int ty = tid / W1_TW, tx = tid % W1_TW;
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const bool ok = oy < p.Ho && ox < p.Wo;
+      const int ofs = ok ? oy * p.Wo + ox : 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int o = b * 16 + j; v[j] = p.g[(size_t)(o < p.O ? o : 0) * HoWo + ofs]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int o = b * 16 + j; gs[o * W1_GP + tid] = (ok && o < p.O) ? v[j] : 0.f; }
+      }
+    }
+    // ---- input patch with halo
+    for (int e = tid; e < p.Cin * PLANE; e += 256) {
+      const int c = e / PLANE, r2 = e - c * PLANE;
+      const int r = r2 / PW, col = r2 - r * PW;
+      const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + col;
+      float v = 0.f;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = p.in[(size_t)c * HW + iy * p.W + ix];
+      ps[e] = v;
+    }
+    __syncthreads();
+    {
+      const float* ga = gs + li * W1_GP + wave * W1_TW + h;          // pixel pair (x, x+1): h selects
+      const float* pb = ps + tapoff + wave * PW + h;
+#pragma unroll 4
+      for (int x = 0; x < W1_TW; x += 2) {
+        const float b = pb[x];
+        const float a0 = ga[x], a1 = ga[32 * W1_GP + x];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the four waves meet in LDS, then one slab slice [tap][o][c] per block
+  float* red = smem;  // [4][64][32]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(wave * 64 + o) * 32 + li] = acc[t][r];
+    }
+  __syncthreads();
+  const int OC = p.O * p.Cin;
+  float* sl = p.slab + (size_t)blockIdx.x * KS * KS * OC;
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int o = e >> 5, j = e & 31;
+    if (o < p.O && j < ntap) {
+      const float v = red[e] + red[64 * 32 + e] + red[2 * 64 * 32 + e] + red[3 * 64 * 32 + e];
+      sl[(size_t)(j % (KS * KS)) * OC + o * p.Cin + j / (KS * KS)] = v;
+    }
   }
 }
 
@@ -667,7 +771,18 @@ static void choose_wgrad_tile(int Ho, int Wo, int k, int tys, int* TH, int* TW) 
   *TH = bth; *TW = btw;
 }
 
+static bool g_wgrad_first_ok = true;  // cleared by conv_wgrad when the input carries a fused activation
+static bool wgrad_is_first(int Cin, int O, int k) { return g_wgrad_first_ok && k == 3 && Cin * 9 <= 32 && O <= 64; }
+
 static void wgrad_plan(WgradArgs& a, int k) {
+  if (wgrad_is_first(a.Cin, a.O, k)) {
+    a.TH = W1_TH; a.TW = W1_TW;
+    a.tilesX = cdiv(a.Wo, W1_TW); a.tilesY = cdiv(a.Ho, W1_TH);
+    a.oTiles = a.cTiles = a.kyGroups = 1;
+    a.nSplit = std::min(512, a.tilesX * a.tilesY);   // one slab slice per block
+    a.dbg = 0;
+    return;
+  }
   const int tys = k == 3 ? 3 : 1;
   choose_wgrad_tile(a.Ho, a.Wo, k, tys, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
@@ -707,7 +822,7 @@ static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStr
   hipLaunchKernelGGL((conv_wgrad_kernel<KS, TYS>), dim3(grid), dim3(256), lds, s, a);
   const int OC = a.O * a.Cin;
   long total = (long)KS * KS * OC;
-  int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
+  int rgrid = (int)std::min<long>(cdivl(total, 64), 4096);
   if (!(a.dbg & 1))
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)a.slab, a.nSplit, KS * KS, OC, gw);
   if (frcnn::prof_enabled(klass)) frcnn::prof_after(klass, flops, bytes, s);
@@ -723,12 +838,30 @@ int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
   FR_CHECK((long)Cin * H * W < (1L << 31) && (long)O * a.Ho * a.Wo < (1L << 31), "conv_wgrad: tensor too large for 32-bit offsets");
+  g_wgrad_first_ok = (in_slope == nullptr && in_scale == nullptr);
   wgrad_plan(a, k);
   size_t need = (size_t)a.nSplit * k * k * O * Cin * 4 + 256;
   FR_CHECK(ws && ws_bytes >= need, "conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
   a.slab = (float*)(((uintptr_t)ws + 255) / 256 * 256);
   double flops = 2.0 * O * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_WGRAD_K3 : KC_CONV_WGRAD_OTHER;
+  if (wgrad_is_first(Cin, O, k)) {
+    size_t lds = ((size_t)64 * W1_GP + (size_t)Cin * (W1_TH + 2) * (W1_TW + 2)) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    if (frcnn::prof_enabled(klass)) frcnn::prof_before(klass, s);
+    hipLaunchKernelGGL((conv_wgrad_first_kernel<3>), dim3(a.nSplit), dim3(256), lds, s, a);
+    const int OC = O * Cin;
+    int rgrid = (int)std::min<long>(cdivl(9L * OC, 64), 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)a.slab, a.nSplit, 9, OC, gw);
+    if (frcnn::prof_enabled(klass)) frcnn::prof_after(klass, flops, 4.0 * ((double)Cin * H * W + (double)O * a.Ho * a.Wo), s);
+    FR_LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   if (k == 3) return launch_wgrad<3, 3>(a, klass, flops, gw, s);
   if (k == 1) return launch_wgrad<1, 1>(a, klass, flops, gw, s);
   if (k == 5) return launch_wgrad<5, 1>(a, klass, flops, gw, s);

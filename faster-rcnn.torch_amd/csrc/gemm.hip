@@ -14,7 +14,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GB 64
 #define GBK 32
-#define GP 65  // LDS pitch (odd)
 
 struct GemmArgs {
   const float* A; long sAm, sAk;
@@ -24,31 +23,40 @@ struct GemmArgs {
   int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 2 atomic
 };
 
-// Operand tile loader: 64 (rows: m or n) x 32 (k) floats -> LDS image T[k][row] (pitch GP).
+// Operand tile loader: ROWS (m or n) x 32 (k) floats -> LDS image T[k][row] (pitch ROWS+1).
 // KC: the operand is contiguous along k (else along the row index).  VEC: 16-byte loads are legal
 // (strides multiple of 4 floats, base 16-byte aligned).  All loads of the tile are issued first with
 // clamped indices, zero fill by select, then the LDS writes: one latency exposure per k-block.
-template <bool KC, bool VEC>
+template <int ROWS, bool KC, bool VEC>
 struct TileLoader {
-  float4 v4[2];
-  float v1[8];
+  static constexpr int NV = ROWS / 32;       // float4 per thread
+  static constexpr int NS = ROWS / 8;        // scalars per thread
+  static constexpr int PITCH = ROWS + 1;
+  float4 v4[NV];
+  float v1[VEC ? 1 : NS];
+  __device__ __forceinline__ static void coord_v(int tid, int it, int& r, int& k) {
+    if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
+    else    { r = (tid % (ROWS / 4)) * 4; k = tid / (ROWS / 4) + (1024 / ROWS) * it; }
+  }
+  __device__ __forceinline__ static void coord_s(int tid, int it, int& r, int& k) {
+    if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
+    else    { r = tid % ROWS; k = tid / ROWS + (256 / ROWS) * it; }
+  }
   __device__ __forceinline__ void load(const float* __restrict__ P, long sRow, long sK, int row0, int nRows, int k0,
                                        int kEnd, int tid) {
     if (VEC) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < NV; ++it) {
         int r, k;
-        if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
-        else    { r = (tid & 15) * 4; k = (tid >> 4) + 16 * it; }
+        coord_v(tid, it, r, k);
         const int rr = min(row0 + r, nRows - (KC ? 1 : 4)), kk = min(k0 + k, kEnd - (KC ? 4 : 1));
         v4[it] = *reinterpret_cast<const float4*>(P + (long)rr * sRow + (long)kk * sK);
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < NS; ++it) {
         int r, k;
-        if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
-        else    { r = tid & 63; k = (tid >> 6) + 4 * it; }
+        coord_s(tid, it, r, k);
         const int rr = min(row0 + r, nRows - 1), kk = min(k0 + k, kEnd - 1);
         v1[it] = P[(long)rr * sRow + (long)kk * sK];
       }
@@ -57,44 +65,48 @@ struct TileLoader {
   __device__ __forceinline__ void store(float* __restrict__ T, int row0, int nRows, int k0, int kEnd, int tid) {
     if (VEC) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < NV; ++it) {
         int r, k;
-        if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
-        else    { r = (tid & 15) * 4; k = (tid >> 4) + 16 * it; }
+        coord_v(tid, it, r, k);
         const float e[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int rj = KC ? r : r + j, kj = KC ? k + j : k;
           // VEC tiles are only used when every 4-group is entirely inside or outside the matrix
-          T[kj * GP + rj] = (row0 + rj < nRows && k0 + kj < kEnd) ? e[j] : 0.f;
+          T[kj * PITCH + rj] = (row0 + rj < nRows && k0 + kj < kEnd) ? e[j] : 0.f;
         }
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < NS; ++it) {
         int r, k;
-        if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
-        else    { r = tid & 63; k = (tid >> 6) + 4 * it; }
-        T[k * GP + r] = (row0 + r < nRows && k0 + k < kEnd) ? v1[it] : 0.f;
+        coord_s(tid, it, r, k);
+        T[k * PITCH + r] = (row0 + r < nRows && k0 + k < kEnd) ? v1[it] : 0.f;
       }
     }
   }
 };
 
-template <bool AK, bool BK_, bool AV, bool BV>
+// Block tile TM x TN (64 or 128 each), 2x2 waves, wave tile (TM/2) x (TN/2) of 32x32 MFMA tiles.
+template <int TM, int TN, bool AK, bool BK_, bool AV, bool BV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  __shared__ float As[GBK * GP];
-  __shared__ float Bs[GBK * GP];
+  constexpr int PA = TM + 1, PB = TN + 1, MT = TM / 64, NT = TN / 64;
+  __shared__ float As[GBK * PA];
+  __shared__ float Bs[GBK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, li = lane & 31;
-  const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int kbeg = blockIdx.z * p.kPerSplit;
   const int kend = min(kbeg + p.kPerSplit, p.K);
-  f32x16 acc;
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  TileLoader<AK, AV> la;
-  TileLoader<BK_, BV> lb;
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  TileLoader<TM, AK, AV> la;
+  TileLoader<TN, BK_, BV> lb;
 
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     la.load(p.A, p.sAm, p.sAk, m0, p.M, k0, kend, tid);
@@ -104,23 +116,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < GBK / 2; ++kk) {
-      float a = As[(kk * 2 + h) * GP + wm * 32 + li];
-      float b = Bs[(kk * 2 + h) * GP + wn * 32 + li];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = As[(kk * 2 + h) * PA + wm * (TM / 2) + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = Bs[(kk * 2 + h) * PB + wn * (TN / 2) + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
-  const int n = n0 + wn * 32 + li;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (m < p.M && n < p.N) {
-      float v = acc[r];
-      if (p.bias && blockIdx.z == 0) v += p.bias[n];
-      float* dst = p.C + (long)m * p.ldc + n;
-      if (p.out_mode == 0) *dst = v;
-      else if (p.out_mode == 1) *dst += v;
-      else unsafeAtomicAdd(dst, v);
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (TN / 2) + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][r];
+          if (p.bias && blockIdx.z == 0) v += p.bias[n];
+          float* dst = p.C + (long)m * p.ldc + n;
+          if (p.out_mode == 0) *dst = v;
+          else if (p.out_mode == 1) *dst += v;
+          else unsafeAtomicAdd(dst, v);
+        }
+      }
     }
   }
 }
@@ -139,7 +163,11 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   GemmArgs p;
   p.A = A; p.sAm = sAm; p.sAk = sAk; p.B = B; p.sBk = sBk; p.sBn = sBn; p.C = C; p.ldc = ldc;
   p.bias = bias_n; p.M = M; p.N = N; p.K = K;
-  int tm = cdiv(M, GB), tn = cdiv(N, GB);
+  // 128-wide tiles when the dimension is large enough to keep >= ~256 blocks, else 64
+  // (short K = few k-blocks per tile: many small tiles hide the load latency better)
+  const int TMs = (M >= 192 && K >= 512) ? 128 : 64;
+  const int TNs = (N >= 2048 && K >= 512) ? 128 : 64;
+  int tm = cdiv(M, TMs), tn = cdiv(N, TNs);
   long tiles = (long)tm * tn;
   int splitK = 1;
   if (tiles < 512) splitK = (int)std::max<long>(1, std::min<long>(cdiv(K, 2 * GBK), cdivl(768, tiles)));
@@ -168,9 +196,14 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   };
   const bool av = vec_ok(A, ak, sAm, sAk, M, K, p.kPerSplit), bv = vec_ok(B, bk, sBn, sBk, N, K, p.kPerSplit);
   const int sel = (ak ? 8 : 0) | (bk ? 4 : 0) | (av ? 2 : 0) | (bv ? 1 : 0);
+#define GEMM_LAUNCH(TMv, TNv, AKv, BKv, AVv, BVv) \
+  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<TMv, TNv, AKv, BKv, AVv, BVv>), grid, dim3(256), 0, p)
 #define GEMM_CASE(AKv, BKv, AVv, BVv)                                                                        \
   case ((AKv ? 8 : 0) | (BKv ? 4 : 0) | (AVv ? 2 : 0) | (BVv ? 1 : 0)):                                      \
-    FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<AKv, BKv, AVv, BVv>), grid, dim3(256), 0, p);           \
+    if (TMs == 128 && TNs == 128) GEMM_LAUNCH(128, 128, AKv, BKv, AVv, BVv);                                 \
+    else if (TMs == 128) GEMM_LAUNCH(128, 64, AKv, BKv, AVv, BVv);                                           \
+    else if (TNs == 128) GEMM_LAUNCH(64, 128, AKv, BKv, AVv, BVv);                                           \
+    else GEMM_LAUNCH(64, 64, AKv, BKv, AVv, BVv);                                                            \
     break;
   switch (sel) {
     GEMM_CASE(true, true, true, true) GEMM_CASE(true, true, true, false) GEMM_CASE(true, true, false, true)
@@ -181,6 +214,7 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
     GEMM_CASE(false, false, false, false)
   }
 #undef GEMM_CASE
+#undef GEMM_LAUNCH
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
