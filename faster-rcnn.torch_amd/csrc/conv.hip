@@ -57,27 +57,68 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int C, i
   }
 }
 
-// All packs of a model in ONE launch: blockIdx.y selects the job, blockIdx.x strides over its elements.
-__global__ void pack_weights_multi_kernel(const float* __restrict__ weights, const PackJob* __restrict__ jobs) {
-  const PackJob j = jobs[blockIdx.y];
+// All packs of a model in ONE launch.  Blocks are dealt to jobs in proportion to their size
+// (blk_begin/nblk); each block transposes 32 (m) x 32 (source-contiguous) tiles through LDS so that both
+// the canonical-layout reads and the packed-layout writes are 128-byte coalesced.
+//   mode 0: source matrix S[m = o][q = (c,ky,kx)]           -> dst[row(c,ky,kx)][o]
+//   mode 1: source, per o: S[c][t = (ky,kx)] (q = t, m = c)  -> dst[row(o,k-1-ky,k-1-kx)][c]
+__global__ void pack_weights_multi_kernel(const float* __restrict__ weights, const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int jb = 0;
+  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_begin) ++jb;
+  const PackJob j = jobs[jb];
   const float* __restrict__ w = weights + j.w_off;
-  const int k = j.k;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < j.total; t += (long)gridDim.x * blockDim.x) {
-    int m = (int)(t % j.Mpad);
-    long row = t / j.Mpad;
-    int h = (int)(row & 1);
-    long r2 = row >> 1;
-    int kx = (int)(r2 % k);
-    r2 /= k;
-    int ky = (int)(r2 % k);
-    int kc = (int)(r2 / k) * 2 + h;
-    float v = 0.f;
-    if (j.mode == 0) {
-      if (m < j.O && kc < j.C) v = w[(((long)m * j.C + kc) * k + ky) * k + kx];
-    } else {
-      if (m < j.C && kc < j.O) v = w[(((long)kc * j.C + m) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+  const int k = j.k, kk = k * k;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  // (padding rows/columns are zeroed once when the packed buffers are allocated)
+  if (j.mode == 0) {
+    const int Q = j.C * kk;
+    const int tm = (j.O + 31) / 32, tq = (Q + 31) / 32;
+    for (int tix = blockIdx.x - j.blk_begin; tix < tm * tq; tix += j.nblk) {
+      const int m0 = (tix / tq) * 32, q0 = (tix % tq) * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 8 * i, q = q0 + tx;
+        tile[ty + 8 * i][tx] = (m < j.O && q < Q) ? w[(size_t)m * Q + q] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = q0 + ty + 8 * i, m = m0 + tx;
+        if (q < Q && m < j.O) {
+          const int c = q / kk, t = q - c * kk;
+          const long row = ((long)(c >> 1) * kk + t) * 2 + (c & 1);
+          j.dst[row * j.Mpad + m] = tile[tx][ty + 8 * i];
+        }
+      }
+      __syncthreads();
     }
-    j.dst[t] = v;
+  } else {
+    // per o: [C][kk] slab -> kk rows of C; tiles of 32 c x 32 t (kk <= 49 -> at most 2 t-tiles)
+    const int tc = (j.C + 31) / 32, tt = (kk + 31) / 32;
+    const long ntile = (long)j.O * tc * tt;
+    for (long tix = blockIdx.x - j.blk_begin; tix < ntile; tix += j.nblk) {
+      const int o = (int)(tix / (tc * tt));
+      const int r = (int)(tix % (tc * tt));
+      const int c0 = (r / tt) * 32, t0 = (r % tt) * 32;
+      const float* src = w + (size_t)o * j.C * kk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, t = t0 + tx;
+        tile[ty + 8 * i][tx] = (c < j.C && t < kk) ? src[(size_t)c * kk + t] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, c = c0 + tx;
+        if (t < kk && c < j.C) {
+          const int tf = kk - 1 - t;   // flipped tap: (k-1-ky, k-1-kx)
+          const long row = ((long)(o >> 1) * kk + tf) * 2 + (o & 1);
+          j.dst[row * j.Mpad + c] = tile[tx][ty + 8 * i];
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -88,12 +129,26 @@ PackJob conv_pack_job(long w_off, int O, int C, int k, int mode, float* dst) {
   j.w_off = w_off; j.O = O; j.C = C; j.k = k; j.mode = mode; j.dst = dst;
   j.Mpad = conv_mpad(M);
   j.total = (long)cdiv(kchan, cc) * cc * k * k * j.Mpad;
+  j.blk_begin = 0; j.nblk = 1;
   return j;
 }
 
-int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int njobs, hipStream_t s) {
+// deals `total_blocks` blocks to the jobs in proportion to their element counts; returns the grid size
+int conv_pack_assign_blocks(PackJob* jobs, int njobs, int total_blocks) {
+  double sum = 0;
+  for (int i = 0; i < njobs; ++i) sum += (double)jobs[i].total;
+  int b = 0;
+  for (int i = 0; i < njobs; ++i) {
+    jobs[i].blk_begin = b;
+    jobs[i].nblk = std::max(1, (int)(total_blocks * ((double)jobs[i].total / sum) + 0.5));
+    b += jobs[i].nblk;
+  }
+  return b;
+}
+
+int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int njobs, int grid, hipStream_t s) {
   if (njobs <= 0) return FRCNN_OK;
-  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_weights_multi_kernel, dim3(96, njobs), dim3(256), 0, weights, jobs_dev);
+  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_weights_multi_kernel, dim3(grid), dim3(256), 0, weights, jobs_dev, njobs);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

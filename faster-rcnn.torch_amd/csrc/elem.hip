@@ -153,7 +153,7 @@ int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope,
 // gx[c][y][x] = (argmax of window == this position ? gpool : 0) * scale[c] * prelu'(x)
 // One block per (channel, slab of rows): the bias-gradient and slope-gradient partial sums are
 // reduced in the block and leave through one atomic each.
-template <bool POOLED>
+template <bool POOLED, bool VEC>
 __global__ void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
                                     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
                                     const float* slope, const float* scale, float* __restrict__ gx,
@@ -161,29 +161,64 @@ __global__ void act_backward_kernel(const float* __restrict__ gin, const unsigne
   __shared__ float sh[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long hw = (long)H * W;
-  const long per = cdivl(hw, chunks);
+  long per = cdivl(hw, chunks);
+  if (VEC) per = (per + 3) & ~3L;
   const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
   const float a = slope ? *slope : 1.f;
   const float sc = scale ? scale[c] : 1.f;
+  const bool has_slope = slope != nullptr;
   float sb = 0.f, sa = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    float g;
-    if (POOLED) {
-      int y = (int)(i / W), xx = (int)(i - (long)y * W);
-      int oy = y >> 1, ox = xx >> 1;
-      long po = ((long)c * Ho + oy) * Wo + ox;
-      g = (idx[po] == (unsigned char)((y & 1) * 2 + (xx & 1))) ? gin[po] : 0.f;
-    } else {
-      g = gin[(size_t)c * hw + i];
+  if (VEC) {
+    // 4 consecutive elements of one row per thread: 16-byte loads/stores (W % 4 == 0, Wo even)
+    for (long i = beg + 4L * threadIdx.x; i < end; i += 4L * blockDim.x) {
+      float g[4];
+      if (POOLED) {
+        const int y = (int)(i / W), xx = (int)(i - (long)y * W);
+        const long po = ((long)c * Ho + (y >> 1)) * Wo + (xx >> 1);
+        const float2 gp = *reinterpret_cast<const float2*>(gin + po);
+        const unsigned short ib = *reinterpret_cast<const unsigned short*>(idx + po);
+        const unsigned char code = (unsigned char)((y & 1) * 2);
+        g[0] = ((ib & 0xff) == code) ? gp.x : 0.f;
+        g[1] = ((ib & 0xff) == code + 1) ? gp.x : 0.f;
+        g[2] = ((ib >> 8) == code) ? gp.y : 0.f;
+        g[3] = ((ib >> 8) == code + 1) ? gp.y : 0.f;
+      } else {
+        const float4 gv = *reinterpret_cast<const float4*>(gin + (size_t)c * hw + i);
+        g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
+      }
+      const float4 xv4 = *reinterpret_cast<const float4*>(x + (size_t)c * hw + i);
+      const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+      float r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gj = g[j];
+        if (scale) gj *= sc;
+        r[j] = gj;
+        if (has_slope && !(xv[j] > 0.f)) { r[j] = a * gj; sa += xv[j] * gj; }
+        sb += r[j];
+      }
+      *reinterpret_cast<float4*>(gx + (size_t)c * hw + i) = make_float4(r[0], r[1], r[2], r[3]);
     }
-    if (scale) g *= sc;
-    float xv = x[(size_t)c * hw + i];
-    float r = g;
-    if (slope) {
-      if (!(xv > 0.f)) { r = a * g; sa += xv * g; }
+  } else {
+    for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+      float g;
+      if (POOLED) {
+        int y = (int)(i / W), xx = (int)(i - (long)y * W);
+        int oy = y >> 1, ox = xx >> 1;
+        long po = ((long)c * Ho + oy) * Wo + ox;
+        g = (idx[po] == (unsigned char)((y & 1) * 2 + (xx & 1))) ? gin[po] : 0.f;
+      } else {
+        g = gin[(size_t)c * hw + i];
+      }
+      if (scale) g *= sc;
+      float xv = x[(size_t)c * hw + i];
+      float r = g;
+      if (has_slope) {
+        if (!(xv > 0.f)) { r = a * g; sa += xv * g; }
+      }
+      gx[(size_t)c * hw + i] = r;
+      sb += r;
     }
-    gx[(size_t)c * hw + i] = r;
-    sb += r;
   }
   float tb = block_sum(sb, sh);
   if (threadIdx.x == 0 && gbias) unsafeAtomicAdd(gbias + c, tb);
@@ -204,8 +239,14 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                          float* gslope, hipStream_t s) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
   int chunks = act_bwd_chunks(C, (long)H * W);
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, act_backward_kernel<true>, dim3(C * chunks),
-            dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+  const bool vec = (W % 4 == 0) && (Wo % 2 == 0) && (((uintptr_t)gpool | (uintptr_t)x | (uintptr_t)gx) % 16 == 0) &&
+                   ((uintptr_t)idx % 2 == 0);
+  if (vec)
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, true>), dim3(C * chunks),
+              dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+  else
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, false>), dim3(C * chunks),
+              dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -213,9 +254,15 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
                  const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s) {
   int chunks = act_bwd_chunks(C, hw);
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, act_backward_kernel<false>, dim3(C * chunks),
-            dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, (int)hw, 1, 1, 1, slope, scale, gx,
-            gbias, gslope, chunks);
+  const bool vec = (hw % 4 == 0) && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) % 16 == 0);
+  if (vec)
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, true>), dim3(C * chunks),
+              dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
+              gbias, gslope, chunks);
+  else
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, false>), dim3(C * chunks),
+              dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
+              gbias, gslope, chunks);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

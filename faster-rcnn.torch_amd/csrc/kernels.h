@@ -17,9 +17,10 @@ int conv_mpad(int M);                        // padded M
 size_t conv_pack_floats(int Kchan, int M, int k);
 int conv_pack_weights(const float* w, int O, int C, int k, float* wf, float* wd, hipStream_t s);
 // table-driven variant: every pack of a model in one launch (jobs live in device memory)
-struct PackJob { long w_off; long total; float* dst; int O, C, k, mode, Mpad; };
+struct PackJob { long w_off; long total; float* dst; int O, C, k, mode, Mpad, blk_begin, nblk; };
 PackJob conv_pack_job(long w_off, int O, int C, int k, int mode, float* dst);
-int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int njobs, hipStream_t s);
+int conv_pack_assign_blocks(PackJob* jobs, int njobs, int total_blocks);
+int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int njobs, int grid, hipStream_t s);
 
 enum { OUT_STORE = 0, OUT_ADD = 1 };
 // out[M][Ho][Wo] (=|+=) conv(act(in)[Cin][H][W], wp) (+ bias).  act(x) = scale[c]*prelu(x, *slope)

@@ -95,7 +95,7 @@ struct frcnn_model {
   DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
-  int n_pack_fwd = 0, n_pack_all = 0;
+  int n_pack_fwd = 0, n_pack_all = 0, pack_grid_fwd = 0, pack_grid_all = 0;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -195,8 +195,15 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
   size_t n = (size_t)c.Cout * c.Ho * c.Wo * 4;
   FR_TRY(c.x.ensure(n));
   FR_TRY(c.gx.ensure(n));
-  FR_TRY(c.wf.ensure(conv_pack_floats(c.Cin, c.Cout, c.k) * 4));
-  if (need_dgrad) FR_TRY(c.wd.ensure(conv_pack_floats(c.Cout, c.Cin, c.k) * 4));
+  // packed weights: the padding (channels beyond C, columns beyond M) is zeroed once here and never written again
+  if (c.wf.bytes < conv_pack_floats(c.Cin, c.Cout, c.k) * 4) {
+    FR_TRY(c.wf.ensure(conv_pack_floats(c.Cin, c.Cout, c.k) * 4));
+    FR_HIP(hipMemset(c.wf.p, 0, c.wf.bytes));
+  }
+  if (need_dgrad && c.wd.bytes < conv_pack_floats(c.Cout, c.Cin, c.k) * 4) {
+    FR_TRY(c.wd.ensure(conv_pack_floats(c.Cout, c.Cin, c.k) * 4));
+    FR_HIP(hipMemset(c.wd.p, 0, c.wd.bytes));
+  }
   return FRCNN_OK;
 }
 
@@ -262,8 +269,14 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 1, hd.c1.wd.f()));
     }
     m->n_pack_all = (int)jobs.size();
-    FR_TRY(m->pack_jobs.ensure(jobs.size() * sizeof(PackJob)));
-    FR_HIP(hipMemcpy(m->pack_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    // two tables: [all jobs, blocks dealt over all] then [forward jobs only, blocks dealt over those]
+    std::vector<PackJob> both = jobs;
+    m->pack_grid_all = conv_pack_assign_blocks(both.data(), m->n_pack_all, 2048);
+    std::vector<PackJob> fwd(jobs.begin(), jobs.begin() + m->n_pack_fwd);
+    m->pack_grid_fwd = conv_pack_assign_blocks(fwd.data(), m->n_pack_fwd, 2048);
+    both.insert(both.end(), fwd.begin(), fwd.end());
+    FR_TRY(m->pack_jobs.ensure(both.size() * sizeof(PackJob)));
+    FR_HIP(hipMemcpy(m->pack_jobs.p, both.data(), both.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
   m->H = H; m->W = W;
   return FRCNN_OK;
@@ -366,7 +379,10 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     }
   }
   // weights change every optimiser step: refresh the packed copies (one table-driven launch)
-  FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, training ? m->n_pack_all : m->n_pack_fwd, s));
+  if (training)
+    FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
+  else
+    FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
   FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
   FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
   const float* cur = m->img.f();
