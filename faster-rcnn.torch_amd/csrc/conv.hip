@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include <type_traits>
 
 namespace frcnn {
 
@@ -186,19 +187,36 @@ struct IgemmArgs {
   int Cin, H, W, M, Mpad, Ho, Wo, pad;
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
-  int out_mode;           // 0 store, 1 add, 2 atomic add
+  int out_mode;           // 0 store, 1 add, 3 split-K slab
   int dbg;                // tuning knobs: bit0 skip epilogue, bit1 skip MFMA, bit2 skip staging, bit3 skip barriers
 };
 
+#ifndef IG_TRACE
+#define IG_TRACE 0
+#endif
+#if IG_TRACE
+__device__ unsigned long long g_ig_trace[16 * 4096];
+extern "C" int frcnn_debug_ig_trace(void* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ig_trace), sizeof(unsigned long long) * 16 * 4096); }
+#define TR_NOW() __builtin_readcyclecounter()
+#else
+#define TR_NOW() 0ull
+#endif
 #define IG_MAXIT 4  // patch plane <= 1024 positions
 
-template <int KS, int CC, int BM, bool DB, int NIT>
-__global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(IgemmArgs p) {
+// MODE 0: one LDS buffer, stage -> barrier -> MFMA -> barrier (latency covered by the other blocks of the CU)
+// MODE 1: As and Bs double-buffered in LDS, one barrier per chunk (1x1: big chunks, 2 blocks per CU)
+template <int CC, int MODE>
+constexpr int igemm_blocks_per_cu(int KS, int BM) { return KS == 1 ? 2 : (BM == 64 && CC != 4 ? 5 : 3); }
+
+template <int KS, int CC, int BM, int MODE, int NIT>
+__global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void conv_igemm_kernel(IgemmArgs p) {
   constexpr int KC = CC * KS * KS;   // K rows per chunk
   constexpr int WM = BM / 2;         // 2x2 waves
   constexpr int MT = WM / 32;        // 32x32 tiles per wave along M
   constexpr int NTW = 2;             // ... along N (wave covers 64 pixels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long trR0 = IG_TRACE ? __builtin_amdgcn_s_memrealtime() : 0;
+  unsigned long long tr0 = TR_NOW(), trS = 0, trB1 = 0, trC = 0, trB2 = 0, trT, trI = 0, trW = 0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -217,9 +235,11 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
   const int NT = p.TH * p.TW;
   const int HW = p.H * p.W;
   constexpr int bufFloats = KC * BM + CC * planeP;  // one LDS buffer: As[KC][BM] then Bs[CC][planeP]
+  constexpr int aFloats = KC * BM;
 
-  // this thread's patch positions (same for every channel and chunk)
-  int gofs[NIT];
+  // this thread's patch positions (same for every channel and chunk): byte offsets inside a channel
+  // plane, so that every patch load is `global_load_dword v, voff, s[base]` with a scalar channel base
+  unsigned gofs[NIT];
   bool gok[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
     int r = e / PW, col = e - r * PW;
     int gy = ty0 - p.pad + r, gx = tx0 - p.pad + col;
     gok[it] = e < plane && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    gofs[it] = gok[it] ? gy * p.W + gx : 0;   // clamped: loads are unconditional, zero fill by select
+    gofs[it] = gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u;   // clamped: loads are unconditional, zero fill by select
   }
   const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
   const float slope = has_slope ? *p.in_slope : 1.f;
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
     int q = wn * 64 + nt * 32 + li;
     q = q < NT ? q : NT - 1;
     int ty = q / p.TW, tx = q - ty * p.TW;
-    boff[nt] = KC * BM + h * planeP + ty * PW + tx;
+    boff[nt] = h * planeP + ty * PW + tx;
   }
 
   f32x16 acc[MT][NTW];
@@ -253,56 +273,80 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
 
   // staging registers: only the patch values; the weight rows go global -> LDS by DMA
   float vb[CC][NIT];
+  float scv = 1.f;   // lane cc holds the dropout scale of channel c0+cc
   // LDS-DMA geometry: one wave instruction moves 64 lanes x 16 B = 1 KiB = RPW consecutive rows of As
   constexpr int RPW = 1024 / (BM * 4), NDMA = (KC + 4 * RPW - 1) / (4 * RPW);
-  const int dma_row = __builtin_amdgcn_readfirstlane(wave) * RPW + lane / (BM / 4);
-  const int dma_col = (lane % (BM / 4)) * 4;
+  constexpr bool DMA_FULL = KC % (4 * RPW) == 0;   // every wave instruction of a chunk is in range
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int dma_row = wave_u * RPW + lane / (BM / 4);
+  const unsigned dma_voff = ((unsigned)dma_row * p.Mpad + (lane % (BM / 4)) * 4) * 4u;   // bytes inside a chunk
+  const size_t dma_step = (size_t)4 * RPW * p.Mpad * 4;                                  // bytes between two instructions
+  const size_t hw_bytes = (size_t)HW * 4;
 
-  // All global loads of a chunk are issued back to back (unconditional, clamped offsets): one
-  // latency exposure per chunk, hidden behind the previous chunk's MFMAs when DB.
-  auto stage_load = [&](int chunk, float* buf) {
+  // A wave that stages shares its SIMD with waves that keep the matrix pipe's issue port saturated and is
+  // granted an issue slot only every few tens of cycles (measured: ~6 k cycles for ~150 instructions), so
+  // the staging code is written for instruction COUNT: scalar bases + fixed lane offsets, no per-element
+  // branches, flags resolved once per chunk.
+  auto stage_load = [&](int chunk, float* buf) {   // buf = As of the target buffer
     // weights: `global_load_lds_dwordx4` (LDS destination = wave-uniform base + lane*16, i.e. the linear
     // As[KC][BM] image); completion is covered by the vmcnt(0) that __syncthreads() carries.
-    const float* srcA = p.wp + ((size_t)chunk * KC) * p.Mpad + m0 + dma_col;
+    const char* srcA = reinterpret_cast<const char*>(p.wp + ((size_t)chunk * KC) * p.Mpad + m0);
+    float* dstA = buf + wave_u * RPW * BM;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-      const int r = dma_row + i * 4 * RPW;
-      if (r < KC)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + (size_t)r * p.Mpad),
-                                         (__attribute__((address_space(3))) void*)(buf + (__builtin_amdgcn_readfirstlane(wave) * RPW + i * 4 * RPW) * BM),
-                                         16, 0, 0);
+      if (DMA_FULL || dma_row + i * 4 * RPW < KC)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + i * dma_step + dma_voff),
+                                         (__attribute__((address_space(3))) void*)(dstA + i * 4 * RPW * BM), 16, 0, 0);
     }
     const int c0 = chunk * CC;
+    const char* srcB = reinterpret_cast<const char*>(p.in + (size_t)c0 * HW);
+    if (c0 + CC <= p.Cin) {
 #pragma unroll
-    for (int cc = 0; cc < CC; ++cc) {
-      const int c = c0 + cc;
-      const float* src = p.in + (size_t)(c < p.Cin ? c : 0) * HW;
+      for (int cc = 0; cc < CC; ++cc)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) vb[cc][it] = src[gofs[it]];
+        for (int it = 0; it < NIT; ++it) vb[cc][it] = *reinterpret_cast<const float*>(srcB + cc * hw_bytes + gofs[it]);
+    } else {   // last, partial chunk: out-of-range channels read channel Cin-1 and are zeroed by stage_store
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        const int back = c0 + cc < p.Cin ? 0 : c0 + cc - (p.Cin - 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          vb[cc][it] = *reinterpret_cast<const float*>(srcB + (cc - back) * (long)hw_bytes + gofs[it]);
+      }
     }
+    if (has_scale) scv = p.in_scale[min(c0 + (lane & (CC - 1)), p.Cin - 1)];
   };
   // registers -> LDS; the producing layer's PReLU / dropout scale is applied here
-  auto stage_store = [&](int chunk, float* buf) {
-    const int c0 = chunk * CC;
+  auto store_as = [&](float* bufB, auto slope_c, auto scale_c, int nvalid) {
+    constexpr bool SLOPE = decltype(slope_c)::value, SCALE = decltype(scale_c)::value;
 #pragma unroll
     for (int cc = 0; cc < CC; ++cc) {
-      const int c = c0 + cc;
-      const bool cok = c < p.Cin;
-      const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
+      float sc = 1.f;
+      if (SCALE) sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scv), cc));
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-          float v = vb[cc][it];
-          if (has_slope) v = v > 0.f ? v : slope * v;
-          if (has_scale) v *= sc;
-          buf[KC * BM + cc * planeP + tid + it * 256] = (cok && gok[it]) ? v : 0.f;
-        }
+        float v = vb[cc][it];
+        if (SLOPE) v = v > 0.f ? v : slope * v;
+        if (SCALE) v *= sc;
+        bufB[cc * planeP + tid + it * 256] = (gok[it] && cc < nvalid) ? v : 0.f;
+      }
+    }
+  };
+  auto stage_store = [&](int chunk, float* bufB) {
+    const int nvalid = p.Cin - chunk * CC;   // >= CC except in a partial last chunk
+    if (has_slope) {
+      if (has_scale) store_as(bufB, std::true_type{}, std::true_type{}, nvalid);
+      else store_as(bufB, std::true_type{}, std::false_type{}, nvalid);
+    } else {
+      if (has_scale) store_as(bufB, std::false_type{}, std::true_type{}, nvalid);
+      else store_as(bufB, std::false_type{}, std::false_type{}, nvalid);
     }
   };
   // MFMA over one staged chunk: K' order = ((cp*KS+ky)*KS+kx)*2 + h.  The operand fragments of
   // k-pair i+1 are read from LDS BEFORE the MFMAs of k-pair i are issued (register double buffer +
   // sched_group_barrier), so the ~100+ cycle LDS latency hides behind 4 x 64 cycles of matrix pipe.
-  auto compute = [&](const float* buf) {
-    constexpr int NKP = (CC / 2) * KS * KS;
+  constexpr int NKP = (CC / 2) * KS * KS;
+  auto compute = [&](const float* buf, const float* bufB, const int kbeg, const int kend) {
     float a[2][MT], b[2][NTW];
     auto frag = [&](int kp, float* fa, float* fb) {
       const int cp = kp / (KS * KS), ky = (kp / KS) % KS, kx = kp % KS;
@@ -310,13 +354,13 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) fa[mt] = buf[aoff + kp * 2 * BM + mt * 32];
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) fb[nt] = buf[boff[nt] + rowoff];
+      for (int nt = 0; nt < NTW; ++nt) fb[nt] = bufB[boff[nt] + rowoff];
     };
-    frag(0, a[0], b[0]);
+    frag(kbeg, a[kbeg & 1], b[kbeg & 1]);
 #pragma unroll
-    for (int kp = 0; kp < NKP; ++kp) {
+    for (int kp = kbeg; kp < kend; ++kp) {
       const int cur = kp & 1;
-      if (kp + 1 < NKP) frag(kp + 1, a[cur ^ 1], b[cur ^ 1]);
+      if (kp + 1 < kend) frag(kp + 1, a[cur ^ 1], b[cur ^ 1]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -329,31 +373,51 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
 
   const int cbeg = split * p.chunksPerSplit;
   const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
-  if (DB) {
+  if (MODE == 1) {
     // double-buffered LDS, one barrier per chunk: chunk k+1 is fetched into registers before the
     // MFMAs of chunk k and written to the other buffer after them.
     stage_load(cbeg, smem);
-    stage_store(cbeg, smem);
+    stage_store(cbeg, smem + aFloats);
     __syncthreads();
     int cur = 0;
     for (int chunk = cbeg; chunk < cend; ++chunk) {
       const bool more = chunk + 1 < cend;
-      if (more) stage_load(chunk + 1, smem + (cur ^ 1) * bufFloats);
-      compute(smem + cur * bufFloats);
-      if (more) stage_store(chunk + 1, smem + (cur ^ 1) * bufFloats);
+      float* nxt = smem + (cur ^ 1) * bufFloats;
+      trT = TR_NOW();
+      if (more) stage_load(chunk + 1, nxt);
+      // the patch of chunk k+1 is written half way through the MFMAs (its loads have landed by then and
+      // the ds_writes issue under the matrix pipe's backlog)
+      compute(smem + cur * bufFloats, smem + cur * bufFloats + aFloats, 0, NKP / 2);
+      if (more) stage_store(chunk + 1, nxt + aFloats);
+      compute(smem + cur * bufFloats, smem + cur * bufFloats + aFloats, NKP / 2, NKP);
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trC += t - trT; trT = t; }
       __syncthreads();
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trB1 += t - trT; trT = t; }
       cur ^= 1;
     }
   } else {
     for (int chunk = cbeg; chunk < cend; ++chunk) {
+      trT = TR_NOW();
+      if (p.dbg & 1) __builtin_amdgcn_s_setprio(3);
       stage_load(chunk, smem);
-      stage_store(chunk, smem);
+#if IG_TRACE
+      { unsigned long long t = TR_NOW(); trI += t - trT; trT = t; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { unsigned long long t = TR_NOW(); trW += t - trT; trT = t; }
+#endif
+      stage_store(chunk, smem + aFloats);
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trS += t - trT; trT = t; }
+      if (p.dbg & 1) __builtin_amdgcn_s_setprio(0);
       __syncthreads();
-      compute(smem);
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trB1 += t - trT; trT = t; }
+      compute(smem, smem + aFloats, 0, NKP);
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trC += t - trT; trT = t; }
       __syncthreads();
+      if (IG_TRACE) { unsigned long long t = TR_NOW(); trB2 += t - trT; trT = t; }
     }
   }
 
+  const unsigned long long trE = TR_NOW();
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
   const long HoWo = (long)p.Ho * p.Wo;
 #pragma unroll
@@ -374,12 +438,22 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 3)) void conv_igemm_kernel(Igem
           float* dst = p.out + (size_t)m * HoWo + pofs;
           if (p.out_mode == 0) *dst = v;
           else if (p.out_mode == 1) *dst += v;
-          else if (p.out_mode == 2) unsafeAtomicAdd(dst, v);
           else dst[(size_t)split * p.M * HoWo] = v;   // split-K slab [split][M][Ho*Wo]
         }
       }
     }
   }
+#if IG_TRACE
+  if (tid == 0 && blockIdx.x < 4096) {
+    unsigned long long* t = g_ig_trace + 16 * blockIdx.x;
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    t[0] = tr0; t[1] = trE; t[2] = TR_NOW(); t[3] = trS; t[4] = trB1; t[5] = trC; t[6] = trB2; t[7] = hwid; t[8] = xcc;
+    t[9] = __builtin_amdgcn_s_memrealtime(); t[10] = trR0; t[11] = trI; t[12] = trW;
+  }
+#endif
 }
 
 // out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
@@ -407,13 +481,6 @@ static int ig_workspace(size_t need, float** out) {
   return FRCNN_OK;
 }
 
-__global__ void bias_fill_kernel(float* out, const float* bias, int M, long hw) {
-  long total = (long)M * hw;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (long)gridDim.x * blockDim.x)
-    out[t] = bias ? bias[t / hw] : 0.f;
-}
-
 // choose the output tile (TH x TW <= 128 pixels, patch plane <= 1024) that wastes the least work
 static void choose_tile(int Ho, int Wo, int k, int maxNT, int* TH, int* TW) {
   long best = -1;
@@ -432,28 +499,29 @@ static void choose_tile(int Ho, int Wo, int k, int maxNT, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
-template <int KS, int CC, int BM, bool DB, int NIT>
+template <int KS, int CC, int BM, int MODE, int NIT>
 static int launch_igemm_n(IgemmArgs& a, int klass, double flops, hipStream_t s) {
-  size_t lds = ((size_t)CC * KS * KS * BM + (size_t)CC * NIT * 256) * 4 * (DB ? 2 : 1);
+  const size_t aB = (size_t)CC * KS * KS * BM * 4, bB = (size_t)CC * NIT * 256 * 4;
+  size_t lds = MODE == 1 ? 2 * (aB + bB) : aB + bB;
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM, DB, NIT>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM, MODE, NIT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM, DB, NIT>), dim3(grid), dim3(256), lds, a);
+  FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM, MODE, NIT>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
-template <int KS, int CC, int BM, bool DB>
+template <int KS, int CC, int BM, int MODE>
 static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
   const int plane = (a.TH + KS - 1) * (a.TW + KS - 1);
-  if (plane <= 256) return launch_igemm_n<KS, CC, BM, DB, 1>(a, klass, flops, s);
-  if (plane <= 512) return launch_igemm_n<KS, CC, BM, DB, 2>(a, klass, flops, s);
-  return launch_igemm_n<KS, CC, BM, DB, 4>(a, klass, flops, s);
+  if (plane <= 256) return launch_igemm_n<KS, CC, BM, MODE, 1>(a, klass, flops, s);
+  if (plane <= 512) return launch_igemm_n<KS, CC, BM, MODE, 2>(a, klass, flops, s);
+  return launch_igemm_n<KS, CC, BM, MODE, 4>(a, klass, flops, s);
 }
 
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
@@ -465,56 +533,56 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1; a.pad = pad;
   FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_igemm: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_igemm: unsupported kernel size %d", k);
-  const int BM = a.Mpad == 64 ? 64 : 128;
+  // 64-row M tiles for every spatial kernel: 32 accumulator registers per lane -> 5 blocks per CU (LDS 27 KB
+  // each).  A CU serves its oldest block first, so blocks retire one after the other and the last one runs
+  // alone with its staging exposed; smaller blocks make that tail shorter (measured on every vgg_small layer:
+  // 64-row tiles are 0-14% faster than 128-row tiles).  1x1 keeps 128 rows (large K chunks, LDS double buffer).
+  static const int ig_bm128 = getenv("FRCNN_IG_BM128") ? atoi(getenv("FRCNN_IG_BM128")) : 0;
+  const int BM = (a.Mpad == 64 || (k > 1 && !ig_bm128)) ? 64 : 128;
   choose_tile(a.Ho, a.Wo, k, 128, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
   a.mTiles = a.Mpad / BM;
   const int cc = conv_cc(k);
   a.nChunks = cdiv(Cin, cc);
   long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
-  int splitK = 1;
-  if (blocks < 512) splitK = (int)std::min<long>(std::max<long>(1, 768 / blocks), std::max(1, a.nChunks / 2));
+  // split K until one wave of blocks fills the resident slots, keeping >= ~200 K rows per split
+  const long slots = BM == 64 && k > 1 ? 1280 : 768;
+  const int minChunks = std::max(1, cdiv(200, cc * k * k));
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), 24), std::max(1, a.nChunks / minChunks));
   if (const char* e = getenv("FRCNN_IG_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
-  a.dbg = 0;
+  static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
+  a.dbg = ig_dbg;
   bool slab = false;
-  if (a.splitK > 2 && !(k == 3 && Cin <= 4)) {
-    // >= 3 splits: partial tiles go to slabs with plain stores and one reduce pass adds the bias
-    // (fp32 atomics from 5-8 splits cost 50-70 us per launch in the memory-side atomic units)
+  if (a.splitK > 1) {
+    // partial tiles go to slabs [split][M][Ho*Wo] with plain stores and one reduce pass adds the bias
+    // (fp32 atomics on the shared result serialise in the memory-side atomic units: 2 splits cost 5-10%
+    // more than the slab pass, 5-8 splits 50-70 us per launch)
     float* ws = nullptr;
     FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
-  } else if (a.splitK > 1) {
-    if (out_mode == OUT_STORE) {  // initialise with the bias, then accumulate atomically
-      long total = (long)M * a.Ho * a.Wo;
-      int grid = (int)std::min<long>(cdivl(total, 256), 2048);
-      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0, s, bias_fill_kernel, dim3(grid), dim3(256), 0, out, bias, M,
-                (long)a.Ho * a.Wo);
-      a.bias = nullptr;
-    }
-    a.out_mode = 2;
   }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_IGEMM_K3 : KC_CONV_IGEMM_OTHER;
   int rc;
   if (k == 3 && Cin <= 4) {  // first layer: a 4-channel chunk (the packed rows are ordered by channel pair)
     a.nChunks = 1; a.chunksPerSplit = 1; a.splitK = 1; a.out_mode = out_mode; a.bias = bias; a.out = out;
-    rc = BM == 64 ? launch_igemm<3, 4, 64, false>(a, klass, algo_flops, s)
-                  : launch_igemm<3, 4, 128, false>(a, klass, algo_flops, s);
+    rc = BM == 64 ? launch_igemm<3, 4, 64, 0>(a, klass, algo_flops, s)
+                  : launch_igemm<3, 4, 128, 0>(a, klass, algo_flops, s);
   } else if (k == 3) {
-    rc = BM == 64 ? launch_igemm<3, 8, 64, false>(a, klass, algo_flops, s)
-                  : launch_igemm<3, 8, 128, false>(a, klass, algo_flops, s);
+    rc = BM == 64 ? launch_igemm<3, 8, 64, 0>(a, klass, algo_flops, s)
+                  : launch_igemm<3, 8, 128, 0>(a, klass, algo_flops, s);
   } else if (k == 1) {
-    rc = BM == 64 ? launch_igemm<1, 32, 64, true>(a, klass, algo_flops, s)
-                  : launch_igemm<1, 32, 128, true>(a, klass, algo_flops, s);
+    rc = BM == 64 ? launch_igemm<1, 32, 64, 1>(a, klass, algo_flops, s)
+                  : launch_igemm<1, 32, 128, 1>(a, klass, algo_flops, s);
   } else if (k == 5) {
-    rc = BM == 64 ? launch_igemm<5, 2, 64, false>(a, klass, algo_flops, s)
-                  : launch_igemm<5, 2, 128, false>(a, klass, algo_flops, s);
+    rc = BM == 64 ? launch_igemm<5, 2, 64, 0>(a, klass, algo_flops, s)
+                  : launch_igemm<5, 2, 128, 0>(a, klass, algo_flops, s);
   } else {
-    rc = BM == 64 ? launch_igemm<7, 2, 64, false>(a, klass, algo_flops, s)
-                  : launch_igemm<7, 2, 128, false>(a, klass, algo_flops, s);
+    rc = BM == 64 ? launch_igemm<7, 2, 64, 0>(a, klass, algo_flops, s)
+                  : launch_igemm<7, 2, 128, 0>(a, klass, algo_flops, s);
   }
   FR_TRY(rc);
   if (slab) {
@@ -835,7 +903,8 @@ static void wgrad_plan(WgradArgs& a, int k) {
     a.tilesX = cdiv(a.Wo, W1_TW); a.tilesY = cdiv(a.Ho, W1_TH);
     a.oTiles = a.cTiles = a.kyGroups = 1;
     a.nSplit = std::min(512, a.tilesX * a.tilesY);   // one slab slice per block
-    a.dbg = 0;
+    static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
+  a.dbg = ig_dbg;
     return;
   }
   const int tys = k == 3 ? 3 : 1;
@@ -847,7 +916,8 @@ static void wgrad_plan(WgradArgs& a, int k) {
   long npix = (long)a.tilesX * a.tilesY;
   // two blocks per CU: aim for ~512 blocks
   a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (512 + base / 2) / base));
-  a.dbg = 0;
+  static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
+  a.dbg = ig_dbg;
   if (const char* e = getenv("FRCNN_WG_DBG")) a.dbg = atoi(e);
   if (const char* e = getenv("FRCNN_WG_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }

@@ -59,5 +59,6 @@ int main() {
   run<1>(256, 400, l1, d, src); run<1>(512, 400, l2, d, src); run<1>(768, 400, l3, d, src);
   run<3>(256, 400, l1, d, src); run<3>(512, 400, l2, d, src); run<3>(768, 400, l3, d, src);
   run<3>(720, 400, l3, d, src);
+  run<0>(720, 16, l3, d, src); run<1>(720, 16, l3, d, src); run<3>(720, 16, l3, d, src); run<3>(720, 32, l3, d, src); run<3>(768, 16, l3, d, src);
   return 0;
 }
