@@ -547,7 +547,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
   // split K until one wave of blocks fills the resident slots, keeping >= ~200 K rows per split
   const long slots = BM == 64 && k > 1 ? 1280 : 768;
-  const int minChunks = std::max(1, cdiv(200, cc * k * k));
+  const int minChunks = k == 1 ? 2 : std::max(1, cdiv(200, cc * k * k));
   int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), 24), std::max(1, a.nChunks / minChunks));
   if (const char* e = getenv("FRCNN_IG_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
@@ -624,12 +624,12 @@ struct WgradArgs {
 #define WG_PM 3      // patch slots per lane (patch plane <= 192)
 #define WG_PP 193    // LDS pitch of a patch channel: odd (conflict-free) and >= 64*WG_PM (unconditional stores)
 
-template <int KS, int TYS>
+template <int KS, int TYS, int PM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   constexpr int NTAP = TYS * KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gs = smem;                  // [64][WG_NTP]
-  float* ps = smem + 64 * WG_NTP;    // [64][PP]
+  float* ps = smem + 64 * WG_NTP;    // [64][PP], PP = 129 | 193
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave >> 1, wc = wave & 1;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   const int o0 = ot * 64, c0 = ct * 64, ky0 = kyg * TYS;
   const int PW = p.TW + KS - 1, PHs = p.TH + TYS - 1;
   const int pplane = PHs * PW;
-  constexpr int PP = WG_PP;
+  constexpr int PP = PM == 2 ? 129 : WG_PP;   // odd pitch >= 64*PM
   const int NT = p.TH * p.TW, halfrows = p.TH >> 1;
   const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
   const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
@@ -659,78 +659,124 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
   // ---- per-lane staging geometry (fixed for the whole launch)
   const int g_ty = lane / p.TW, g_tx = lane - g_ty * p.TW;
   const bool g_in = lane < NT;
-  int p_r[WG_PM], p_c[WG_PM];
-  bool p_in[WG_PM];
+  int p_r[PM], p_c[PM];
+  bool p_in[PM];
 #pragma unroll
-  for (int m = 0; m < WG_PM; ++m) {
+  for (int m = 0; m < PM; ++m) {
     const int e = lane + 64 * m;
     p_r[m] = e / PW; p_c[m] = e - p_r[m] * PW;
     p_in[m] = e < pplane;
   }
   // the 16 channels / gradient rows this wave stages
   const int so0 = o0 + wave * 16, sc0 = c0 + wave * 16;
+  const bool stage_full = so0 + 16 <= p.O && sc0 + 16 <= p.Cin;
+  const long g_bytes = (long)HoWo * 4, in_bytes = (long)HW * 4;
+  const char* gb = reinterpret_cast<const char*>(p.g + (size_t)so0 * HoWo);
+  const char* ib = reinterpret_cast<const char*>(p.in + (size_t)sc0 * HW);
+  // lane j holds the dropout scale of staged channel sc0 + j
+  const float scv = has_scale ? p.in_scale[min(sc0 + (lane & 15), p.Cin - 1)] : 1.f;
+
+  // Staging = two batches of 8 rows/channels per pixel tile.  Every batch issues ALL its global loads first
+  // (unconditional, offsets clamped into the tensor -> no divergent branches, one latency exposure per
+  // batch), then selects the zero fill and writes LDS.  Written for instruction count (a staging wave shares
+  // its SIMD with a wave that saturates the matrix pipe's issue port): scalar row/channel bases + per-lane
+  // byte offsets, activation flags resolved outside the loops.  (Prefetching the next tile into registers
+  // during the MFMAs was measured slower: 144 accumulator + 48 staging registers spill, and scratch traffic
+  // shares vmcnt with the prefetch.)
+  auto batch = [&](int b, bool gok, unsigned gofs, const bool* pok, const unsigned* pofs, auto slope_c, auto scale_c, auto full_c) {
+    constexpr bool SLOPE = decltype(slope_c)::value, SCALE = decltype(scale_c)::value, FULL = decltype(full_c)::value;
+    float vg[8], vp[8][PM];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // rows / channels past the end re-read the last valid one (finite data) and are zeroed below
+      const long jo = FULL ? b * 8 + j : b * 8 + j - max(0, so0 + b * 8 + j - (p.O - 1));
+      const long jc = FULL ? b * 8 + j : b * 8 + j - max(0, sc0 + b * 8 + j - (p.Cin - 1));
+      vg[j] = *reinterpret_cast<const float*>(gb + jo * g_bytes + gofs);
+#pragma unroll
+      for (int m = 0; m < PM; ++m) vp[j][m] = *reinterpret_cast<const float*>(ib + jc * in_bytes + pofs[m]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ook = FULL || so0 + b * 8 + j < p.O, cok = FULL || sc0 + b * 8 + j < p.Cin;
+      float sc = 1.f;
+      if (SCALE) sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, scv), b * 8 + j));
+      gs[(wave * 16 + b * 8 + j) * WG_NTP + lane] = (gok && ook) ? vg[j] : 0.f;
+#pragma unroll
+      for (int m = 0; m < PM; ++m) {
+        float v = vp[j][m];
+        if (SLOPE) v = v > 0.f ? v : slope * v;
+        if (SCALE) v *= sc;
+        ps[(wave * 16 + b * 8 + j) * PP + lane + 64 * m] = (pok[m] && cok) ? v : 0.f;
+      }
+    }
+  };
+  auto stage_tile = [&](int t, auto slope_c, auto scale_c) {
+    const int oy0 = (t / p.tilesX) * p.TH, ox0 = (t % p.tilesX) * p.TW;
+    const int goy = oy0 + g_ty, gox = ox0 + g_tx;
+    const bool gok = g_in && goy < p.Ho && gox < p.Wo;
+    const unsigned gofs = gok ? (unsigned)(goy * p.Wo + gox) * 4u : 0u;
+    bool pok[PM];
+    unsigned pofs[PM];
+#pragma unroll
+    for (int m = 0; m < PM; ++m) {
+      const int iy = oy0 - p.pad + ky0 + p_r[m], ix = ox0 - p.pad + p_c[m];
+      pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      pofs[m] = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+    }
+    if (stage_full) {
+      batch(0, gok, gofs, pok, pofs, slope_c, scale_c, std::true_type{});
+      batch(1, gok, gofs, pok, pofs, slope_c, scale_c, std::true_type{});
+    } else {
+      batch(0, gok, gofs, pok, pofs, slope_c, scale_c, std::false_type{});
+      batch(1, gok, gofs, pok, pofs, slope_c, scale_c, std::false_type{});
+    }
+  };
 
   const int nPix = p.tilesX * p.tilesY;
   for (int t = split; t < nPix; t += p.nSplit) {
-    const int oy0 = (t / p.tilesX) * p.TH, ox0 = (t % p.tilesX) * p.TW;
     if (!(p.dbg & 4)) {
-      // Staging = two batches of 8 rows/channels.  Every batch issues ALL its global loads first
-      // (unconditional, offsets clamped into the tensor -> no divergent branches, one latency
-      // exposure per batch), then selects the zero fill and writes LDS.
-      const int goy = oy0 + g_ty, gox = ox0 + g_tx;
-      const bool gok = g_in && goy < p.Ho && gox < p.Wo;
-      const int gofs = gok ? goy * p.Wo + gox : 0;
-      int pofs[WG_PM];
-      bool pok[WG_PM];
-#pragma unroll
-      for (int m = 0; m < WG_PM; ++m) {
-        const int iy = oy0 - p.pad + ky0 + p_r[m], ix = ox0 - p.pad + p_c[m];
-        pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        pofs[m] = pok[m] ? iy * p.W + ix : 0;
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float vg[8], vp[8][WG_PM];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int o = so0 + b * 8 + j, c = sc0 + b * 8 + j;
-          vg[j] = p.g[(size_t)(o < p.O ? o : 0) * HoWo + gofs];
-          const float* ip = p.in + (size_t)(c < p.Cin ? c : 0) * HW;
-#pragma unroll
-          for (int m = 0; m < WG_PM; ++m) vp[j][m] = ip[pofs[m]];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int o = so0 + b * 8 + j, c = sc0 + b * 8 + j;
-          const bool cok = c < p.Cin;
-          const float sc = (has_scale && cok) ? p.in_scale[c] : 1.f;
-          gs[(wave * 16 + b * 8 + j) * WG_NTP + lane] = (gok && o < p.O) ? vg[j] : 0.f;
-#pragma unroll
-          for (int m = 0; m < WG_PM; ++m) {
-            float v = vp[j][m];
-            if (has_slope) v = v > 0.f ? v : slope * v;
-            if (has_scale) v *= sc;
-            ps[(wave * 16 + b * 8 + j) * WG_PP + lane + 64 * m] = (pok[m] && cok) ? v : 0.f;
-          }
-        }
+      if (has_slope) {
+        if (has_scale) stage_tile(t, std::true_type{}, std::true_type{}); else stage_tile(t, std::true_type{}, std::false_type{});
+      } else {
+        if (has_scale) stage_tile(t, std::false_type{}, std::true_type{}); else stage_tile(t, std::false_type{}, std::false_type{});
       }
     }
     __syncthreads();
     if (wave_active && !(p.dbg & 2)) {
+      // K = pixels: lane half h walks rows [h*halfrows, (h+1)*halfrows).  Along a row the KS taps of one
+      // patch row are a sliding window: per pixel ONE new patch value per tap row (+ one gradient value)
+      // is read from LDS for TYS*KS MFMAs; the gradient value of the next pixel is fetched a step ahead and
+      // the MFMAs that only need window values already in registers are issued first.
       const float* ga = gs + (wo * 32 + li) * WG_NTP + h * halfrows * p.TW;
       const float* pb = ps + (wc * 32 + li) * PP + h * halfrows * PW;
+      float a_cur = ga[0];
       for (int r = 0; r < halfrows; ++r) {
         const float* gar = ga + r * p.TW;
         const float* pbr = pb + r * PW;
-        for (int x = 0; x < p.TW; ++x) {
-          const float a = gar[x];
+        float w[TYS][KS];
 #pragma unroll
-          for (int ty = 0; ty < TYS; ++ty)
+        for (int ty = 0; ty < TYS; ++ty)
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-              const float b = pbr[x + ty * PW + kx];
-              acc[ty * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ty * KS + kx], 0, 0, 0);
+          for (int kx = 0; kx < KS - 1; ++kx) w[ty][kx] = pbr[ty * PW + kx];
+        for (int x0 = 0; x0 < p.TW; x0 += KS) {
+#pragma unroll
+          for (int st = 0; st < KS; ++st) {
+            if (x0 + st < p.TW) {
+              const int x = x0 + st;
+              const float a_next = gar[x + 1];   // next pixel (next row's first one at the row end)
+#pragma unroll
+              for (int ty = 0; ty < TYS; ++ty) w[ty][(st + KS - 1) % KS] = pbr[ty * PW + x + KS - 1];
+#pragma unroll
+              for (int ty = 0; ty < TYS; ++ty)
+#pragma unroll
+                for (int kx = 0; kx < KS - 1; ++kx)
+                  acc[ty * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, w[ty][(st + kx) % KS], acc[ty * KS + kx], 0, 0, 0);
+#pragma unroll
+              for (int ty = 0; ty < TYS; ++ty)
+                acc[ty * KS + KS - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, w[ty][(st + KS - 1) % KS], acc[ty * KS + KS - 1], 0, 0, 0);
+              a_cur = a_next;
             }
+          }
         }
       }
     }
@@ -903,8 +949,7 @@ static void wgrad_plan(WgradArgs& a, int k) {
     a.tilesX = cdiv(a.Wo, W1_TW); a.tilesY = cdiv(a.Ho, W1_TH);
     a.oTiles = a.cTiles = a.kyGroups = 1;
     a.nSplit = std::min(512, a.tilesX * a.tilesY);   // one slab slice per block
-    static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
-  a.dbg = ig_dbg;
+    a.dbg = 0;
     return;
   }
   const int tys = k == 3 ? 3 : 1;
@@ -916,8 +961,7 @@ static void wgrad_plan(WgradArgs& a, int k) {
   long npix = (long)a.tilesX * a.tilesY;
   // two blocks per CU: aim for ~512 blocks
   a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (512 + base / 2) / base));
-  static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
-  a.dbg = ig_dbg;
+  a.dbg = 0;
   if (const char* e = getenv("FRCNN_WG_DBG")) a.dbg = atoi(e);
   if (const char* e = getenv("FRCNN_WG_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }
@@ -930,21 +974,19 @@ size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad) 
   return (size_t)a.nSplit * k * k * O * Cin * 4 + 256;
 }
 
-template <int KS, int TYS>
-static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStream_t s) {
-  int pplane = (a.TH + TYS - 1) * (a.TW + KS - 1);
-  (void)pplane;
-  size_t lds = ((size_t)64 * WG_NTP + (size_t)64 * WG_PP) * 4;
+template <int KS, int TYS, int PM>
+static int launch_wgrad_pm(WgradArgs& a, int klass, double flops, float* gw, hipStream_t s) {
+  size_t lds = ((size_t)64 * WG_NTP + (size_t)64 * (PM == 2 ? 129 : WG_PP)) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, TYS>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS, TYS, PM>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.oTiles * a.cTiles * a.kyGroups * a.nSplit;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
   if (frcnn::prof_enabled(klass)) frcnn::prof_before(klass, s);
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS, TYS>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS, TYS, PM>), dim3(grid), dim3(256), lds, s, a);
   const int OC = a.O * a.Cin;
   long total = (long)KS * KS * OC;
   int rgrid = (int)std::min<long>(cdivl(total, 64), 4096);
@@ -953,6 +995,13 @@ static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStr
   if (frcnn::prof_enabled(klass)) frcnn::prof_after(klass, flops, bytes, s);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+template <int KS, int TYS>
+static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStream_t s) {
+  const int pplane = (a.TH + TYS - 1) * (a.TW + KS - 1);   // patch slots: 2 or 3 per lane
+  if (pplane <= 128) return launch_wgrad_pm<KS, TYS, 2>(a, klass, flops, gw, s);
+  return launch_wgrad_pm<KS, TYS, 3>(a, klass, flops, gw, s);
 }
 
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
