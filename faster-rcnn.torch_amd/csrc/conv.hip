@@ -59,63 +59,80 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int C, i
 }
 
 // All packs of a model in ONE launch.  Blocks are dealt to jobs in proportion to their size
-// (blk_begin/nblk); each block transposes 32 (m) x 32 (source-contiguous) tiles through LDS so that both
-// the canonical-layout reads and the packed-layout writes are 128-byte coalesced.
-//   mode 0: source matrix S[m = o][q = (c,ky,kx)]           -> dst[row(c,ky,kx)][o]
-//   mode 1: source, per o: S[c][t = (ky,kx)] (q = t, m = c)  -> dst[row(o,k-1-ky,k-1-kx)][c]
-__global__ void pack_weights_multi_kernel(const float* __restrict__ weights, const PackJob* __restrict__ jobs, int njobs) {
-  __shared__ float tile[32][33];
+// (blk_begin/nblk).  Both layouts are transposes, done through a 64 x 64 LDS tile so that the canonical-layout
+// reads and the packed-layout writes are 256-byte runs (16-byte accesses where the alignment allows):
+//   mode 0: source matrix S[m = o][q = (c,ky,kx)]            -> dst[row(c,ky,kx)][o]
+//   mode 1: source, per o: S[c][t = (ky,kx)] (contiguous)     -> dst[row(o,k-1-ky,k-1-kx)][c]
+// (padding rows/columns of dst are zeroed once when the packed buffers are allocated)
+#define PK_T 64
+#define PK_P 65
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const float* __restrict__ weights, const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[PK_T * PK_P];
   int jb = 0;
   while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_begin) ++jb;
   const PackJob j = jobs[jb];
   const float* __restrict__ w = weights + j.w_off;
   const int k = j.k, kk = k * k;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  // (padding rows/columns are zeroed once when the packed buffers are allocated)
+  const int tid = threadIdx.x;
   if (j.mode == 0) {
     const int Q = j.C * kk;
-    const int tm = (j.O + 31) / 32, tq = (Q + 31) / 32;
+    const int tm = (j.O + PK_T - 1) / PK_T, tq = (Q + PK_T - 1) / PK_T;
+    const bool vec = (Q & 3) == 0 && ((j.w_off & 3) == 0);
+    const int l16 = tid & 15, r16 = tid >> 4;
     for (int tix = blockIdx.x - j.blk_begin; tix < tm * tq; tix += j.nblk) {
-      const int m0 = (tix / tq) * 32, q0 = (tix % tq) * 32;
+      const int m0 = (tix / tq) * PK_T, q0 = (tix % tq) * PK_T;
+      if (vec) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty + 8 * i, q = q0 + tx;
-        tile[ty + 8 * i][tx] = (m < j.O && q < Q) ? w[(size_t)m * Q + q] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + r16 + 16 * i, q = q0 + l16 * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < j.O && q < Q) v = *reinterpret_cast<const float4*>(w + (size_t)m * Q + q);
+          float* t = tile + (r16 + 16 * i) * PK_P + l16 * 4;
+          t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        }
+      } else {
+        const int lq = tid & 63, rm = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = m0 + rm + 4 * i, q = q0 + lq;
+          tile[(rm + 4 * i) * PK_P + lq] = (m < j.O && q < Q) ? w[(size_t)m * Q + q] : 0.f;
+        }
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int q = q0 + ty + 8 * i, m = m0 + tx;
-        if (q < Q && m < j.O) {
+        const int ql = r16 + 16 * i, q = q0 + ql;
+        if (q < Q) {
           const int c = q / kk, t = q - c * kk;
           const long row = ((long)(c >> 1) * kk + t) * 2 + (c & 1);
-          j.dst[row * j.Mpad + m] = tile[tx][ty + 8 * i];
+          const float* tp = tile + (l16 * 4) * PK_P + ql;
+          // columns m0..m0+63 exist in dst (Mpad is a multiple of 64); the tile holds 0 for m >= O
+          *reinterpret_cast<float4*>(j.dst + row * j.Mpad + m0 + l16 * 4) = make_float4(tp[0], tp[PK_P], tp[2 * PK_P], tp[3 * PK_P]);
         }
       }
       __syncthreads();
     }
   } else {
-    // per o: [C][kk] slab -> kk rows of C; tiles of 32 c x 32 t (kk <= 49 -> at most 2 t-tiles)
-    const int tc = (j.C + 31) / 32, tt = (kk + 31) / 32;
-    const long ntile = (long)j.O * tc * tt;
-    for (long tix = blockIdx.x - j.blk_begin; tix < ntile; tix += j.nblk) {
-      const int o = (int)(tix / (tc * tt));
-      const int r = (int)(tix % (tc * tt));
-      const int c0 = (r / tt) * 32, t0 = (r % tt) * 32;
-      const float* src = w + (size_t)o * j.C * kk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, t = t0 + tx;
-        tile[ty + 8 * i][tx] = (c < j.C && t < kk) ? src[(size_t)c * kk + t] : 0.f;
+    // work item = (group of G output channels o, 64-channel c tile): G*n*kk contiguous-per-o source floats
+    const int G = min(16, (PK_T * PK_P) / (PK_T * kk));
+    const int tc = (j.C + PK_T - 1) / PK_T, og = (j.O + G - 1) / G;
+    const long nitem = (long)og * tc;
+    for (long tix = blockIdx.x - j.blk_begin; tix < nitem; tix += j.nblk) {
+      const int o0 = (int)(tix / tc) * G, c0 = (int)(tix % tc) * PK_T;
+      const int n = min(PK_T, j.C - c0), ng = min(G, j.O - o0);
+      const int per = n * kk;
+      for (int e = tid; e < ng * per; e += 256) {
+        const int g = e / per, r = e - g * per;
+        tile[g * (PK_T * kk) + r] = w[((size_t)(o0 + g) * j.C + c0) * kk + r];
       }
       __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t = t0 + ty + 8 * i, c = c0 + tx;
-        if (t < kk && c < j.C) {
-          const int tf = kk - 1 - t;   // flipped tap: (k-1-ky, k-1-kx)
+      for (int e = tid; e < ng * kk * PK_T; e += 256) {
+        const int c = e & (PK_T - 1), gt = e >> 6;
+        const int g = gt / kk, t = gt - g * kk;
+        if (c < n) {
+          const int o = o0 + g, tf = kk - 1 - t;   // flipped tap: (k-1-ky, k-1-kx)
           const long row = ((long)(o >> 1) * kk + tf) * 2 + (o & 1);
-          j.dst[row * j.Mpad + c] = tile[tx][ty + 8 * i];
+          j.dst[row * j.Mpad + c0 + c] = tile[g * (PK_T * kk) + c * kk + t];
         }
       }
       __syncthreads();

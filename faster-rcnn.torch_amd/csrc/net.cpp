@@ -95,7 +95,8 @@ struct frcnn_model {
   DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
-  int n_pack_fwd = 0, n_pack_all = 0, pack_grid_fwd = 0, pack_grid_all = 0;
+  int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
+  bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -264,17 +265,23 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     m->n_pack_fwd = (int)jobs.size();
     for (auto& c : m->convs)
       if (!(c.block == 0 && c.step == 0)) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
-    for (auto& hd : m->heads) {
-      jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 1, hd.c3.wd.f()));
-      jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 1, hd.c1.wd.f()));
-    }
     m->n_pack_all = (int)jobs.size();
-    // two tables: [all jobs, blocks dealt over all] then [forward jobs only, blocks dealt over those]
+    // the heads' input-gradient packs are only needed by the dense head backward (more than SPARSE_MAX_POS
+    // examples on a head); they are refreshed lazily by frcnn_pnet_backward
+    std::vector<PackJob> hd_jobs;
+    for (auto& hd : m->heads) {
+      hd_jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 1, hd.c3.wd.f()));
+      hd_jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 1, hd.c1.wd.f()));
+    }
+    m->n_pack_heads = (int)hd_jobs.size();
+    // three tables: [training jobs, blocks dealt over all] [forward jobs only] [head input-gradient jobs]
     std::vector<PackJob> both = jobs;
     m->pack_grid_all = conv_pack_assign_blocks(both.data(), m->n_pack_all, 2048);
     std::vector<PackJob> fwd(jobs.begin(), jobs.begin() + m->n_pack_fwd);
     m->pack_grid_fwd = conv_pack_assign_blocks(fwd.data(), m->n_pack_fwd, 2048);
+    m->pack_grid_heads = hd_jobs.empty() ? 0 : conv_pack_assign_blocks(hd_jobs.data(), m->n_pack_heads, 2048);
     both.insert(both.end(), fwd.begin(), fwd.end());
+    both.insert(both.end(), hd_jobs.begin(), hd_jobs.end());
     FR_TRY(m->pack_jobs.ensure(both.size() * sizeof(PackJob)));
     FR_HIP(hipMemcpy(m->pack_jobs.p, both.data(), both.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
@@ -379,6 +386,7 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     }
   }
   // weights change every optimiser step: refresh the packed copies (one table-driven launch)
+  m->head_packs_fresh = false;
   if (training)
     FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
   else
@@ -493,6 +501,11 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       continue;
     }
     h.sp_count = -1; h.sp_pos = nullptr;
+    if (!m->head_packs_fresh) {   // dense fallback: bring the heads' input-gradient packs up to date
+      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all + m->n_pack_fwd, m->n_pack_heads,
+                                     m->pack_grid_heads, s));
+      m->head_packs_fresh = true;
+    }
     // 1x1 conv: accGradParameters + updateGradInput
     FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
     FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));

@@ -24,6 +24,6 @@ def run(R, I, O, reps=5):
         print("R=%d I=%d O=%d %-6s %8.1f us  %6.2f TFLOP/s  weight stream %.2f TB/s" % (R, I, O, name, t * 1e3, 2.0 * R * I * O / t / 1e9, (O * I * 4.0 * (2 if name == "wgrad" else 1)) / t / 1e9), flush=True)
 
 if __name__ == "__main__":
-    for R in (64, 100, 130):
+    for R in (138, 320, 560):
         run(R, 13824, 1024)
-    run(100, 1024, 512)
+    run(560, 1024, 512)
