@@ -97,6 +97,9 @@ struct frcnn_model {
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
+  hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
+  std::vector<hipEvent_t> fork_ev;
+  hipEvent_t join_ev = nullptr;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -325,6 +328,9 @@ int frcnn_model_destroy(frcnn_model* m) {
   }
   m->spD.release(); m->spHX.release(); m->spHY.release(); m->spGH.release(); m->spCol.release(); m->spDX.release();
   m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->zero_arena.release();
+  for (auto e : m->fork_ev) (void)hipEventDestroy(e);
+  if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+  if (m->side) (void)hipStreamDestroy(m->side);
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
   delete m;
@@ -520,6 +526,17 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
                       in.gpooled.f(), OUT_ADD, f3, s));  // nngraph fan-out: gradients add up
   }
+  // The weight gradient of a layer and the input gradient that feeds the next act_backward are independent:
+  // accGradParameters goes to a side stream, so its blocks fill the CUs that the tail of the updateGradInput
+  // kernel (one wave of blocks, retiring unevenly) leaves idle, and the ~4 us dispatch gaps of one chain
+  // are covered by the other.
+  static const bool use_side = !(getenv("FRCNN_SIDE_STREAM") && atoi(getenv("FRCNN_SIDE_STREAM")) == 0);
+  if (use_side && !m->side) {
+    FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
+  }
+  hipStream_t ws = use_side ? m->side : s;
+  size_t n_fork = 0;
   for (int b = nb - 1; b >= 0; --b) {
     Block& blk = m->blocks[b];
     for (int st = blk.nconv - 1; st >= 0; --st) {
@@ -541,7 +558,17 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
-      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
+      if (use_side) {
+        if (m->fork_ev.size() <= n_fork) {
+          hipEvent_t e;
+          FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          m->fork_ev.push_back(e);
+        }
+        FR_HIP(hipEventRecord(m->fork_ev[n_fork], s));           // c.gx is final here
+        FR_HIP(hipStreamWaitEvent(ws, m->fork_ev[n_fork], 0));
+        ++n_fork;
+      }
+      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
       if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       if (st > 0) {
@@ -553,6 +580,10 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
                           c.k - 1 - c.pad, m->blocks[b - 1].gpooled.f(), OUT_ADD, fl, s));
       }
     }
+  }
+  if (use_side) {   // the caller's stream continues after every weight gradient has landed
+    FR_HIP(hipEventRecord(m->join_ev, ws));
+    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
   }
   return FRCNN_OK;
 }
