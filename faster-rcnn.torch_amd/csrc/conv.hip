@@ -485,16 +485,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nSplit,
 }
 
 // library-owned split-K workspace (grown outside the steady state)
-static void* g_ig_ws = nullptr;
-static size_t g_ig_ws_bytes = 0;
-static int ig_workspace(size_t need, float** out) {
-  if (need > g_ig_ws_bytes) {
-    if (g_ig_ws) FR_HIP(hipFree(g_ig_ws));
-    g_ig_ws = nullptr; g_ig_ws_bytes = 0;
-    FR_HIP(hipMalloc(&g_ig_ws, need));
-    g_ig_ws_bytes = need;
+// (one per stream that may run split-K convolutions concurrently: slot 0 = caller's stream, 1 = side stream)
+static void* g_ig_ws[2] = {nullptr, nullptr};
+static size_t g_ig_ws_bytes[2] = {0, 0};
+static int ig_workspace(size_t need, float** out, int slot) {
+  if (need > g_ig_ws_bytes[slot]) {
+    if (g_ig_ws[slot]) FR_HIP(hipFree(g_ig_ws[slot]));
+    g_ig_ws[slot] = nullptr; g_ig_ws_bytes[slot] = 0;
+    FR_HIP(hipMalloc(&g_ig_ws[slot], need));
+    g_ig_ws_bytes[slot] = need;
   }
-  *out = (float*)g_ig_ws;
+  *out = (float*)g_ig_ws[slot];
   return FRCNN_OK;
 }
 
@@ -543,7 +544,7 @@ static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
 
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
-               double algo_flops, hipStream_t s) {
+               double algo_flops, hipStream_t s, int ws_slot) {
   IgemmArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.Mpad = conv_mpad(M);
@@ -578,7 +579,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
     // (fp32 atomics on the shared result serialise in the memory-side atomic units: 2 splits cost 5-10%
     // more than the slab pass, 5-8 splits 50-70 us per launch)
     float* ws = nullptr;
-    FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws));
+    FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 1));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;

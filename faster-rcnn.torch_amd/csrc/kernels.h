@@ -27,7 +27,7 @@ enum { OUT_STORE = 0, OUT_ADD = 1 };
 // when the pointers are non-null.  Ho = H + 2*pad - k + 1.
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
-               double algo_flops, hipStream_t s);
+               double algo_flops, hipStream_t s, int ws_slot = 0);  // ws_slot: split-K workspace (0 | 1)
 
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (atomic accumulation)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.

@@ -100,6 +100,7 @@ struct frcnn_model {
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  bool side_busy = false;          // work was forked to the side stream and not joined yet
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -373,11 +374,49 @@ int frcnn_model_localizer_layers(const frcnn_model* m, int output_index, int* la
 }
 
 // ------------------------------------------------------------------------------------ pnet
+static bool side_enabled() {
+  static const bool on = !(getenv("FRCNN_SIDE_STREAM") && atoi(getenv("FRCNN_SIDE_STREAM")) == 0);
+  return on;
+}
+
+static int ensure_side(frcnn_model* m) {
+  if (!m->side) {
+    FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
+  }
+  return FRCNN_OK;
+}
+
+// side stream waits for everything enqueued on `s` so far
+static int fork_side(frcnn_model* m, hipStream_t s, size_t idx) {
+  FR_TRY(ensure_side(m));
+  while (m->fork_ev.size() <= idx) {
+    hipEvent_t e;
+    FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->fork_ev.push_back(e);
+  }
+  FR_HIP(hipEventRecord(m->fork_ev[idx], s));
+  FR_HIP(hipStreamWaitEvent(m->side, m->fork_ev[idx], 0));
+  m->side_busy = true;
+  return FRCNN_OK;
+}
+
+// one anchor net: k x k conv -> PReLU (fused into the 1x1 loader) -> 1x1 conv (models/model_utilities.lua:31-34)
+static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, int ws_slot) {
+  const Block& in = m->blocks[h.input];
+  FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
+                    h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
+  FR_TRY(conv_igemm(h.c3.x.f(), h.c1.Cin, h.c1.H, h.c1.W, w + h.c3.a_off, nullptr, h.c1.wf.f(), w + h.c1.b_off,
+                    HEAD_OUT, 1, 0, h.c1.x.f(), OUT_STORE, 0, s, ws_slot));
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
                        const float* const* drop_masks, unsigned long long seed, void* stream) {
   hipStream_t s = S(stream);
   if (H != m->H || W != m->W) FR_TRY(ensure_shapes(m, H, W));
   m->training = training;
+  const bool use_side = side_enabled();
   // SpatialDropout scales
   for (size_t b = 0; b < m->blocks.size(); ++b) {
     Block& blk = m->blocks[b];
@@ -418,13 +457,41 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     cur = blk.pooled.f();
     cur_slope = nullptr;
     cur_scale = nullptr;
+    // anchor nets on an earlier block's map run beside the following blocks
+    if (use_side && b + 1 < m->blocks.size()) {
+      bool forked = false;
+      for (auto& h : m->heads) {
+        if (h.input != (int)b) continue;
+        if (!forked) {
+          FR_TRY(fork_side(m, s, b));
+          forked = true;
+        }
+        FR_TRY(head_forward(m, h, w, m->side, 1));
+      }
+    }
   }
-  for (auto& h : m->heads) {
-    const Block& in = m->blocks[h.input];
-    FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
-                      h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s));
-    FR_TRY(conv_igemm(h.c3.x.f(), h.c1.Cin, h.c1.H, h.c1.W, w + h.c3.a_off, nullptr, h.c1.wf.f(), w + h.c1.b_off,
-                      HEAD_OUT, 1, 0, h.c1.x.f(), OUT_STORE, 0, s));
+  // heads on the LAST block's map: the heaviest stays on the caller's stream, the others share the side stream
+  {
+    const int last = (int)m->blocks.size() - 1;
+    int heavy = -1;
+    for (size_t i = 0; i < m->heads.size(); ++i)
+      if ((!use_side || m->heads[i].input == last) && (heavy < 0 || m->heads[i].c3.k > m->heads[heavy].c3.k)) heavy = (int)i;
+    bool forked = false;
+    for (size_t i = 0; use_side && i < m->heads.size(); ++i) {
+      if (m->heads[i].input != last || (int)i == heavy) continue;
+      if (!forked) {
+        FR_TRY(fork_side(m, s, m->blocks.size()));
+        forked = true;
+      }
+      FR_TRY(head_forward(m, m->heads[i], w, m->side, 1));
+    }
+    for (size_t i = 0; i < m->heads.size(); ++i)
+      if ((int)i == heavy || (!use_side)) FR_TRY(head_forward(m, m->heads[i], w, s, 0));
+  }
+  if (use_side && m->side_busy) {   // the caller's stream continues after every head is done
+    FR_HIP(hipEventRecord(m->join_ev, m->side));
+    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+    m->side_busy = false;
   }
   return FRCNN_OK;
 }
@@ -530,11 +597,8 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   // accGradParameters goes to a side stream, so its blocks fill the CUs that the tail of the updateGradInput
   // kernel (one wave of blocks, retiring unevenly) leaves idle, and the ~4 us dispatch gaps of one chain
   // are covered by the other.
-  static const bool use_side = !(getenv("FRCNN_SIDE_STREAM") && atoi(getenv("FRCNN_SIDE_STREAM")) == 0);
-  if (use_side && !m->side) {
-    FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
-  }
+  const bool use_side = side_enabled();
+  if (use_side) FR_TRY(ensure_side(m));
   hipStream_t ws = use_side ? m->side : s;
   size_t n_fork = 0;
   for (int b = nb - 1; b >= 0; --b) {
@@ -558,16 +622,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
-      if (use_side) {
-        if (m->fork_ev.size() <= n_fork) {
-          hipEvent_t e;
-          FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          m->fork_ev.push_back(e);
-        }
-        FR_HIP(hipEventRecord(m->fork_ev[n_fork], s));           // c.gx is final here
-        FR_HIP(hipStreamWaitEvent(ws, m->fork_ev[n_fork], 0));
-        ++n_fork;
-      }
+      if (use_side) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
       FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
       if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
@@ -584,6 +639,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   if (use_side) {   // the caller's stream continues after every weight gradient has landed
     FR_HIP(hipEventRecord(m->join_ev, ws));
     FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+    m->side_busy = false;
   }
   return FRCNN_OK;
 }
