@@ -100,6 +100,7 @@ struct frcnn_model {
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  bool heads_begun = false;        // anchor-net backward already running on the side stream
   bool side_busy = false;          // work was forked to the side stream and not joined yet
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
@@ -416,6 +417,7 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
   hipStream_t s = S(stream);
   if (H != m->H || W != m->W) FR_TRY(ensure_shapes(m, H, W));
   m->training = training;
+  m->heads_begun = false;
   const bool use_side = side_enabled();
   // SpatialDropout scales
   for (size_t b = 0; b < m->blocks.size(); ++b) {
@@ -529,16 +531,9 @@ int frcnn_pnet_zero_deltas(frcnn_model* m, void* stream) {
   return FRCNN_OK;
 }
 
-int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* stream) {
-  hipStream_t s = S(stream);
-  FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
-                                    "(nn.SpatialDropout: backprop only defined while training)");
-  const int nb = (int)m->blocks.size();
-  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
-  {  // output nheads+1 is the last pooled map itself (model_utilities.lua:55)
-    Block& last = m->blocks.back();
-    FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
-  }
+// anchor-net part of pnet:backward: gradients of the head parameters, input gradients added into the pooled
+// maps' gradient buffers (nngraph fan-out).  Runs on stream s with split-K workspace slot ws_slot.
+static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream_t s, int ws_slot) {
   for (auto& h : m->heads) {
     Block& in = m->blocks[h.input];
     Conv &a = h.c3, &c = h.c1;
@@ -584,14 +579,45 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));
     double f1 = 2.0 * HEAD_OUT * c.Cin * (double)hw1;
     FR_TRY(conv_igemm(h.delta.f(), HEAD_OUT, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, 1, 0, a.gx.f(),
-                      OUT_STORE, f1, s));
+                      OUT_STORE, f1, s, ws_slot));
     // PReLU backward of the head (+ bias gradient of the k x k conv)
     FR_TRY(act_backward(a.gx.f(), a.x.f(), a.Cout, (long)a.Ho * a.Wo, w + a.a_off, nullptr, a.gx.f(),
                         grad + a.b_off, grad + a.a_off, s));
     FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
     double f3 = 2.0 * a.Cout * a.Cin * a.k * a.k * (double)a.Ho * a.Wo;
     FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
-                      in.gpooled.f(), OUT_ADD, f3, s));  // nngraph fan-out: gradients add up
+                      in.gpooled.f(), OUT_ADD, f3, s, ws_slot));  // nngraph fan-out: gradients add up
+  }
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_backward_heads_begin(frcnn_model* m, const float* w, float* grad, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(m->H > 0 && m->training, "pnet_backward_heads_begin: needs a preceding training-mode forward");
+  if (!side_enabled() || m->heads_begun) return FRCNN_OK;   // frcnn_pnet_backward does everything
+  FR_TRY(fork_side(m, s, m->blocks.size() + 1));             // delta_outputs[1..nheads] are final on s
+  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
+  FR_TRY(backward_heads(m, w, grad, m->side, 1));
+  m->heads_begun = true;
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
+                                    "(nn.SpatialDropout: backprop only defined while training)");
+  const int nb = (int)m->blocks.size();
+  if (m->heads_begun) {   // started by frcnn_pnet_backward_heads_begin: wait for the side stream
+    FR_HIP(hipEventRecord(m->join_ev, m->side));
+    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+    m->heads_begun = false; m->side_busy = false;
+  } else {
+    FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
+    FR_TRY(backward_heads(m, w, grad, s, 0));
+  }
+  {  // output nheads+1 is the last pooled map itself (model_utilities.lua:55)
+    Block& last = m->blocks.back();
+    FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
   }
   // The weight gradient of a layer and the input gradient that feeds the next act_backward are independent:
   // accGradParameters goes to a side stream, so its blocks fill the CUs that the tail of the updateGradInput

@@ -166,6 +166,12 @@ class ProposalNet(object):
         _lib.call("frcnn_pnet_backward", nat.h, ptr(nat.weights), ptr(nat.gradient), stream_ptr())
         return None  # gradInput of the first convolution is unused by the reference and not computed
 
+    def backward_heads_begin(self):
+        """Optional early start of :backward: the anchor nets' part runs on the library's side stream as soon
+        as delta_outputs[1..nheads] are final (they are, after objective.lua:140), beside the cnet stage."""
+        nat = self.native
+        _lib.call("frcnn_pnet_backward_heads_begin", nat.h, ptr(nat.weights), ptr(nat.gradient), stream_ptr())
+
     def parameters(self):
         return _param_views(self.native, 0, self.native.pnet_params)
 

@@ -174,6 +174,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                           C.c_void_p(d_roi), C.c_void_p(d_class), npos, nneg, bgclass, ptr(ex_loss), ptr(crtarget),
                           ptr(cctarget), s)
                 _accumulate_losses(ex_loss, E, acc_dev, s)
+                # delta_outputs[1..4] are final (the fine-tuning stage only touches delta_outputs[5], :182-185):
+                # the anchor nets' backward starts now on the side stream, beside the cnet stage
+                pnet.backward_heads_begin()  # (delta_outputs are the model-owned buffers of :78-84)
                 # ---- ROI pooling of every example in one launch (:117-119, :137-139) ---------
                 cinput = scratch.get("cinput", (E, D))
                 pidx = scratch.get("pidx", (E, D), np.int32)
@@ -199,11 +202,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             ccls_count += 1
 
         # ---- statistics: one read-back per call ------------------------------------------
+        single = _dist() is None
+        if single and cls_count > 0:  # the divisor is host-known: queue the scaling before the blocking read-back
+            _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         a = acc_dev.numpy()
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
         tot = allreduce_gradient_and_stats(gradient, tot)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
-        if cls_count > 0:
+        if not single and cls_count > 0:
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         with np.errstate(divide="ignore", invalid="ignore"):
             pcls = float(np.float64(cls_loss) / cls_count)  # :202-205

@@ -217,6 +217,12 @@ int frcnn_pnet_zero_deltas(frcnn_model *, void *stream);
  * how objective.lua:91-134 fills it (only the sampled anchors).  The head's backward then runs on those
  * positions only; the result is identical.  count < 0 (default) or > 512: dense backward. */
 int frcnn_pnet_set_sparse_deltas(frcnn_model *, int head, const int *positions, int count);
+/* Optional early start of pnet:backward (objective.lua:189): once delta_outputs[1..nheads] are final (after
+ * the anchor loop, objective.lua:91-140 -- the fine-tuning stage only adds into delta_outputs[nheads+1]),
+ * the anchor-net part of the backward pass may begin on the library's side stream, beside the
+ * classification network's forward/backward on `stream`.  frcnn_pnet_backward then joins it.  Without this
+ * call frcnn_pnet_backward does everything itself; the result is the same. */
+int frcnn_pnet_backward_heads_begin(frcnn_model *, const float *weights, float *grad, void *stream);
 /* pnet:backward(img, delta_outputs) (objective.lua:189): accumulates into the flat gradient.
  * The (unused) input gradient of the first convolution is not computed. */
 int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *stream);
