@@ -239,12 +239,20 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, li = lane & 31;
 
-  int bid = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so block b and
+  // b+8 share an L2.  The virtual index v walks one XCD's blocks consecutively, and consecutive v are the
+  // M tiles of ONE pixel tile: the input patch they all stage is read from HBM once and then hits in that L2.
   const int nT = p.tilesX * p.tilesY;
-  const int nt_id = bid % nT;
-  bid /= nT;
-  const int mt_id = bid % p.mTiles;
-  const int split = bid / p.mTiles;
+  int v;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    v = xcd * q + min(xcd, r) + idx;
+  }
+  const int mt_id = v % p.mTiles;
+  v /= p.mTiles;
+  const int nt_id = v % nT;
+  const int split = v / nT;
   const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
   const int m0 = mt_id * BM;
   const int PW = p.TW + KS - 1, PH = p.TH + KS - 1, plane = PH * PW;
