@@ -375,9 +375,17 @@ int frcnn_model_localizer_layers(const frcnn_model* m, int output_index, int* la
 }
 
 // ------------------------------------------------------------------------------------ pnet
+static int g_side_stream = -1;   // -1: not decided yet (environment FRCNN_SIDE_STREAM, default on)
 static bool side_enabled() {
-  static const bool on = !(getenv("FRCNN_SIDE_STREAM") && atoi(getenv("FRCNN_SIDE_STREAM")) == 0);
-  return on;
+  if (g_side_stream < 0) g_side_stream = !(getenv("FRCNN_SIDE_STREAM") && atoi(getenv("FRCNN_SIDE_STREAM")) == 0) ? 1 : 0;
+  return g_side_stream != 0;
+}
+
+int frcnn_set_option(const char* name, int value) {
+  FR_CHECK(name != nullptr, "set_option: null name");
+  if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
+  FR_CHECK(false, "set_option: unknown option '%s'", name);
+  return FRCNN_OK;
 }
 
 static int ensure_side(frcnn_model* m) {

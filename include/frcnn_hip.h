@@ -41,6 +41,10 @@ const char *frcnn_last_error(void);
 int frcnn_device_count(int *n);
 int frcnn_set_device(int device);            /* cutorch.setDevice, main.lua:52 (0-based here) */
 int frcnn_device_name(char *buf_host, int len);
+/* Library tuning knobs.  "side_stream" (default 1; environment FRCNN_SIDE_STREAM): independent parts of a
+ * pass (anchor nets, weight gradients) are issued on a library-owned second HIP stream and joined before the
+ * entry point's results are used on the caller's stream.  0 = strictly serial on the caller's stream. */
+int frcnn_set_option(const char *name, int value);
 
 /* ---- device buffers (torch.CudaTensor storage; main.lua:86-89, objective.lua:66,147-149) */
 int frcnn_malloc(void **ptr_out_host, size_t bytes);

@@ -1,0 +1,36 @@
+"""Build profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs with
+--kernel-trace only, as MI355X_MICROARCH.md prescribes).  usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+Values are KB per dispatch (x1024).  gfx950 correction: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled
+(calibrated on rmsprop_kernel: 3 reads + 2 writes of the flat parameter vector)."""
+import collections, csv, glob, json, re, sys
+
+
+def collect(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"^void |frcnn::|\(.*$", "", r["Kernel_Name"])
+        acc[name].append(float(r["Counter_Value"]) * 1024.0)
+    return acc
+
+
+fetch = collect(sys.argv[1], "FETCH_SIZE")
+write = collect(sys.argv[2], "WRITE_SIZE")
+out = {"method": __doc__.split("usage")[0].strip() + " Passes ran over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`.",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    fv, wv = fetch.get(k, []), write.get(k, [])
+    out["kernels"][k] = dict(launches=max(len(fv), len(wv)),
+                             fetch_bytes_per_launch_corrected=2.0 * sum(fv) / max(len(fv), 1),
+                             write_bytes_per_launch=sum(wv) / max(len(wv), 1))
+k3 = [k for k in out["kernels"] if k.startswith("conv_igemm_kernel<3, 8")]
+n = sum(out["kernels"][k]["launches"] for k in k3)
+if n:
+    out["conv_igemm_k3_bytes_per_launch"] = round(sum(out["kernels"][k]["launches"] * (out["kernels"][k]["fetch_bytes_per_launch_corrected"] + out["kernels"][k]["write_bytes_per_launch"]) for k in k3) / n)
+rm = out["kernels"].get("rmsprop_kernel")
+if rm:
+    out["calibration_rmsprop"] = dict(fetch_corrected=rm["fetch_bytes_per_launch_corrected"], write=rm["write_bytes_per_launch"])
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print("conv_igemm_k3 bytes/launch:", out.get("conv_igemm_k3_bytes_per_launch"), " rmsprop:", out.get("calibration_rmsprop"))
