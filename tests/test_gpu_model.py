@@ -279,3 +279,42 @@ def test_sparse_head_backward_equals_dense(F, setup):
     g_dense, g_sparse = run(False), run(True)
     pnet.drop_masks = None
     _compare_gradient(nat, g_sparse, g_dense, 0, nat.pnet_params, tol_l2=1e-5, elementwise=False)
+
+
+def test_side_stream_equals_serial(F, setup):
+    """frcnn_set_option("side_stream"): issuing the anchor nets / weight gradients on the library's second
+    stream (and starting the anchor nets' backward early, frcnn_pnet_backward_heads_begin) must not change the
+    result: same losses, same gradient up to the summation order of delta_outputs[5] + anchor-net terms."""
+    import torch
+    s = setup
+    model, cfg = s["model"], s["cfg"]
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rois = F.synthetic_rois(cfg, W, H, 3, 7, 1)
+    pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(11), negatives=8)
+    sizes = F.output_map_sizes(model, H, W)
+    pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
+    batch = [dict(img=F.synthetic_image(H, W, 1), positive=pos, negative=neg)]
+    R = len(pos) + len(neg)
+    assert R > 0
+    rng = np.random.RandomState(5)
+    nat = model["native"]
+    bn0 = nat.bn_running.cpu().numpy().copy()
+    model["pnet"].drop_masks = _masks(rng, model)
+    model["cnet"].drop_masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+    res = {}
+    try:
+        for mode in (1, 0):
+            F._lib.call("frcnn_set_option", b"side_stream", mode)
+            stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+            f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+            loss, grad = f(s["weights"])
+            res[mode] = (loss, [stats[k][-1] for k in ("pcls", "preg", "dcls", "dreg")], grad.cpu().numpy().copy())
+            nat.bn_running.copy_(torch.from_numpy(bn0))
+    finally:
+        F._lib.call("frcnn_set_option", b"side_stream", 1)
+        model["pnet"].drop_masks = None
+        model["cnet"].drop_masks = None
+    assert res[1][0] == res[0][0] and res[1][1] == res[0][1]
+    a, b = res[1][2], res[0][2]
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
