@@ -6,6 +6,7 @@
 //   wgrad   : gW[O][I] += gY[R][O]^T * X[R][I]     A m-contiguous, B n-contiguous
 // 64x64 block tile (2x2 waves of one 32x32 MFMA tile), BK = 32, split-K over gridDim.z with
 // fp32 atomics when the tile grid alone cannot fill 256 CUs (R is a few hundred rows at most).
+#include <cstdlib>
 #include "kernels.h"
 
 namespace frcnn {
@@ -163,14 +164,17 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   GemmArgs p;
   p.A = A; p.sAm = sAm; p.sAk = sAk; p.B = B; p.sBk = sBk; p.sBn = sBn; p.C = C; p.ldc = ldc;
   p.bias = bias_n; p.M = M; p.N = N; p.K = K;
-  // 128-wide tiles when the dimension is large enough to keep >= ~256 blocks, else 64
-  // (short K = few k-blocks per tile: many small tiles hide the load latency better)
-  const int TMs = (M >= 192 && K >= 512) ? 128 : 64;
-  const int TNs = (N >= 2048 && K >= 512) ? 128 : 64;
+  // 64-row tiles (more, shorter-lived blocks per CU: same finding as for the convolution tiles); 128 columns
+  // when N is long.  Split K until one wave of blocks fills the resident slots, >= 256 K values per split, <= 16 splits.
+  int TMs = 64;
+  int TNs = (N >= 2048 && K >= 512) ? 128 : 64;
+  if (const char* e = getenv("FRCNN_GEMM_TM")) TMs = atoi(e);
+  if (const char* e = getenv("FRCNN_GEMM_TN")) TNs = atoi(e);
   int tm = cdiv(M, TMs), tn = cdiv(N, TNs);
   long tiles = (long)tm * tn;
-  int splitK = 1;
-  if (tiles < 512) splitK = (int)std::max<long>(1, std::min<long>(cdiv(K, 2 * GBK), cdivl(768, tiles)));
+  const long slots = TNs == 128 ? 1280 : 2048;
+  int splitK = (int)std::max<long>(1, std::min<long>(std::min<long>(K / 256, 16), slots / tiles));
+  if (const char* e = getenv("FRCNN_GEMM_SPLITK")) splitK = std::max(1, atoi(e));
   p.kPerSplit = cdiv(cdiv(K, splitK), GBK) * GBK;
   splitK = cdiv(K, p.kPerSplit);
   p.out_mode = out_mode;
@@ -183,6 +187,7 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
       p.bias = nullptr;
     }
     p.out_mode = 2;
+    if (getenv("FRCNN_GEMM_NOATOM")) p.out_mode = 0;
   }
   dim3 grid(tn, tm, splitK);
   double flops = 2.0 * M * N * (double)K;
