@@ -423,7 +423,6 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   } else {
     for (int chunk = cbeg; chunk < cend; ++chunk) {
       trT = TR_NOW();
-      if (p.dbg & 1) __builtin_amdgcn_s_setprio(3);
       stage_load(chunk, smem);
 #if IG_TRACE
       { unsigned long long t = TR_NOW(); trI += t - trT; trT = t; }
@@ -432,7 +431,6 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
 #endif
       stage_store(chunk, smem + aFloats);
       if (IG_TRACE) { unsigned long long t = TR_NOW(); trS += t - trT; trT = t; }
-      if (p.dbg & 1) __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       if (IG_TRACE) { unsigned long long t = TR_NOW(); trB1 += t - trT; trT = t; }
       compute(smem, smem + aFloats, 0, NKP);
