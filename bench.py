@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--height", type=int, default=FULL_H)
     ap.add_argument("--width", type=int, default=FULL_W)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="vgg_small", choices=["vgg_small", "vgg_large"],
+                    help="vgg_large = SURVEY 8d config 5 (config/imagenet.lua, use --height 600 --width 1000); not the bench line")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
     args = ap.parse_args()
 
@@ -119,8 +121,8 @@ def main():
     import frcnn_amd as F
     L = F._lib.load()
     F._lib.call("frcnn_set_device", local_rank)
-    cfg = dict(F.duplo_cfg)
-    model = F.vgg_small(cfg)
+    cfg = dict(F.duplo_cfg if args.model == "vgg_small" else F.imgnet_cfg)
+    model = (F.vgg_small if args.model == "vgg_small" else F.vgg_large)(cfg)
     weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)  # same seed on every rank
     H, W = args.height, args.width
     it = F.SyntheticBatchIterator(model, H=H, W=W, images_per_batch=1, rank=rank, world_size=world, pool=4)
@@ -194,11 +196,11 @@ def main():
                                      tflops=round((fl[i] / 1e12) / (ms[i] / 1e3), 2) if fl[i] > 0 and ms[i] > 0 else None)
         conv_ms = sum(ms[i] for i in range(4)) / args.steps
         out = dict(
-            metric="images/sec (vgg_small 800x450 fwd+bwd)", value=round(world * args.steps / dt, 3), unit="images/sec",
+            metric="images/sec (%s %dx%d fwd+bwd)" % (args.model, W, H), value=round(world * args.steps / dt, 3), unit="images/sec",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload="vgg_small %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
-                                 "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/duplo.lua values" % (W, H),
+            config=dict(workload=args.model + " %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
+                                 "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/%s.lua values" % (W, H, "duplo" if args.model == "vgg_small" else "imagenet"),
                         images_per_gpu_per_step=1,
                         examples_per_image=[len(b["positive"]) + len(b["negative"]) for b in it.pool], global_batch=world, parallelism="dp%d" % world,
                         conv_gflop_per_image=round(train_flops / 1e9, 2),
