@@ -72,19 +72,39 @@ def _dist():
     return None
 
 
-def allreduce_gradient_and_stats(gradient, tot):
+def allreduce_begin(gradient, lo, hi):
+    """Start the all-reduce of gradient[lo:hi] (a bucket whose values are final) without waiting for it: RCCL
+    runs it on its own stream, ordered after the kernels already queued on the current stream, beside whatever
+    the caller queues next.  Returns a handle for allreduce_gradient_and_stats(pending=...) or None (single
+    process)."""
+    dist = _dist()
+    if dist is None or hi <= lo:
+        return None
+    return (lo, hi, dist.all_reduce(gradient[lo:hi], async_op=True))
+
+
+def allreduce_gradient_and_stats(gradient, tot, pending=()):
     """Data-parallel exchange step: sum the flat gradient (in place) and the 8 fp64
     accumulators {cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss,
     ccls_count} (objective.lua:52-58) over all ranks.  `gradient` is a torch tensor (CUDA: RCCL over
-    xGMI through torch.distributed's "nccl" backend; CPU: gloo, used by the tests).  No-op without an
-    initialised process group."""
+    xGMI through torch.distributed's "nccl" backend; CPU: gloo, used by the tests).  Buckets already started
+    with allreduce_begin() (`pending`) are only waited for; the rest of the vector is reduced here.  No-op
+    without an initialised process group."""
     dist = _dist()
     if dist is None:
         return tot
     import torch
     t = torch.from_numpy(np.asarray(tot, dtype=np.float64)).to(gradient.device)
-    dist.all_reduce(gradient)
-    dist.all_reduce(t)
+    done = sorted((lo, hi) for lo, hi, _ in [p for p in pending if p is not None])
+    works = [w for _, _, w in [p for p in pending if p is not None]]
+    pos = 0
+    for lo, hi in done + [(gradient.numel(), gradient.numel())]:
+        if lo > pos:
+            works.append(dist.all_reduce(gradient[pos:lo], async_op=True))
+        pos = max(pos, hi)
+    works.append(dist.all_reduce(t, async_op=True))
+    for w in works:
+        w.wait()
     return t.cpu().numpy()
 
 
@@ -119,6 +139,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         pnet.training()  # :61-62
         cnet.training()
         batch = batch_iterator.nextTraining()  # :64
+        pending = []
         for x in batch:
             img = to_device(x["img"])  # :66
             outputs = pnet.forward(img)  # :71
@@ -195,6 +216,10 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             if E == 0:
                 for l in range(4):
                     _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, None, 0)
+            if x is batch[-1]:
+                # the classification net's slice of the flat gradient (55 % of it) is final: its all-reduce runs
+                # beside the proposal net's backward pass
+                pending.append(allreduce_begin(gradient, native.pnet_params, gradient.numel()))
             pnet.backward(img, delta_outputs)  # :189
             reg_count += npos  # :194-198
             cls_count += npos + nneg
@@ -207,7 +232,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         a = acc_dev.numpy()
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
-        tot = allreduce_gradient_and_stats(gradient, tot)  # DP: no-op for a single process
+        tot = allreduce_gradient_and_stats(gradient, tot, pending)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
         if not single and cls_count > 0:
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200

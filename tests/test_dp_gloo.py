@@ -55,7 +55,11 @@ def _worker(rank, world, port, out_dir):
     for k in range(rank, 4, world):          # rank r takes images r, r+W, ...
         _local(k, grad, acc, bn)
     g = torch.from_numpy(grad)
-    tot = F.allreduce_gradient_and_stats(g, acc)
+    # the bucket that is final early (the cnet slice in lossAndGradient) starts first, the rest + the 8
+    # accumulators follow in allreduce_gradient_and_stats
+    pending = [F.allreduce_begin(g, n // 3, n - 5)]
+    assert pending[0] is not None
+    tot = F.allreduce_gradient_and_stats(g, acc, pending)
     g /= tot[2]
     np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
     np.save(os.path.join(out_dir, "t%d.npy" % rank), tot)
