@@ -218,19 +218,25 @@ extern "C" int frcnn_debug_ig_trace(void* host_out) { return (int)hipMemcpyFromS
 #else
 #define TR_NOW() 0ull
 #endif
+#ifndef IG_NTW
+#define IG_NTW 2
+#endif
+#ifndef IG_BPC
+#define IG_BPC 5
+#endif
 #define IG_MAXIT 4  // patch plane <= 1024 positions
 
 // MODE 0: one LDS buffer, stage -> barrier -> MFMA -> barrier (latency covered by the other blocks of the CU)
 // MODE 1: As and Bs double-buffered in LDS, one barrier per chunk (1x1: big chunks, 2 blocks per CU)
 template <int CC, int MODE>
-constexpr int igemm_blocks_per_cu(int KS, int BM) { return KS == 1 ? 2 : (BM == 64 && CC != 4 ? 5 : 3); }
+constexpr int igemm_blocks_per_cu(int KS, int BM) { return KS == 1 ? 2 : (BM == 64 && CC != 4 ? IG_BPC : 3); }
 
 template <int KS, int CC, int BM, int MODE, int NIT>
 __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void conv_igemm_kernel(IgemmArgs p) {
   constexpr int KC = CC * KS * KS;   // K rows per chunk
   constexpr int WM = BM / 2;         // 2x2 waves
   constexpr int MT = WM / 32;        // 32x32 tiles per wave along M
-  constexpr int NTW = 2;             // ... along N (wave covers 64 pixels)
+  constexpr int NTW = IG_NTW;        // ... along N (wave covers 32*NTW pixels)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long trR0 = IG_TRACE ? __builtin_amdgcn_s_memrealtime() : 0;
   unsigned long long tr0 = TR_NOW(), trS = 0, trB1 = 0, trC = 0, trB2 = 0, trT, trI = 0, trW = 0;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   int boff[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    int q = wn * 64 + nt * 32 + li;
+    int q = wn * (32 * NTW) + nt * 32 + li;
     q = q < NT ? q : NT - 1;
     int ty = q / p.TW, tx = q - ty * p.TW;
     boff[nt] = h * planeP + ty * PW + tx;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   const long HoWo = (long)p.Ho * p.Wo;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    const int q = wn * 64 + nt * 32 + li;
+    const int q = wn * (32 * NTW) + nt * 32 + li;
     const int ty = q / p.TW, tx = q - ty * p.TW;
     const int oy = ty0 + ty, ox = tx0 + tx;
     const bool pok = q < NT && oy < p.Ho && ox < p.Wo;
@@ -521,6 +527,10 @@ static void choose_tile(int Ho, int Wo, int k, int maxNT, int* TH, int* TW) {
     }
   }
   *TH = bth; *TW = btw;
+  if (const char* e = getenv("FRCNN_IG_TW")) {
+    int tw = atoi(e);
+    if (tw >= 1 && tw <= Wo && tw <= maxNT) { *TW = tw; *TH = std::max(1, std::min(maxNT / tw, Ho)); }
+  }
 }
 
 template <int KS, int CC, int BM, int MODE, int NIT>
@@ -563,14 +573,14 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   // 64-row tiles are 0-14% faster than 128-row tiles).  1x1 keeps 128 rows (large K chunks, LDS double buffer).
   static const int ig_bm128 = getenv("FRCNN_IG_BM128") ? atoi(getenv("FRCNN_IG_BM128")) : 0;
   const int BM = (a.Mpad == 64 || (k > 1 && !ig_bm128)) ? 64 : 128;
-  choose_tile(a.Ho, a.Wo, k, 128, &a.TH, &a.TW);
+  choose_tile(a.Ho, a.Wo, k, 64 * IG_NTW, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
   a.mTiles = a.Mpad / BM;
   const int cc = conv_cc(k);
   a.nChunks = cdiv(Cin, cc);
   long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
   // split K until one wave of blocks fills the resident slots, keeping >= ~200 K rows per split
-  const long slots = BM == 64 && k > 1 ? 1280 : 768;
+  const long slots = BM == 64 && k > 1 ? 256 * IG_BPC : 768;
   const int minChunks = k == 1 ? 2 : std::max(1, cdiv(200, cc * k * k));
   int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), 24), std::max(1, a.nChunks / minChunks));
   if (const char* e = getenv("FRCNN_IG_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
