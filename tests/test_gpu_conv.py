@@ -115,3 +115,36 @@ def test_conv_full_size_linearity(F):
             assert np.array_equal(r[:, 100 + 1 - ky, 200 + 1 - kx], w[:, 5, ky, kx])
     r[:, 99:102, 199:202] = 0
     assert not r.any()
+
+
+FULL_LAYERS = [
+    # vgg_small 800x450 shapes: C, H, W, O, k, pad
+    (128, 225, 400, 128, 3, 1),   # b2c2: one wave of 1440 blocks, no split
+    (256, 57, 100, 384, 3, 1),    # b4c1: split-K slabs + reduce
+    (384, 29, 50, 256, 7, 0),     # a4: 7x7 anchor net, 24 splits
+    (256, 55, 98, 18, 1, 0),      # 1x1 head, M = 18
+]
+
+
+@pytest.mark.parametrize("C_,H,W,O_,k,pad", FULL_LAYERS)
+def test_conv_full_size_adjoint(F, C_, H, W, O_, k, pad):
+    """At BASELINE.json's full layer sizes the three kernels must be each other's adjoints:
+    <conv(x; w), g> == <x, updateGradInput(g; w)> == <w, accGradParameters(x, g)>  (a size-independent property
+    that exercises the split-K slabs, the XCD block order and the tile edges without an oracle run)."""
+    rng = np.random.RandomState(k * 1000 + C_)
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    g = rng.randn(O_, Ho, Wo).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) / np.sqrt(C_ * k * k)).astype(np.float32)
+    dx, dg, dw = _dev(F, x), _dev(F, g), _dev(F, w)
+    out = F.DeviceTensor.empty((O_, Ho, Wo)); gin = F.DeviceTensor.empty((C_, H, W)); gw = F.DeviceTensor.zeros((O_, C_, k, k))
+    s = F.stream_ptr()
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), None, O_, k, pad, F.ptr(out), s)
+    F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, k, pad, F.ptr(gin), 0, s)
+    F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, None, None, F.ptr(dg), O_, k, pad, F.ptr(gw), None, s)
+    a = float(np.dot(out.numpy().astype(np.float64).ravel(), g.astype(np.float64).ravel()))
+    b = float(np.dot(gin.numpy().astype(np.float64).ravel(), x.astype(np.float64).ravel()))
+    c = float(np.dot(gw.numpy().astype(np.float64).ravel(), w.astype(np.float64).ravel()))
+    # each inner product sums ~1e7 terms of size ~1: its own fp32 rounding noise is ~1e-4 of sqrt(#terms)
+    scale = np.sqrt(float(out.numel())) * 4.0
+    assert abs(a - b) <= 1e-4 * scale and abs(a - c) <= 1e-4 * scale, (a, b, c, scale)
