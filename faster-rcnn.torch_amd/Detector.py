@@ -14,7 +14,7 @@ from .Anchors import Anchors
 from .Localizer import Localizer
 from .Rect import Rect
 from .nms import nms
-from .objective import roi_window
+from .objective import roi_window, roi_windows
 from .tensor import DeviceTensor, ptr, stream_ptr, to_device
 
 MAX_MATCHES = 32768
@@ -89,8 +89,8 @@ class Detector(object):
         fm = outputs[-1]
         fmC, fmH, fmW = fm.shape
         R = len(cand)
-        rects = [Rect(*rect_all[i]) for i in cand]
-        wins = np.array([roi_window(r, self.localizer, fmH, fmW) for r in rects], dtype=np.int32)
+        cand_a = np.asarray(cand, dtype=np.int64)
+        wins = roi_windows(rect_all[cand_a], self.localizer, fmH, fmW)   # all candidates at once (objective.lua:5-13)
         dwins = self._buf("wins", wins.shape, np.int32)
         dwins.copy_from_numpy(wins)
         cinput = self._buf("cinput", (R, kh * kw * planes))
@@ -102,8 +102,11 @@ class Detector(object):
         bbox_h = bbox_out.numpy(); cls_h = dcls.numpy(); conf_h = dconf.numpy()
         self.last_cnet = dict(bbox=bbox_h, cls=cls_out.numpy())
         yclass = {}
-        for k, i in enumerate(cand):  # :106-122
-            x = dict(p=float(p_all[i]), r=rects[k], l=int(idx_all[i][0]),
+        # the class test of :115 first (vectorised); the per-candidate tables are only built for survivors
+        keep = np.nonzero((cls_h != bgclass) & (np.exp(conf_h.astype(np.float64)) > 0.2))[0]
+        for k in keep:  # :106-122
+            i = cand[k]
+            x = dict(p=float(p_all[i]), r=Rect(*rect_all[i]), l=int(idx_all[i][0]),
                      a=self.anchors.get(*[int(v) for v in idx_all[i]]))
             x["r2"] = Anchors.anchorToInput(x["r"], bbox_h[k])  # :107
             x["class"] = int(cls_h[k]); x["confidence"] = float(conf_h[k])
