@@ -447,31 +447,39 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   }
 
   const unsigned long long trE = TR_NOW();
-  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel).
+  // One exec mask per pixel column, row pointers advanced by the channel stride, the output mode resolved once.
   const long HoWo = (long)p.Ho * p.Wo;
+  const bool add_bias = p.bias != nullptr && split == 0;
+  const int mrow0 = m0 + wm * WM + 4 * h;
+  auto store_tile = [&](auto mode_c) {
+    constexpr int OM = decltype(mode_c)::value;
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int q = wn * (32 * NTW) + nt * 32 + li;
-    const int ty = q / p.TW, tx = q - ty * p.TW;
-    const int oy = ty0 + ty, ox = tx0 + tx;
-    const bool pok = q < NT && oy < p.Ho && ox < p.Wo;
-    const long pofs = (long)oy * p.Wo + ox;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int q = wn * (32 * NTW) + nt * 32 + li;
+      const int ty = q / p.TW, tx = q - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      if (q < NT && oy < p.Ho && ox < p.Wo) {
+        float* col = p.out + (OM == 3 ? (size_t)split * p.M * HoWo : (size_t)0) + (size_t)oy * p.Wo + ox;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (pok && m < p.M) {
-          float v = acc[mt][nt][r];
-          if (p.bias != nullptr && split == 0) v += p.bias[m];
-          float* dst = p.out + (size_t)m * HoWo + pofs;
-          if (p.out_mode == 0) *dst = v;
-          else if (p.out_mode == 1) *dst += v;
-          else dst[(size_t)split * p.M * HoWo] = v;   // split-K slab [split][M][Ho*Wo]
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) {
+              float v = acc[mt][nt][r];
+              if (add_bias) v += p.bias[m];
+              float* dst = col + (size_t)m * HoWo;
+              if (OM == 1) *dst += v; else *dst = v;
+            }
+          }
         }
       }
     }
-  }
+  };
+  if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
+  else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
+  else store_tile(std::integral_constant<int, 3>{});
 #if IG_TRACE
   if (tid == 0 && blockIdx.x < 4096) {
     unsigned long long* t = g_ig_trace + 16 * blockIdx.x;

@@ -314,7 +314,9 @@ def test_side_stream_equals_serial(F, setup):
         F._lib.call("frcnn_set_option", b"side_stream", 1)
         model["pnet"].drop_masks = None
         model["cnet"].drop_masks = None
-    assert res[1][0] == res[0][0] and res[1][1] == res[0][1]
+    # (the cnet GEMMs accumulate their K splits with fp32 atomics: sums may differ in the last ulp between runs)
+    assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+    assert np.allclose(res[1][1], res[0][1], rtol=1e-6, atol=0)
     a, b = res[1][2], res[0][2]
     assert np.isfinite(a).all() and np.abs(a).max() > 0
     assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
