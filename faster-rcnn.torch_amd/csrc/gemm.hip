@@ -4,8 +4,8 @@
 //   forward : Y[R][O]  = X[R][I]  * W[O][I]^T      A k-contiguous, B k-contiguous
 //   dgrad   : gX[R][I] = gY[R][O] * W[O][I]        A k-contiguous, B n-contiguous
 //   wgrad   : gW[O][I] += gY[R][O]^T * X[R][I]     A m-contiguous, B n-contiguous
-// 64x64 block tile (2x2 waves of one 32x32 MFMA tile), BK = 32, split-K over gridDim.z with
-// fp32 atomics when the tile grid alone cannot fill 256 CUs (R is a few hundred rows at most).
+// 64-row block tiles (2x2 waves of 32x32 MFMA tiles), BK = 32, split-K over gridDim.z into slabs + one
+// reduce pass when the tile grid alone cannot fill 256 CUs (R is a few hundred rows at most).
 #include <cstdlib>
 #include "kernels.h"
 
@@ -21,7 +21,7 @@ struct GemmArgs {
   const float* B; long sBk, sBn;
   float* C; long ldc;
   const float* bias;
-  int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 2 atomic
+  int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 3 split-K slab
 };
 
 // Operand tile loader: ROWS (m or n) x 32 (k) floats -> LDS image T[k][row] (pitch ROWS+1).
@@ -140,26 +140,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if (m < p.M && n < p.N) {
           float v = acc[i][j][r];
           if (p.bias && blockIdx.z == 0) v += p.bias[n];
-          float* dst = p.C + (long)m * p.ldc + n;
-          if (p.out_mode == 0) *dst = v;
-          else if (p.out_mode == 1) *dst += v;
-          else unsafeAtomicAdd(dst, v);
+          if (p.out_mode == 3) {   // split-K slab [split][M][N]
+            p.C[((long)blockIdx.z * p.M + m) * p.N + n] = v;
+          } else {
+            float* dst = p.C + (long)m * p.ldc + n;
+            if (p.out_mode == 0) *dst = v; else *dst += v;
+          }
         }
       }
     }
   }
 }
 
-__global__ void gemm_init_kernel(float* C, long ldc, int M, int N, const float* bias) {
-  long total = (long)M * N;
+// C[m][n] (= | +=) bias[n] + sum_s slab[s][m][n]: fixed summation order -> the result does not depend on which
+// block finished first (fp32 atomics did, in the last ulp)
+__global__ void gemm_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, int N, const float* __restrict__ bias,
+                                   float* __restrict__ C, long ldc, int accumulate) {
+  const long total = (long)M * N;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    int m = (int)(t / N), n = (int)(t % N);
-    C[(long)m * ldc + n] = bias ? bias[n] : 0.f;
+    const int m = (int)(t / N), n = (int)(t - (long)m * N);
+    float v = bias ? bias[n] : 0.f;
+    for (int sI = 0; sI < nSplit; ++sI) v += slab[(size_t)sI * total + t];
+    float* dst = C + (long)m * ldc + n;
+    if (accumulate) *dst += v; else *dst = v;
   }
 }
 
+// library-owned split-K workspaces (one per stream that may run GEMMs concurrently; grown outside the steady state)
+static void* g_gemm_ws[2] = {nullptr, nullptr};
+static size_t g_gemm_ws_bytes[2] = {0, 0};
+static int gemm_workspace(size_t need, float** out, int slot) {
+  if (need > g_gemm_ws_bytes[slot]) {
+    if (g_gemm_ws[slot]) FR_HIP(hipFree(g_gemm_ws[slot]));
+    g_gemm_ws[slot] = nullptr; g_gemm_ws_bytes[slot] = 0;
+    FR_HIP(hipMalloc(&g_gemm_ws[slot], need));
+    g_gemm_ws_bytes[slot] = need;
+  }
+  *out = (float*)g_gemm_ws[slot];
+  return FRCNN_OK;
+}
+
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
-             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s) {
+             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot) {
   if (M <= 0 || N <= 0) return FRCNN_OK;
   GemmArgs p;
   p.A = A; p.sAm = sAm; p.sAk = sAk; p.B = B; p.sBk = sBk; p.sBn = sBn; p.C = C; p.ldc = ldc;
@@ -178,16 +200,11 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   p.kPerSplit = cdiv(cdiv(K, splitK), GBK) * GBK;
   splitK = cdiv(K, p.kPerSplit);
   p.out_mode = out_mode;
-  if (splitK > 1) {
-    if (out_mode == OUT_STORE) {
-      long total = (long)M * N;
-      int grid = (int)std::min<long>(cdivl(total, 256), 1024);
-      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0, s, gemm_init_kernel, dim3(grid), dim3(256), 0, C, ldc, M, N,
-                bias_n);
-      p.bias = nullptr;
-    }
-    p.out_mode = 2;
-    if (getenv("FRCNN_GEMM_NOATOM")) p.out_mode = 0;
+  float* user_C = C;
+  if (splitK > 1) {   // partial products go to slabs with plain stores; one pass folds them (+ bias, + accumulate)
+    float* ws = nullptr;
+    FR_TRY(gemm_workspace((size_t)splitK * M * N * 4, &ws, ws_slot & 1));
+    p.C = ws; p.bias = nullptr; p.out_mode = 3;
   }
   dim3 grid(tn, tm, splitK);
   double flops = 2.0 * M * N * (double)K;
@@ -220,6 +237,12 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   }
 #undef GEMM_CASE
 #undef GEMM_LAUNCH
+  if (splitK > 1) {
+    long total = (long)M * N;
+    int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (splitK + 1), s, gemm_reduce_kernel, dim3(rgrid), dim3(256), 0, (const float*)p.C,
+              splitK, M, N, bias_n, user_C, ldc, out_mode == OUT_ADD ? 1 : 0);
+  }
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

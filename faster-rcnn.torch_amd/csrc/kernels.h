@@ -71,7 +71,7 @@ int rmsprop_step(float* x, const float* g, float* m, long n, float lr, float alp
 // ---------------------------------------------------------------- gemm (gemm.hip)
 // C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
-             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s);
+             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot = 0);
 
 // ---------------------------------------------------------------- roi (roi.hip)
 int roi_pool_forward(const float* fmap, int C, int H, int W, const int* wins, int R, int kh, int kw,

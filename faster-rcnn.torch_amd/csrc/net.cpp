@@ -563,16 +563,16 @@ static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream
       FR_TRY(gather_positions(h.delta.f(), HEAD_OUT, hw1, pos, P, D, nullptr, nullptr, s));
       FR_TRY(gather_positions(a.x.f(), n, hw1, pos, P, HX, w + a.a_off, HY, s));
       // 1x1 conv: gW1[18][n] += D[18][P] * HY[n][P]^T ; gb1 += rowsum(D)
-      FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s));
+      FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s, ws_slot));
       FR_TRY(channel_sum(D, HEAD_OUT, P, grad + c.b_off, s));
       // GH[n][P] = W1^T[n][18] * D[18][P], then PReLU backward (+ bias / slope gradients of the k x k conv)
-      FR_TRY(gemm_f32(w + c.w_off, 1, n, D, P, 1, GH, P, n, P, HEAD_OUT, OUT_STORE, nullptr, s));
+      FR_TRY(gemm_f32(w + c.w_off, 1, n, D, P, 1, GH, P, n, P, HEAD_OUT, OUT_STORE, nullptr, s, ws_slot));
       FR_TRY(act_backward(GH, HX, n, P, w + a.a_off, nullptr, GH, grad + a.b_off, grad + a.a_off, s));
       // k x k conv: gW[n][ckk] += GH[n][P] * COL[P][ckk]
       FR_TRY(im2col_positions(in.pooled.f(), a.Cin, a.H, a.W, a.k, a.Wo, pos, P, COL, s));
-      FR_TRY(gemm_f32(GH, P, 1, COL, ckk, 1, grad + a.w_off, ckk, n, ckk, P, OUT_ADD, nullptr, s));
+      FR_TRY(gemm_f32(GH, P, 1, COL, ckk, 1, grad + a.w_off, ckk, n, ckk, P, OUT_ADD, nullptr, s, ws_slot));
       // DX[P][ckk] = GH^T[P][n] * W[n][ckk], scattered back into the pooled-map gradient
-      FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s));
+      FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s, ws_slot));
       FR_TRY(col2im_positions_add(DX, a.Cin, a.H, a.W, a.k, a.Wo, pos, P, in.gpooled.f(), s));
       continue;
     }
