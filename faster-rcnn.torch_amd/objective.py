@@ -121,15 +121,21 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     D = kh * kw * cnet_input_planes
     ncls = cfg["class_count"] + 1
     scratch = _Scratch()
-    acc_dev = DeviceTensor.zeros((8,), np.float64)
+    import torch
+    acc_t = torch.zeros(8, dtype=torch.float64, device="cuda")       # the accumulators of objective.lua:52-58
+    acc_dev = DeviceTensor(acc_t.data_ptr(), (8,), np.float64, owner=acc_t)
+    acc_pin = torch.zeros(8, dtype=torch.float64).pin_memory()
+    acc_event = torch.cuda.Event()
     L = _lib.load()
 
     def cleanAnchors(examples, outputs):  # objective.lua:32-43
         return [e for e in examples
                 if not (e[0].index[1] > outputs[e[0].layer - 1].shape[1] or e[0].index[2] > outputs[e[0].layer - 1].shape[2])]
 
-    def lossAndGradient(w):
-        import torch
+    def run(w, defer):
+        """Queues the whole pass.  Returns finish() -> (loss, gradient); with defer=True (single process) the
+        accumulators travel to pinned host memory asynchronously and finish() only waits for that copy, so the
+        caller may queue more work (the optimiser step) before it looks at the loss."""
         if w is not weights:  # :46-48
             weights.copy_(w)
         s = stream_ptr()
@@ -230,7 +236,18 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         single = _dist() is None
         if single and cls_count > 0:  # the divisor is host-known: queue the scaling before the blocking read-back
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
-        a = acc_dev.numpy()
+        counts = (cls_count, reg_count, creg_count, ccls_count)
+        if single and defer:
+            acc_pin.copy_(acc_t, non_blocking=True)
+            acc_event.record()
+            return lambda: finish(None, counts, pending, single)
+        return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
+
+    def finish(a, counts, pending, single):
+        if a is None:
+            acc_event.synchronize()
+            a = acc_pin.numpy().copy()
+        cls_count, reg_count, creg_count, ccls_count = counts
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
         tot = allreduce_gradient_and_stats(gradient, tot, pending)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
@@ -247,6 +264,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         stats["dcls"].append(dcls); stats["dreg"].append(dreg)
         return pcls + preg, gradient  # :216-217
 
+    def lossAndGradient(w):
+        return run(w, False)()
+
+    # private protocol with utilities.rmsprop: begin(w) queues the pass and returns (finish, gradient); the
+    # optimiser queues its update and only then calls finish() for the loss (no device idle during the read-back)
+    lossAndGradient.begin = lambda w: (run(w, True), gradient)
     return lossAndGradient
 
 

@@ -39,9 +39,15 @@ def rmsprop(opfunc, x, state):
     Returns x, [f(x)] like the Lua function (main.lua:133)."""
     import torch
     lr = state.get("learningRate", 1e-2); alpha = state.get("alpha", 0.99); eps = state.get("epsilon", 1e-8)
-    fx, dfdx = opfunc(x)
     if "m" not in state:
         state["m"] = torch.zeros_like(x)
+    begin = getattr(opfunc, "begin", None)
+    if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued
+        finish, dfdx = begin(x)
+        _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())
+        fx, _ = finish()
+        return x, [fx]
+    fx, dfdx = opfunc(x)
     _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())
     return x, [fx]
 
