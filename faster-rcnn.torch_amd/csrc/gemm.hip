@@ -14,7 +14,9 @@ namespace frcnn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GB 64
+#ifndef GBK
 #define GBK 32
+#endif
 
 struct GemmArgs {
   const float* A; long sAm, sAk;
@@ -24,23 +26,23 @@ struct GemmArgs {
   int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 3 split-K slab
 };
 
-// Operand tile loader: ROWS (m or n) x 32 (k) floats -> LDS image T[k][row] (pitch ROWS+1).
+// Operand tile loader: ROWS (m or n) x GBK (k) floats -> LDS image T[k][row] (pitch ROWS+1).
 // KC: the operand is contiguous along k (else along the row index).  VEC: 16-byte loads are legal
 // (strides multiple of 4 floats, base 16-byte aligned).  All loads of the tile are issued first with
 // clamped indices, zero fill by select, then the LDS writes: one latency exposure per k-block.
 template <int ROWS, bool KC, bool VEC>
 struct TileLoader {
-  static constexpr int NV = ROWS / 32;       // float4 per thread
-  static constexpr int NS = ROWS / 8;        // scalars per thread
+  static constexpr int NV = ROWS * GBK / 1024;   // float4 per thread
+  static constexpr int NS = ROWS * GBK / 256;    // scalars per thread
   static constexpr int PITCH = ROWS + 1;
   float4 v4[NV];
   float v1[VEC ? 1 : NS];
   __device__ __forceinline__ static void coord_v(int tid, int it, int& r, int& k) {
-    if (KC) { k = (tid & 7) * 4; r = (tid >> 3) + 32 * it; }
+    if (KC) { k = (tid % (GBK / 4)) * 4; r = tid / (GBK / 4) + (1024 / GBK) * it; }
     else    { r = (tid % (ROWS / 4)) * 4; k = tid / (ROWS / 4) + (1024 / ROWS) * it; }
   }
   __device__ __forceinline__ static void coord_s(int tid, int it, int& r, int& k) {
-    if (KC) { k = tid & 31; r = (tid >> 5) + 8 * it; }
+    if (KC) { k = tid % GBK; r = tid / GBK + (256 / GBK) * it; }
     else    { r = tid % ROWS; k = tid / ROWS + (256 / ROWS) * it; }
   }
   __device__ __forceinline__ void load(const float* __restrict__ P, long sRow, long sK, int row0, int nRows, int k0,
