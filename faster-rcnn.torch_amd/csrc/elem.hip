@@ -153,8 +153,9 @@ int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope,
 // gx[c][y][x] = (argmax of window == this position ? gpool : 0) * scale[c] * prelu'(x)
 // One block per (channel, slab of rows): the bias-gradient and slope-gradient partial sums are
 // reduced in the block and leave through one atomic each.
+#define ACT_BWD_THREADS 1024
 template <bool POOLED, bool VEC>
-__global__ void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
+__global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
                                     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
                                     const float* slope, const float* scale, float* __restrict__ gx,
                                     float* gbias, float* gslope, int chunks) {
@@ -169,24 +170,33 @@ __global__ void act_backward_kernel(const float* __restrict__ gin, const unsigne
   const bool has_slope = slope != nullptr;
   float sb = 0.f, sa = 0.f;
   if (VEC) {
-    // 4 consecutive elements of one row per thread: 16-byte loads/stores (W % 4 == 0, Wo even)
-    for (long i = beg + 4L * threadIdx.x; i < end; i += 4L * blockDim.x) {
-      float g[4];
+    // 4 consecutive elements of one row per thread and load: 16-byte loads/stores (W % 4 == 0, Wo even).
+    // Two such groups are in flight per thread (all loads issued before the first use) and the indices are
+    // 32-bit (a channel plane has < 2^31 elements): the kernel is a pure HBM stream and was latency-bound.
+    const float* xc = x + (size_t)c * hw;
+    const float* gc = POOLED ? gin + (size_t)c * Ho * Wo : gin + (size_t)c * hw;
+    const unsigned char* ic = POOLED ? idx + (size_t)c * Ho * Wo : nullptr;
+    float* oc = gx + (size_t)c * hw;
+    const unsigned ibeg = (unsigned)beg, iend = (unsigned)end, uW = (unsigned)W, stride = 4u * blockDim.x;
+    auto fetch = [&](unsigned i, bool ok, float* g, float4& xv4) {
+      if (!ok) { g[0] = g[1] = g[2] = g[3] = 0.f; xv4 = make_float4(1.f, 1.f, 1.f, 1.f); return; }
       if (POOLED) {
-        const int y = (int)(i / W), xx = (int)(i - (long)y * W);
-        const long po = ((long)c * Ho + (y >> 1)) * Wo + (xx >> 1);
-        const float2 gp = *reinterpret_cast<const float2*>(gin + po);
-        const unsigned short ib = *reinterpret_cast<const unsigned short*>(idx + po);
+        const unsigned y = i / uW, xx = i - y * uW;
+        const unsigned po = (y >> 1) * (unsigned)Wo + (xx >> 1);
+        const float2 gp = *reinterpret_cast<const float2*>(gc + po);
+        const unsigned short ib = *reinterpret_cast<const unsigned short*>(ic + po);
         const unsigned char code = (unsigned char)((y & 1) * 2);
         g[0] = ((ib & 0xff) == code) ? gp.x : 0.f;
         g[1] = ((ib & 0xff) == code + 1) ? gp.x : 0.f;
         g[2] = ((ib >> 8) == code) ? gp.y : 0.f;
         g[3] = ((ib >> 8) == code + 1) ? gp.y : 0.f;
       } else {
-        const float4 gv = *reinterpret_cast<const float4*>(gin + (size_t)c * hw + i);
+        const float4 gv = *reinterpret_cast<const float4*>(gc + i);
         g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
       }
-      const float4 xv4 = *reinterpret_cast<const float4*>(x + (size_t)c * hw + i);
+      xv4 = *reinterpret_cast<const float4*>(xc + i);
+    };
+    auto finish = [&](unsigned i, const float* g, const float4& xv4) {
       const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
       float r[4];
 #pragma unroll
@@ -197,7 +207,17 @@ __global__ void act_backward_kernel(const float* __restrict__ gin, const unsigne
         if (has_slope && !(xv[j] > 0.f)) { r[j] = a * gj; sa += xv[j] * gj; }
         sb += r[j];
       }
-      *reinterpret_cast<float4*>(gx + (size_t)c * hw + i) = make_float4(r[0], r[1], r[2], r[3]);
+      *reinterpret_cast<float4*>(oc + i) = make_float4(r[0], r[1], r[2], r[3]);
+    };
+    for (unsigned i = ibeg + 4u * threadIdx.x; i < iend; i += 2u * stride) {
+      const unsigned i2 = i + stride;
+      const bool ok2 = i2 < iend;
+      float g0[4], g1[4];
+      float4 x0, x1;
+      fetch(i, true, g0, x0);
+      fetch(i2, ok2, g1, x1);
+      finish(i, g0, x0);
+      if (ok2) finish(i2, g1, x1);
     }
   } else {
     for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
@@ -228,9 +248,12 @@ __global__ void act_backward_kernel(const float* __restrict__ gin, const unsigne
   }
 }
 
+// Blocks of 1024 threads, ~512-768 of them: every block ends with ONE atomic on the single slope-gradient
+// address, and 2048 of those serialise for ~15 us in the memory-side atomic unit (measured: a 26 MB and a
+// 138 MB launch both took 35 us; without the atomic 12-21 us).
 static int act_bwd_chunks(int C, long hw) {
-  long want = cdivl(2048, C);
-  long maxc = cdivl(hw, 1024);
+  long want = cdivl(512, C);
+  long maxc = cdivl(hw, 4096);
   return (int)std::max<long>(1, std::min<long>(want, maxc));
 }
 
@@ -243,10 +266,10 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                    ((uintptr_t)idx % 2 == 0);
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, true>), dim3(C * chunks),
-              dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, false>), dim3(C * chunks),
-              dim3(256), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -257,11 +280,11 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
   const bool vec = (hw % 4 == 0) && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) % 16 == 0);
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, true>), dim3(C * chunks),
-              dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
+              dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
               gbias, gslope, chunks);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, false>), dim3(C * chunks),
-              dim3(256), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
+              dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
               gbias, gslope, chunks);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
