@@ -79,6 +79,7 @@ _SIGS = {
     "frcnn_pnet_set_sparse_deltas": ([vp, C.c_int, vp, C.c_int], C.c_int),
     "frcnn_pnet_zero_deltas": ([vp, vp], C.c_int),
     "frcnn_pnet_backward_heads_begin": ([vp, vp, vp, vp], C.c_int),
+    "frcnn_pnet_backward_heads_join": ([vp, vp, C.POINTER(C.c_int)], C.c_int),
     "frcnn_pnet_backward": ([vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_forward": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_backward": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),

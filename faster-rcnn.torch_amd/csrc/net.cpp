@@ -101,6 +101,7 @@ struct frcnn_model {
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   bool heads_begun = false;        // anchor-net backward already running on the side stream
+  bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
@@ -425,7 +426,7 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
   hipStream_t s = S(stream);
   if (H != m->H || W != m->W) FR_TRY(ensure_shapes(m, H, W));
   m->training = training;
-  m->heads_begun = false;
+  m->heads_begun = false; m->heads_joined = false;
   const bool use_side = side_enabled();
   // SpatialDropout scales
   for (size_t b = 0; b < m->blocks.size(); ++b) {
@@ -610,15 +611,30 @@ int frcnn_pnet_backward_heads_begin(frcnn_model* m, const float* w, float* grad,
   return FRCNN_OK;
 }
 
+int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
+  hipStream_t s = S(stream);
+  if (joined) *joined = 0;
+  if (!m->heads_begun) return FRCNN_OK;   // nothing was started: frcnn_pnet_backward computes the anchor nets' part
+  if (!m->heads_joined) {
+    FR_HIP(hipEventRecord(m->join_ev, m->side));
+    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+    m->heads_joined = true;   // frcnn_pnet_backward will not wait again
+  }
+  if (joined) *joined = 1;
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* stream) {
   hipStream_t s = S(stream);
   FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
                                     "(nn.SpatialDropout: backprop only defined while training)");
   const int nb = (int)m->blocks.size();
   if (m->heads_begun) {   // started by frcnn_pnet_backward_heads_begin: wait for the side stream
-    FR_HIP(hipEventRecord(m->join_ev, m->side));
-    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
-    m->heads_begun = false; m->side_busy = false;
+    if (!m->heads_joined) {
+      FR_HIP(hipEventRecord(m->join_ev, m->side));
+      FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+    }
+    m->heads_begun = false; m->heads_joined = false; m->side_busy = false;
   } else {
     FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
     FR_TRY(backward_heads(m, w, grad, s, 0));

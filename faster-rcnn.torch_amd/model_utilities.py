@@ -172,6 +172,19 @@ class ProposalNet(object):
         nat = self.native
         _lib.call("frcnn_pnet_backward_heads_begin", nat.h, ptr(nat.weights), ptr(nat.gradient), stream_ptr())
 
+    def backward_heads_join(self):
+        """The caller's stream waits for backward_heads_begin()'s work.  True: the anchor nets' gradient slice is
+        final in stream order; False: nothing had been started (backward() will compute it)."""
+        joined = C.c_int(0)
+        _lib.call("frcnn_pnet_backward_heads_join", self.native.h, stream_ptr(), C.byref(joined))
+        return bool(joined.value)
+
+    def heads_param_range(self):
+        """[lo, hi) of the anchor nets' parameters in the flat vector (they follow the backbone convolutions)."""
+        d = self.native.desc
+        nconv = sum(int(d.conv_steps[b]) for b in range(d.nblocks))
+        return int(self.native.param_table[3 * nconv][0]), int(self.native.pnet_params)
+
     def parameters(self):
         return _param_views(self.native, 0, self.native.pnet_params)
 

@@ -222,10 +222,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             if E == 0:
                 for l in range(4):
                     _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, None, 0)
-            if x is batch[-1]:
-                # the classification net's slice of the flat gradient (55 % of it) is final: its all-reduce runs
-                # beside the proposal net's backward pass
+            if x is batch[-1] and _dist() is not None:
+                # the classification net's slice of the flat gradient (55 % of it) is final, and so is the anchor
+                # nets' slice once the side stream's part is joined: their all-reduces run beside the backbone's
+                # backward pass; only the backbone's 3.3 M elements remain for the end
                 pending.append(allreduce_begin(gradient, native.pnet_params, gradient.numel()))
+                if len(batch) == 1 and pnet.backward_heads_join():   # (earlier images of a batch accumulate there too)
+                    lo, hi = pnet.heads_param_range()
+                    pending.append(allreduce_begin(gradient, lo, hi))
             pnet.backward(img, delta_outputs)  # :189
             reg_count += npos  # :194-198
             cls_count += npos + nneg

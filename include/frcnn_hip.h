@@ -227,6 +227,10 @@ int frcnn_pnet_set_sparse_deltas(frcnn_model *, int head, const int *positions, 
  * classification network's forward/backward on `stream`.  frcnn_pnet_backward then joins it.  Without this
  * call frcnn_pnet_backward does everything itself; the result is the same. */
 int frcnn_pnet_backward_heads_begin(frcnn_model *, const float *weights, float *grad, void *stream);
+/* Makes `stream` wait for the anchor-net part started by frcnn_pnet_backward_heads_begin.  *joined_host = 1:
+ * the anchor nets' slice of `grad` is final in stream order (e.g. for an early all-reduce of that slice beside
+ * the remaining backward pass); 0: nothing had been started, frcnn_pnet_backward will compute that part. */
+int frcnn_pnet_backward_heads_join(frcnn_model *, void *stream, int *joined_host);
 /* pnet:backward(img, delta_outputs) (objective.lua:189): accumulates into the flat gradient.
  * The (unused) input gradient of the first convolution is not computed. */
 int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *stream);

@@ -320,3 +320,67 @@ def test_side_stream_equals_serial(F, setup):
     a, b = res[1][2], res[0][2]
     assert np.isfinite(a).all() and np.abs(a).max() > 0
     assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_bucketed_exchange_path_on_one_gpu(F, setup, monkeypatch):
+    """The data-parallel code path of lossAndGradient (early all-reduce buckets for the cnet slice and, after
+    frcnn_pnet_backward_heads_join, the anchor nets' slice; the rest + the 8 accumulators at the end) with an
+    identity 'all-reduce': the result must equal the single-process result, and every element of the gradient
+    must have been exchanged exactly once."""
+    import torch
+    from importlib import import_module
+    obj = import_module(F.create_objective.__module__)
+    s = setup
+    model, cfg = s["model"], s["cfg"]
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rois = F.synthetic_rois(cfg, W, H, 3, 7, 2)
+    pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(13), negatives=8)
+    sizes = F.output_map_sizes(model, H, W)
+    pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
+    batch = [dict(img=F.synthetic_image(H, W, 2), positive=pos, negative=neg)]
+    R = len(pos) + len(neg)
+    rng = np.random.RandomState(9)
+    nat = model["native"]
+    bn0 = nat.bn_running.cpu().numpy().copy()
+    model["pnet"].drop_masks = _masks(rng, model)
+    model["cnet"].drop_masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+
+    class _Work(object):
+        def wait(self):
+            return True
+
+    class _FakeDist(object):
+        def __init__(self):
+            self.ranges = []
+
+        def all_reduce(self, t, async_op=False):
+            if t.dtype == torch.float32:
+                base = s["gradient"].data_ptr()
+                lo = (t.data_ptr() - base) // 4
+                self.ranges.append((lo, lo + t.numel()))
+            return _Work()
+
+    try:
+        stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+        f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+        loss0, grad = f(s["weights"])
+        g0 = grad.cpu().numpy().copy()
+        nat.bn_running.copy_(torch.from_numpy(bn0))
+        fake = _FakeDist()
+        monkeypatch.setattr(obj, "_dist", lambda: fake)
+        stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+        f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+        loss1, grad = f(s["weights"])
+        g1 = grad.cpu().numpy().copy()
+    finally:
+        model["pnet"].drop_masks = None
+        model["cnet"].drop_masks = None
+        nat.bn_running.copy_(torch.from_numpy(bn0))
+    assert abs(loss1 - loss0) <= 1e-6 * abs(loss0)
+    assert np.linalg.norm(g1 - g0) <= 1e-6 * np.linalg.norm(g0)
+    # coverage: the buckets tile [0, n) exactly once; the early ones are the cnet slice and the anchor nets' slice
+    r = sorted(fake.ranges)
+    assert r[0][0] == 0 and r[-1][1] == nat.total_params
+    assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:])), r
+    lo, hi = model["pnet"].heads_param_range()
+    assert (nat.pnet_params, nat.total_params) in fake.ranges and (lo, hi) in fake.ranges and lo == 3321095
