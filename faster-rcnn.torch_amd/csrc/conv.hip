@@ -205,7 +205,6 @@ struct IgemmArgs {
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 3 split-K slab
-  int dbg;                // tuning knobs: bit0 skip epilogue, bit1 skip MFMA, bit2 skip staging, bit3 skip barriers
 };
 
 #ifndef IG_TRACE
@@ -595,8 +594,6 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
-  static const int ig_dbg = getenv("FRCNN_IG_DBG") ? atoi(getenv("FRCNN_IG_DBG")) : 0;
-  a.dbg = ig_dbg;
   bool slab = false;
   if (a.splitK > 1) {
     // partial tiles go to slabs [split][M][Ho*Wo] with plain stores and one reduce pass adds the bias
