@@ -48,3 +48,19 @@ def test_product_path_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "pyoracle" not in txt and "frcnn_oracle" not in txt and "naive_np" not in txt, fn
+
+
+def test_lua_binding_in_sync_with_header():
+    """bindings/frcnn_hip.lua (the LuaJIT ffi binding a maintainer of the reference would `require`) carries a
+    generated ffi.cdef: it must declare exactly the functions of include/frcnn_hip.h."""
+    import re
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_lua_binding.py"), "--check"]) == 0, \
+        "bindings/frcnn_hip.lua is stale: run python tools/gen_lua_binding.py"
+    lua = open(os.path.join(ROOT, "bindings", "frcnn_hip.lua")).read()
+    cdef = lua[lua.index("ffi.cdef[["):lua.index("]]")]
+    declared = set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", cdef))
+    assert declared == set(_header_symbols())
+    used = set(re.findall(r"C\.(frcnn_[a-z0-9_]+)", lua))
+    assert used <= declared, used - declared
