@@ -154,6 +154,156 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// DMA variant (the large cnet GEMMs): both operand tiles go global -> LDS by `global_load_lds_dwordx4`, no
+// VGPR payload, no transposing LDS stores, two LDS stages (the next K block streams in under the MFMAs), one
+// barrier per K block.  The register-staged kernel above measured 33-50 % MFMA-busy (the staging waves starve
+// for issue slots beside the MFMA waves, see conv.hip); this one is used whenever every operand is 16-byte
+// addressable.  Block tile 64 x TN, 2x2 waves, K block 32.
+//   operand contiguous along its row index (A m-contiguous / B n-contiguous): LDS image T[k][row], fragment
+//     reads T[k][row0 + lane] are consecutive words;
+//   operand contiguous along k: LDS image T[row][chunk ^ (row & 7)] of 16-byte chunks (4 consecutive k): a
+//     lane fetches one chunk with ds_read_b128 and feeds 4 MFMAs; the XOR swizzle makes 8 consecutive rows hit
+//     8 different bank quads.  The DMA writes LDS linearly, so the swizzle is applied to the GLOBAL address each
+//     lane reads.  Within a group of 8 k the lower wave half takes k = 0..3 and the upper half k = 4..7 for both
+//     operands (MFMA is indifferent to the order of k as long as A and B agree).
+//   K tail: chunks / k rows at or beyond kend read a 16-byte zero page instead (DMA cannot zero-fill).
+// ------------------------------------------------------------------------------------------------------
+#ifndef GD_BK
+#define GD_BK 32
+#endif
+#ifndef GD_STAGES
+#define GD_STAGES 1
+#endif
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int ROWS, bool KCONT>
+__device__ __forceinline__ void gd_issue(const float* __restrict__ P, long sRow, long sK, int row0, int nRows, int k0,
+                                         int kend, float* lds, int wave_u, int lane) {
+  constexpr int NINST = ROWS * GD_BK / 256;          // wave instructions per tile (1 KiB each)
+#pragma unroll
+  for (int j = 0; j < NINST / 4; ++j) {
+    const int inst = wave_u + 4 * j;                 // instruction index, dealt round-robin to the 4 waves
+    const int slot = inst * 64 + lane;               // 16-byte slot in the linear LDS image
+    const float* src;
+    if (KCONT) {
+      const int r = slot / (GD_BK / 4), cphys = slot % (GD_BK / 4);
+      const int k = k0 + ((cphys ^ (r & 7)) << 2);
+      const int rr = min(row0 + r, nRows - 1);
+      src = k < kend ? P + (long)rr * sRow + k : g_zero16;
+    } else {
+      const int kr = slot / (ROWS / 4), r4 = (slot % (ROWS / 4)) * 4;
+      const int k = k0 + kr;
+      const int rr = min(row0 + r4, nRows - 4);
+      src = k < kend ? P + (long)k * sK + rr : g_zero16;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + inst * 256), 16, 0, 0);
+  }
+}
+
+template <int TM, int TN, bool AK, bool BK_>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
+  constexpr int MT = TM / 64, NT = TN / 64;
+  constexpr int AF = TM * GD_BK, BF = TN * GD_BK;    // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* As = gsm;                      // [GD_STAGES][AF]
+  float* Bs = gsm + GD_STAGES * AF;     // [GD_STAGES][BF]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int kbeg = blockIdx.z * p.kPerSplit;
+  const int kend = min(kbeg + p.kPerSplit, p.K);
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto stage = [&](int k0, int buf) {
+    gd_issue<TM, AK>(p.A, p.sAm, p.sAk, m0, p.M, k0, kend, As + buf * AF, wave, lane);
+    gd_issue<TN, BK_>(p.B, p.sBn, p.sBk, n0, p.N, k0, kend, Bs + buf * BF, wave, lane);
+  };
+  // The compiler does not count an LDS-DMA load as a pending LDS write: without an explicit vmcnt(0) the barrier
+  // would let the MFMAs read a tile that is still in flight.
+#define GD_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+  if (GD_STAGES == 2) stage(kbeg, 0);
+  GD_DMA_WAIT();
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GD_BK) {
+    if (GD_STAGES == 2) {
+      if (k0 + GD_BK < kend) stage(k0 + GD_BK, cur ^ 1);
+    } else {
+      stage(k0, 0);
+      GD_DMA_WAIT();
+      __syncthreads();
+    }
+    const float* A_ = As + cur * AF;
+    const float* B_ = Bs + cur * BF;
+#pragma unroll
+    for (int g = 0; g < GD_BK / 8; ++g) {
+      float a[MT][4], b[NT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int arow = wm * (TM / 2) + mt * 32 + li;
+        if (AK) {
+          const float4 v = *reinterpret_cast<const float4*>(A_ + (arow * (GD_BK / 4) + ((2 * g + h) ^ (arow & 7))) * 4);
+          a[mt][0] = v.x; a[mt][1] = v.y; a[mt][2] = v.z; a[mt][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[mt][j] = A_[(8 * g + 4 * h + j) * TM + arow];
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int brow = wn * (TN / 2) + nt * 32 + li;
+        if (BK_) {
+          const float4 v = *reinterpret_cast<const float4*>(B_ + (brow * (GD_BK / 4) + ((2 * g + h) ^ (brow & 7))) * 4);
+          b[nt][0] = v.x; b[nt][1] = v.y; b[nt][2] = v.z; b[nt][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[nt][j] = B_[(8 * g + 4 * h + j) * TN + brow];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    if (GD_STAGES == 2) GD_DMA_WAIT();
+    __syncthreads();   // next stage landed and every wave is done with `cur`
+    if (GD_STAGES == 2) cur ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (TN / 2) + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][r];
+          if (p.bias && blockIdx.z == 0) v += p.bias[n];
+          if (p.out_mode == 3) {
+            p.C[((long)blockIdx.z * p.M + m) * p.N + n] = v;
+          } else {
+            float* dst = p.C + (long)m * p.ldc + n;
+            if (p.out_mode == 0) *dst = v; else *dst += v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // C[m][n] (= | +=) bias[n] + sum_s slab[s][m][n]: fixed summation order -> the result does not depend on which
 // block finished first (fp32 atomics did, in the last ulp)
 __global__ void gemm_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, int N, const float* __restrict__ bias,
@@ -219,6 +369,37 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
     return sRow == 1 && (sK % 4) == 0 && (nRows % 4) == 0;
   };
   const bool av = vec_ok(A, ak, sAm, sAk, M, K, p.kPerSplit), bv = vec_ok(B, bk, sBn, sBk, N, K, p.kPerSplit);
+  // DMA kernel: every operand 16-byte addressable (k-contiguous: K and the row stride multiples of 4;
+  // row-contiguous: row count and k stride multiples of 4), split boundaries on whole K blocks
+  static const bool dma_on = !(getenv("FRCNN_GEMM_DMA") && atoi(getenv("FRCNN_GEMM_DMA")) == 0);
+  const bool dma_ok = dma_on && av && bv && (p.kPerSplit % GD_BK == 0 || splitK == 1) && K >= 64 &&
+                      (ak ? true : (M % 4 == 0 && M >= 4)) && (bk ? true : (N % 4 == 0 && N >= 4));
+  if (dma_ok) {
+    const size_t lds = (size_t)GD_STAGES * (TMs + TNs) * GD_BK * 4;
+#define GEMM_DMA(TMv, TNv, AKv, BKv)                                                                              \
+  do {                                                                                                            \
+    static bool attr_ = false;                                                                                    \
+    if (!attr_) {                                                                                                 \
+      FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<TMv, TNv, AKv, BKv>),              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                        \
+      attr_ = true;                                                                                               \
+    }                                                                                                             \
+    FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_dma_kernel<TMv, TNv, AKv, BKv>), grid, dim3(256), lds, p);          \
+  } while (0)
+#define GEMM_DMA_T(TMv, TNv)                                                       \
+  do {                                                                             \
+    if (ak && bk) GEMM_DMA(TMv, TNv, true, true);                                  \
+    else if (ak) GEMM_DMA(TMv, TNv, true, false);                                  \
+    else if (bk) GEMM_DMA(TMv, TNv, false, true);                                  \
+    else GEMM_DMA(TMv, TNv, false, false);                                         \
+  } while (0)
+    if (TMs == 128 && TNs == 128) GEMM_DMA_T(128, 128);
+    else if (TMs == 128) GEMM_DMA_T(128, 64);
+    else if (TNs == 128) GEMM_DMA_T(64, 128);
+    else GEMM_DMA_T(64, 64);
+#undef GEMM_DMA_T
+#undef GEMM_DMA
+  } else {
   const int sel = (ak ? 8 : 0) | (bk ? 4 : 0) | (av ? 2 : 0) | (bv ? 1 : 0);
 #define GEMM_LAUNCH(TMv, TNv, AKv, BKv, AVv, BVv) \
   FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_kernel<TMv, TNv, AKv, BKv, AVv, BVv>), grid, dim3(256), 0, p)
@@ -239,6 +420,7 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   }
 #undef GEMM_CASE
 #undef GEMM_LAUNCH
+  }
   if (splitK > 1) {
     long total = (long)M * N;
     int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
