@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
   // branches, flags resolved once per chunk.
   auto stage_load = [&](int chunk, float* buf) {   // buf = As of the target buffer
     // weights: `global_load_lds_dwordx4` (LDS destination = wave-uniform base + lane*16, i.e. the linear
-    // As[KC][BM] image); completion is covered by the vmcnt(0) that __syncthreads() carries.
+    // As[KC][BM] image).  The compiler does NOT treat the DMA as a pending LDS write at a barrier; completion is
+    // covered because the patch loads below are issued AFTER it and vmcnt retires in order: stage_store waits for
+    // them before the barrier, hence for the DMA too.
     const char* srcA = reinterpret_cast<const char*>(p.wp + ((size_t)chunk * KC) * p.Mpad + m0);
     float* dstA = buf + wave_u * RPW * BM;
 #pragma unroll
