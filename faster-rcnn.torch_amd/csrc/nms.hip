@@ -31,24 +31,32 @@ __global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, int ncol
   key[i] = key_mode == 2 ? b[key_col - 1] : (key_mode == 1 ? a : b[3]);
 }
 
-// rank[i] = #{ j : key[j] < key[i]  or (key[j] == key[i] and j < i) }; sorted[n-1-rank] = i
-__global__ void nms_rank_kernel(const float* __restrict__ key, int n, int* __restrict__ sorted) {
+// rank[i] = #{ j : key[j] < key[i]  or (key[j] == key[i] and j < i) }; sorted[n-1-rank] = i.
+// 2-D grid: block (x, y) counts, for its 256 keys i, the keys j of slice y; partial counts meet in an integer
+// atomic (exact, order-independent), then nms_scatter_kernel writes the permutation.
+#define NMS_RANK_SLICE 1024
+__global__ void nms_rank_kernel(const float* __restrict__ key, int n, int* __restrict__ rank) {
   __shared__ float sk[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float ki = i < n ? key[i] : 0.f;
-  int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 256) {
+  const int jbeg = blockIdx.y * NMS_RANK_SLICE, jend = min(jbeg + NMS_RANK_SLICE, n);
+  int r = 0;
+  for (int j0 = jbeg; j0 < jend; j0 += 256) {
     int j = j0 + threadIdx.x;
-    sk[threadIdx.x] = j < n ? key[j] : 0.f;
+    sk[threadIdx.x] = j < jend ? key[j] : 0.f;
     __syncthreads();
-    int lim = min(256, n - j0);
+    const int lim = min(256, jend - j0);
     for (int t = 0; t < lim; ++t) {
-      float kj = sk[t];
-      rank += (kj < ki || (kj == ki && (j0 + t) < i)) ? 1 : 0;
+      const float kj = sk[t];
+      r += (kj < ki || (kj == ki && (j0 + t) < i)) ? 1 : 0;
     }
     __syncthreads();
   }
-  if (i < n) sorted[n - 1 - rank] = i;
+  if (i < n && r) atomicAdd(rank + i, r);
+}
+__global__ void nms_scatter_kernel(const int* __restrict__ rank, int n, int* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sorted[n - 1 - rank[i]] = i;
 }
 
 // mask[a][w] bit b: box at sorted position a suppresses box at sorted position w*64+b (b > a)
@@ -94,52 +102,63 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
   mask[(size_t)rpos * nw + cb] = bits;
 }
 
-__global__ void nms_reduce_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ sorted,
-                                  int n, int nw, long long* __restrict__ pick, int* __restrict__ count) {
+// Greedy scan in sorted order, 64 boxes per step.  Wave 0 resolves the 64 x 64 diagonal block serially in
+// registers (the next step's diagonal words are already in flight); then ALL 1024 threads OR the mask rows of
+// the boxes kept in this step into the `removed` bit set (LDS, ds_or_b64): (kept row, word) pairs are dealt
+// round-robin, so the global loads of one step are independent and coalesced along the words.
+#define NMS_RED_THREADS 1024
+__global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
+                                                                     const int* __restrict__ sorted, int n, int nw,
+                                                                     long long* __restrict__ pick, int* __restrict__ count) {
   extern __shared__ unsigned long long removed[];  // [nw]
-  __shared__ unsigned long long kept_bits;
+  __shared__ int kept_list[64];
+  __shared__ int nkept;
   __shared__ int cnt;
   for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
   if (threadIdx.x == 0) cnt = 0;
+  unsigned long long diag_next = 0ull;
+  if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * nw];
   __syncthreads();
   for (int g = 0; g < nw; ++g) {
     if (threadIdx.x < 64) {  // wave 0 resolves the diagonal block sequentially
       const int row = g * 64 + threadIdx.x;
-      unsigned long long diag = row < n ? mask[(size_t)row * nw + g] : 0ull;
-      unsigned long long word = removed[g];
-      unsigned long long kept = 0ull;
+      const unsigned long long diag = diag_next;
+      const int nrow = row + 64;
+      if (g + 1 < nw) diag_next = nrow < n ? mask[(size_t)nrow * nw + g + 1] : 0ull;
+      // wave-uniform bit sets in scalar registers; one step per KEPT box (first clear bit), not per box
+      const unsigned long long w0 = removed[g];
+      unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
       const int lim = min(64, n - g * 64);
-      for (int t = 0; t < lim; ++t) {
-        unsigned long long dt = __shfl(diag, t, 64);
-        if (!((word >> t) & 1ull)) {
-          kept |= 1ull << t;
-          word |= dt;
-        }
+      if (lim < 64) word |= ~0ull << lim;          // positions past the last box count as removed
+      unsigned long long kept = 0ull;
+      const int dlo = (int)diag, dhi = (int)(diag >> 32);
+      while (~word) {
+        const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)~word) - 1);
+        kept |= 1ull << t;
+        const unsigned long long dt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, t) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane(dlo, t);
+        word |= dt | (1ull << t);
       }
       // emit picks in order
-      int base = cnt;
+      const int base = cnt;
       if ((kept >> threadIdx.x) & 1ull) {
-        int before = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
+        const int before = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
         pick[base + before] = (long long)sorted[row] + 1;  // 1-based like the Lua surface
+        kept_list[before] = row;
       }
       if (threadIdx.x == 0) {
-        kept_bits = kept;
+        nkept = __popcll(kept);
         cnt = base + __popcll(kept);
       }
     }
     __syncthreads();
-    const unsigned long long kept = kept_bits;
-    if (kept) {
-      for (int w = g + 1 + threadIdx.x; w < nw; w += blockDim.x) {
-        unsigned long long acc = removed[w];
-        unsigned long long k = kept;
-        while (k) {
-          int t = __ffsll((long long)k) - 1;
-          k &= k - 1;
-          acc |= mask[(size_t)(g * 64 + t) * nw + w];
-        }
-        removed[w] = acc;
-      }
+    const int nk = nkept, W = nw - (g + 1);
+    const int items = nk * W;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+      const int q = it / W, w = g + 1 + (it - q * W);
+      const unsigned long long v = mask[(size_t)kept_list[q] * nw + w];
+      if (v) atomicOr(&removed[w], v);
     }
     __syncthreads();
   }
@@ -149,7 +168,7 @@ __global__ void nms_reduce_kernel(const unsigned long long* __restrict__ mask, c
 size_t nms_workspace_bytes(int n) {
   size_t nw = (size_t)cdiv(n, 64);
   size_t b = 0;
-  b += (size_t)n * 4 * 3;          // area, key, sorted
+  b += (size_t)n * 4 * 4;          // area, key, sorted, rank
   b = (b + 255) / 256 * 256;
   b += (size_t)n * nw * 8;         // mask
   return b + 256;
@@ -172,15 +191,18 @@ int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode
   float* area = (float*)base;
   float* key = area + n;
   int* sorted = (int*)(key + n);
-  size_t off = ((size_t)n * 12 + 255) / 256 * 256;
+  int* rank = sorted + n;
+  size_t off = ((size_t)n * 16 + 255) / 256 * 256;
   unsigned long long* mask = (unsigned long long*)(base + off);
   double pair_bytes = 20.0 * n;
   FR_LAUNCH(KC_NMS, 0, pair_bytes, s, nms_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, boxes, n, ncols,
             key_mode, key_col, area, key);
-  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, key, n, sorted);
+  FR_HIP(hipMemsetAsync(rank, 0, (size_t)n * 4, s));
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256), cdiv(n, NMS_RANK_SLICE)), dim3(256), 0, key, n, rank);
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (const int*)rank, n, sorted);
   FR_LAUNCH(KC_NMS, 3.5 * n * (double)n, 8.0 * n * nw / 2, s, nms_mask_kernel, dim3(nw, nw), dim3(64), 0,
             boxes, ncols, area, sorted, n, nw, overlap, mask);
-  FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(256), (size_t)nw * 8, mask,
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(NMS_RED_THREADS), (size_t)nw * 8, mask,
             sorted, n, nw, pick, count);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
