@@ -369,10 +369,20 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
     return sRow == 1 && (sK % 4) == 0 && (nRows % 4) == 0;
   };
   const bool av = vec_ok(A, ak, sAm, sAk, M, K, p.kPerSplit), bv = vec_ok(B, bk, sBn, sBk, N, K, p.kPerSplit);
+  // the DMA path moves 16-byte chunks but only needs DWORD-aligned global addresses (the cnet weights sit at odd
+  // offsets of the flat parameter vector: 12 089 683 pnet elements precede them)
+  auto chunk_ok = [](const float* P, bool kc, long sRow, long sK, int nRows, int Kdim, int kPer) {
+    if (((uintptr_t)P & 3) != 0) return false;
+    if (kc) return sK == 1 && (Kdim % 4) == 0 && (kPer % 4) == 0;
+    return sRow == 1 && (nRows % 4) == 0;
+  };
+  static const bool dma_unaligned = !(getenv("FRCNN_GEMM_DMA_UNALIGNED") && atoi(getenv("FRCNN_GEMM_DMA_UNALIGNED")) == 0);
+  const bool ad = dma_unaligned ? chunk_ok(A, ak, sAm, sAk, M, K, p.kPerSplit) : av;
+  const bool bd = dma_unaligned ? chunk_ok(B, bk, sBn, sBk, N, K, p.kPerSplit) : bv;
   // DMA kernel: every operand 16-byte addressable (k-contiguous: K and the row stride multiples of 4;
   // row-contiguous: row count and k stride multiples of 4), split boundaries on whole K blocks
   static const bool dma_on = !(getenv("FRCNN_GEMM_DMA") && atoi(getenv("FRCNN_GEMM_DMA")) == 0);
-  const bool dma_ok = dma_on && av && bv && (p.kPerSplit % GD_BK == 0 || splitK == 1) && K >= 64 &&
+  const bool dma_ok = dma_on && ad && bd && (p.kPerSplit % GD_BK == 0 || splitK == 1) && K >= 64 &&
                       (ak ? true : (M % 4 == 0 && M >= 4)) && (bk ? true : (N % 4 == 0 && N >= 4));
   if (dma_ok) {
     const size_t lds = (size_t)GD_STAGES * (TMs + TNs) * GD_BK * 4;
