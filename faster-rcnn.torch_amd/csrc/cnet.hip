@@ -10,15 +10,20 @@ namespace frcnn {
 #define BN_EPS 1e-5
 #define BN_MOM 0.1
 
-// Block = 64 features x 16 row groups (1024 threads): lanes run along the feature dimension
-// (coalesced), the 16 row groups split the R rows and meet in LDS.  fp64 partial sums.
-#define BN_RG 16
+// Block = BN_CB features x BN_RG row groups (1024 threads): lanes run along the feature dimension, the row
+// groups split the R rows and meet in LDS (fixed order, fp64 partial sums).  16 features per block -> 64 blocks
+// for the 1024-wide layer (64 features per block left 240 of the 256 CUs idle: 18-20 us per launch).
+#define BN_CB 16
+#define BN_RG 64
 __device__ __forceinline__ double bn_reduce(double v, double* sh, int tx, int ty) {
-  sh[ty * 64 + tx] = v;
+  sh[ty * BN_CB + tx] = v;
   __syncthreads();
-  double s = 0.0;
-#pragma unroll
-  for (int g = 0; g < BN_RG; ++g) s += sh[g * 64 + tx];
+  // tree over the row groups, same order for every feature
+  for (int stride = BN_RG / 2; stride > 0; stride >>= 1) {
+    if (ty < stride) sh[ty * BN_CB + tx] += sh[(ty + stride) * BN_CB + tx];
+    __syncthreads();
+  }
+  const double s = sh[tx];
   __syncthreads();
   return s;
 }
@@ -27,9 +32,9 @@ __global__ __launch_bounds__(1024) void bn_forward_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running, int training, float* __restrict__ xhat,
                                                           float* __restrict__ invstd, float* __restrict__ y) {
-  __shared__ double sh[BN_RG * 64];
+  __shared__ double sh[BN_RG * BN_CB];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int j = blockIdx.x * 64 + tx;
+  const int j = blockIdx.x * BN_CB + tx;
   const bool ok = j < n;
   double mean, var;
   if (training) {
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(1024) void bn_forward_kernel(const float* __restric
 int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,
                int training, float* xhat, float* invstd, float* y, hipStream_t s) {
   FR_CHECK(training || running, "bn_forward: evaluate mode needs running statistics");
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_forward_kernel, dim3(cdiv(n, 64)), dim3(64, BN_RG), 0, x, R, n,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_forward_kernel, dim3(cdiv(n, BN_CB)), dim3(BN_CB, BN_RG), 0, x, R, n,
             gamma, beta, running, training, xhat, invstd, y);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(1024) void bn_backward_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            int R, int n, int training, float* __restrict__ gx, float* ggamma,
                                                            float* gbeta) {
-  __shared__ double sh[BN_RG * 64];
+  __shared__ double sh[BN_RG * BN_CB];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int j = blockIdx.x * 64 + tx;
+  const int j = blockIdx.x * BN_CB + tx;
   const bool ok = j < n;
   double sg = 0.0, sgx = 0.0;
   if (ok)
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(1024) void bn_backward_kernel(const float* __restri
 }
 int bn_backward(const float* gy, const float* xhat, const float* invstd, const float* gamma, int R,
                 int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s) {
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, 64)), dim3(64, BN_RG), 0, gy,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, BN_CB)), dim3(BN_CB, BN_RG), 0, gy,
             xhat, invstd, gamma, R, n, training, gx, ggamma, gbeta);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
