@@ -112,22 +112,38 @@ int bn_backward(const float* gy, const float* xhat, const float* invstd, const f
 }
 
 // y = prelu(x) * (mask * inv_keep)   (nn.PReLU then nn.Dropout v2; mask==null -> identity)
+// GEN: the keep mask is drawn here (same counter-based stream as dropout_mask()) and stored for the backward pass
+template <bool GEN>
 __global__ void prelu_dropout_forward_kernel(const float* __restrict__ x, long n, const float* slope,
-                                             const float* __restrict__ mask, float inv_keep,
-                                             float* __restrict__ y) {
+                                             float* __restrict__ mask, float inv_keep, float p,
+                                             unsigned long long seed, float* __restrict__ y) {
   const float a = *slope;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float v = x[i];
     v = v > 0.f ? v : a * v;
-    if (mask) v = v * (mask[i] * inv_keep);
+    if (GEN) {
+      const float mk = frcnn_keep_mask(seed, (unsigned long long)i, p);
+      mask[i] = mk;
+      v = v * (mk * inv_keep);
+    } else if (mask) {
+      v = v * (mask[i] * inv_keep);
+    }
     y[i] = v;
   }
 }
 int prelu_dropout_forward(const float* x, long n, const float* slope, const float* mask, float inv_keep,
                           float* y, hipStream_t s) {
   int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 1024);
-  FR_LAUNCH(KC_ELEMWISE, 0, n * 12.0, s, prelu_dropout_forward_kernel, dim3(grid), dim3(256), 0, x, n, slope,
-            mask, inv_keep, y);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 12.0, s, prelu_dropout_forward_kernel<false>, dim3(grid), dim3(256), 0, x, n, slope,
+            const_cast<float*>(mask), inv_keep, 0.f, 0ull, y);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+int prelu_dropout_forward_gen(const float* x, long n, const float* slope, float* mask_out, float p,
+                              unsigned long long seed, float* y, hipStream_t s) {
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 1024);
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 12.0, s, prelu_dropout_forward_kernel<true>, dim3(grid), dim3(256), 0, x, n, slope,
+            mask_out, 1.0f / (1.0f - p), p, seed, y);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -399,18 +399,23 @@ int col2im_positions_add(const float* col, int C, int H, int W, int k, int Wo, c
 }
 
 // ---------------------------------------------------------------- RNG (throughput runs)
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 __global__ void bernoulli_kernel(float* m, long n, float p, unsigned long long seed) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    unsigned long long r = splitmix64(seed * 0x100000001B3ull + (unsigned long long)i);
-    float u = (float)(r >> 40) * (1.0f / 16777216.0f);
-    m[i] = u < p ? 0.f : 1.f;  // keep with probability 1-p
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m[i] = frcnn_keep_mask(seed, (unsigned long long)i, p);
+}
+__global__ void bernoulli_multi_kernel(DropoutJobs j) {
+  const int k = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.C[k]; i += gridDim.x * blockDim.x)
+    j.ptr[k][i] = frcnn_keep_mask(j.seed[k], (unsigned long long)i, j.p[k]);
+}
+// the SpatialDropout keep vectors of all blocks of a forward pass in ONE launch
+int dropout_channel_masks(const DropoutJobs& j, hipStream_t s) {
+  if (j.n <= 0) return FRCNN_OK;
+  int maxC = 0;
+  for (int k = 0; k < j.n; ++k) maxC = std::max(maxC, j.C[k]);
+  FR_LAUNCH(KC_ELEMWISE, 0, maxC * 4.0 * j.n, s, bernoulli_multi_kernel, dim3(cdiv(maxC, 256), j.n), dim3(256), 0, j);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, hipStream_t s) {
   FR_LAUNCH(KC_ELEMWISE, 0, C * 4.0, s, bernoulli_kernel, dim3(cdiv(C, 256)), dim3(256), 0, scale, (long)C,

@@ -107,9 +107,14 @@ int bn_backward(const float* gy, const float* xhat, const float* invstd, const f
                 int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s);
 int prelu_dropout_forward(const float* x, long n, const float* slope, const float* mask, float inv_keep,
                           float* y, hipStream_t s);
+// same, drawing the keep mask (probability 1-p, counter-based stream `seed`) into mask_out on the fly
+int prelu_dropout_forward_gen(const float* x, long n, const float* slope, float* mask_out, float p,
+                              unsigned long long seed, float* y, hipStream_t s);
 int prelu_dropout_backward(const float* gy, const float* x, long n, const float* slope,
                            const float* mask, float inv_keep, float* gx, float* gslope, hipStream_t s);
 int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s);
+struct DropoutJobs { float* ptr[8]; int C[8]; float p[8]; unsigned long long seed[8]; int n; };
+int dropout_channel_masks(const DropoutJobs& j, hipStream_t s);
 int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s);
 // losses of objective.lua:170-177 + their gradients, fused
 int cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,

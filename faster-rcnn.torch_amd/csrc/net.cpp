@@ -428,7 +428,9 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
   m->training = training;
   m->heads_begun = false; m->heads_joined = false;
   const bool use_side = side_enabled();
-  // SpatialDropout scales
+  // SpatialDropout scales (device-drawn ones: one launch for all blocks)
+  DropoutJobs dj;
+  dj.n = 0;
   for (size_t b = 0; b < m->blocks.size(); ++b) {
     Block& blk = m->blocks[b];
     if (!blk.has_drop) continue;
@@ -438,9 +440,11 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     } else if (drop_masks && drop_masks[b]) {
       FR_HIP(hipMemcpyAsync(blk.scale.p, drop_masks[b], (size_t)C * 4, hipMemcpyDeviceToDevice, s));
     } else {
-      FR_TRY(dropout_channel_mask(blk.scale.f(), C, blk.p_drop, seed * 131 + b, s));
+      dj.ptr[dj.n] = blk.scale.f(); dj.C[dj.n] = C; dj.p[dj.n] = blk.p_drop; dj.seed[dj.n] = seed * 131 + b;
+      ++dj.n;
     }
   }
+  FR_TRY(dropout_channel_masks(dj, s));
   // weights change every optimiser step: refresh the packed copies (one table-driven launch)
   m->head_packs_fresh = false;
   if (training)
@@ -736,15 +740,20 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
     }
     const float* mask = nullptr;
     float inv_keep = 1.f;
+    bool draw = false;
     if (training && L.p_drop > 0.f) {  // nn.Dropout v2: train = mask/(1-p), evaluate = identity [ext]
       inv_keep = 1.0f / (1.0f - L.p_drop);
       if (drop_masks && drop_masks[l])
         FR_HIP(hipMemcpyAsync(L.mask.p, drop_masks[l], (size_t)R * L.n * 4, hipMemcpyDeviceToDevice, s));
       else
-        FR_TRY(dropout_mask(L.mask.f(), (long)R * L.n, L.p_drop, seed * 977 + l + 17, s));
+        draw = true;   // mask drawn inside the activation kernel
       mask = L.mask.f();
     }
-    FR_TRY(prelu_dropout_forward(pre, (long)R * L.n, w + L.a_off, mask, inv_keep, L.post.f(), s));
+    if (draw)
+      FR_TRY(prelu_dropout_forward_gen(pre, (long)R * L.n, w + L.a_off, L.mask.f(), L.p_drop, seed * 977 + l + 17,
+                                       L.post.f(), s));
+    else
+      FR_TRY(prelu_dropout_forward(pre, (long)R * L.n, w + L.a_off, mask, inv_keep, L.post.f(), s));
     cur = L.post.f();
   }
   const int nf = m->cls.empty() ? m->D : m->cls.back().n;
