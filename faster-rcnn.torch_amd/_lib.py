@@ -68,6 +68,7 @@ _SIGS = {
     "frcnn_linear_forward": ([vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp], C.c_int),
     "frcnn_linear_backward": ([vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp], C.c_int),
     "frcnn_rmsprop": ([vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
+    "frcnn_scale_rmsprop": ([vp, vp, C.c_float, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
     "frcnn_model_create": ([C.POINTER(ModelDesc), C.POINTER(vp)], C.c_int),
     "frcnn_model_destroy": ([vp], C.c_int),
     "frcnn_model_param_count": ([vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], C.c_int),

@@ -257,7 +257,12 @@ int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const f
 
 int frcnn_rmsprop(float* x, const float* g, float* m, long long n, float lr, float alpha, float eps,
                   void* stream) {
-  return rmsprop_step(x, g, m, n, lr, alpha, eps, S(stream));
+  return rmsprop_step(x, const_cast<float*>(g), m, n, lr, alpha, eps, 1.f, false, S(stream));
+}
+
+int frcnn_scale_rmsprop(float* x, float* g, float gscale, float* m, long long n, float lr, float alpha, float eps,
+                        void* stream) {
+  return rmsprop_step(x, g, m, n, lr, alpha, eps, gscale, true, S(stream));
 }
 
 int frcnn_cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,

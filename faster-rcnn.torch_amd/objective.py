@@ -238,13 +238,15 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
 
         # ---- statistics: one read-back per call ------------------------------------------
         single = _dist() is None
-        if single and cls_count > 0:  # the divisor is host-known: queue the scaling before the blocking read-back
+        fold = single and defer == "fold" and cls_count > 0   # the optimiser folds gradient:div into its own pass
+        if single and cls_count > 0 and not fold:  # the divisor is host-known: queue the scaling before the read-back
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         counts = (cls_count, reg_count, creg_count, ccls_count)
         if single and defer:
             acc_pin.copy_(acc_t, non_blocking=True)
             acc_event.record()
-            return lambda: finish(None, counts, pending, single)
+            fin = lambda: finish(None, counts, pending, single)
+            return (fin, 1.0 / cls_count) if fold else fin
         return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
 
     def finish(a, counts, pending, single):
@@ -274,6 +276,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     # private protocol with utilities.rmsprop: begin(w) queues the pass and returns (finish, gradient); the
     # optimiser queues its update and only then calls finish() for the loss (no device idle during the read-back)
     lossAndGradient.begin = lambda w: (run(w, True), gradient)
+    # begin_fold(w) -> (finish, gradient, gscale): gradient:div(cls_count) (:200) is left to the caller, who folds it
+    # into the first pass of its update (frcnn_scale_rmsprop); gscale is None when there is nothing to scale
+    def begin_fold(w):
+        r = run(w, "fold")
+        return (r[0], gradient, r[1]) if isinstance(r, tuple) else (r, gradient, None)
+    lossAndGradient.begin_fold = begin_fold
     return lossAndGradient
 
 

@@ -41,10 +41,14 @@ def rmsprop(opfunc, x, state):
     lr = state.get("learningRate", 1e-2); alpha = state.get("alpha", 0.99); eps = state.get("epsilon", 1e-8)
     if "m" not in state:
         state["m"] = torch.zeros_like(x)
-    begin = getattr(opfunc, "begin", None)
-    if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued
-        finish, dfdx = begin(x)
-        _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())
+    begin = getattr(opfunc, "begin_fold", None)
+    if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued,
+        finish, dfdx, gscale = begin(x)   # and gradient:div(n) rides on the update's own pass over the vectors
+        if gscale is None:
+            _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())
+        else:
+            _lib.call("frcnn_scale_rmsprop", ptr(x), ptr(dfdx), gscale, ptr(state["m"]), x.numel(), lr, alpha, eps,
+                      stream_ptr())
         fx, _ = finish()
         return x, [fx]
     fx, dfdx = opfunc(x)

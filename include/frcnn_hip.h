@@ -172,6 +172,11 @@ int frcnn_linear_backward(const float *x, const float *gy, int R, int I, const f
 /* ---- optim.rmsprop (main.lua:122,133): m = a*m + (1-a)*g^2 ; x -= lr*g/(sqrt(m)+eps) -- */
 int frcnn_rmsprop(float *x, const float *g, float *m, long long n, float lr, float alpha,
                   float eps, void *stream);
+/* frcnn_scale(g, n, gscale) followed by frcnn_rmsprop in ONE pass over the flat vectors: gradient:div(n)
+ * (objective.lua:200) folded into the optimiser step that follows it in main.lua:133.  g holds the scaled
+ * gradient afterwards, exactly as after the two separate calls. */
+int frcnn_scale_rmsprop(float *x, float *g, float gscale, float *m, long long n, float lr, float alpha,
+                        float eps, void *stream);
 
 /* ---- model runtime: models/model_utilities.lua:3-136 --------------------------------- */
 typedef struct {

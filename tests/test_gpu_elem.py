@@ -125,3 +125,19 @@ def test_rmsprop_and_scale(F, O):
     assert_close(tm.cpu().numpy(), m, 1e-6, "rmsprop m")
     F._lib.call("frcnn_scale", F.ptr(tg), n, 1.0 / 37.0, F.stream_ptr())
     assert_close(tg.cpu().numpy(), g * np.float32(1.0 / 37.0), 1e-6, "scale")
+
+
+def test_scale_rmsprop_equals_the_two_calls(F):
+    """frcnn_scale_rmsprop == frcnn_scale followed by frcnn_rmsprop, bit for bit (x, m and the scaled g)."""
+    import torch
+    rng = np.random.RandomState(10)
+    n = 100003
+    x = rng.randn(n).astype(np.float32); g = rng.randn(n).astype(np.float32); m = rng.rand(n).astype(np.float32)
+    a = [torch.from_numpy(v.copy()).cuda() for v in (x, g, m)]
+    b = [torch.from_numpy(v.copy()).cuda() for v in (x, g, m)]
+    s = F.stream_ptr()
+    F._lib.call("frcnn_scale", F.ptr(a[1]), n, 1.0 / 41.0, s)
+    F._lib.call("frcnn_rmsprop", F.ptr(a[0]), F.ptr(a[1]), F.ptr(a[2]), n, 1e-4, 0.9, 1e-8, s)
+    F._lib.call("frcnn_scale_rmsprop", F.ptr(b[0]), F.ptr(b[1]), 1.0 / 41.0, F.ptr(b[2]), n, 1e-4, 0.9, 1e-8, s)
+    for u, v, what in zip(a, b, ("x", "g", "m")):
+        assert torch.equal(u, v), what
