@@ -83,6 +83,21 @@ def allreduce_begin(gradient, lo, hi):
     return (lo, hi, dist.all_reduce(gradient[lo:hi], async_op=True))
 
 
+def allreduce_begin_rest(gradient, pending):
+    """Start the all-reduce of every part of `gradient` that no handle in `pending` covers yet (the whole vector
+    is final).  Returns the extended list; lets the exchange run while the host still reads the accumulators."""
+    if _dist() is None:
+        return list(pending)
+    done = sorted((p[0], p[1]) for p in pending if p is not None)
+    out = [p for p in pending if p is not None]
+    pos = 0
+    for lo, hi in done + [(gradient.numel(), gradient.numel())]:
+        if lo > pos:
+            out.append(allreduce_begin(gradient, pos, lo))
+        pos = max(pos, hi)
+    return out
+
+
 def allreduce_gradient_and_stats(gradient, tot, pending=()):
     """Data-parallel exchange step: sum the flat gradient (in place) and the 8 fp64
     accumulators {cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss,
@@ -242,6 +257,8 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         if single and cls_count > 0 and not fold:  # the divisor is host-known: queue the scaling before the read-back
             _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         counts = (cls_count, reg_count, creg_count, ccls_count)
+        if not single:   # the rest of the gradient is final too: its exchange starts before the host read-back below
+            pending[:] = allreduce_begin_rest(gradient, pending)
         if single and defer:
             acc_pin.copy_(acc_t, non_blocking=True)
             acc_event.record()
