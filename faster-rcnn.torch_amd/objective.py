@@ -264,9 +264,15 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             acc_event.record()
             fin = lambda: finish(None, counts, pending, single)
             return (fin, 1.0 / cls_count) if fold else fin
+        if defer == "fold" and not single:   # the all-reduced count is known after finish(): scaling left to the caller
+            res = finish(acc_dev.numpy(), counts, pending, single, fold=True)
+            gs = dp_gscale[0]
+            return ((lambda: res), gs) if gs is not None else (lambda: res)
         return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
 
-    def finish(a, counts, pending, single):
+    dp_gscale = [None]
+
+    def finish(a, counts, pending, single, fold=False):
         if a is None:
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
@@ -274,8 +280,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
         tot = allreduce_gradient_and_stats(gradient, tot, pending)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
+        dp_gscale[0] = None
         if not single and cls_count > 0:
-            _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
+            if fold:
+                dp_gscale[0] = 1.0 / cls_count
+            else:
+                _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), 1.0 / cls_count, stream_ptr())  # :200
         with np.errstate(divide="ignore", invalid="ignore"):
             pcls = float(np.float64(cls_loss) / cls_count)  # :202-205
             preg = float(np.float64(reg_loss) / reg_count)

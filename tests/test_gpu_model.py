@@ -372,6 +372,24 @@ def test_bucketed_exchange_path_on_one_gpu(F, setup, monkeypatch):
         f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
         loss1, grad = f(s["weights"])
         g1 = grad.cpu().numpy().copy()
+        first_ranges = list(fake.ranges)
+        # one optimiser step through utilities.rmsprop (begin_fold protocol: gradient:div folded into the update) in
+        # both modes: identical weights afterwards
+        w_start = s["weights"].clone()
+        upd = {}
+        for mode, dist_fn in (("dp", lambda: fake), ("single", lambda: None)):
+            monkeypatch.setattr(obj, "_dist", dist_fn)
+            stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+            f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+            F.rmsprop(f, s["weights"], dict(learningRate=1e-4, alpha=0.9))
+            upd[mode] = s["weights"].cpu().numpy().copy()
+            s["weights"].copy_(w_start)
+            nat.bn_running.copy_(torch.from_numpy(bn0))
+        assert np.abs(upd["dp"] - w_start.cpu().numpy()).max() > 0
+        # (the first RMSprop step is lr * g / (sqrt(0.1 g^2) + eps) ~ lr * sign(g) / sqrt(0.1): elements whose gradient is
+        # ~0 may flip with the last-ulp differences between the two runs, so compare against the size of the update)
+        w0 = w_start.cpu().numpy()
+        assert np.linalg.norm(upd["dp"] - upd["single"]) <= 1e-3 * np.linalg.norm(upd["single"] - w0)
     finally:
         model["pnet"].drop_masks = None
         model["cnet"].drop_masks = None
@@ -379,8 +397,8 @@ def test_bucketed_exchange_path_on_one_gpu(F, setup, monkeypatch):
     assert abs(loss1 - loss0) <= 1e-6 * abs(loss0)
     assert np.linalg.norm(g1 - g0) <= 1e-6 * np.linalg.norm(g0)
     # coverage: the buckets tile [0, n) exactly once; the early ones are the cnet slice and the anchor nets' slice
-    r = sorted(fake.ranges)
+    r = sorted(first_ranges)
     assert r[0][0] == 0 and r[-1][1] == nat.total_params
     assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:])), r
     lo, hi = model["pnet"].heads_param_range()
-    assert (nat.pnet_params, nat.total_params) in fake.ranges and (lo, hi) in fake.ranges and lo == 3321095
+    assert (nat.pnet_params, nat.total_params) in first_ranges and (lo, hi) in first_ranges and lo == 3321095
