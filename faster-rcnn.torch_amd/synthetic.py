@@ -111,7 +111,18 @@ class SyntheticBatchIterator(object):
             self.pool.append(dict(img=img, positive=pos, negative=neg, rois=rois))
 
     def nextTraining(self, count=None):
+        """images_per_batch images (benchmarks: 1); with images_per_batch=None the reference's
+        rule (BatchIterator.lua:166-268): keep adding images until they carry `count` (default cfg.batch_size)
+        examples in total."""
         batch = []
+        if self.images_per_batch is None:
+            count = count or self.cfg["batch_size"]
+            while count > 0:
+                x = self.pool[self.i % len(self.pool)]
+                self.i += 1
+                batch.append(x)
+                count -= max(1, len(x["positive"]) + len(x["negative"]))   # (an empty image still advances the loop)
+            return batch
         for _ in range(self.images_per_batch):
             batch.append(self.pool[self.i % len(self.pool)])
             self.i += 1

@@ -89,3 +89,20 @@ def test_nms_key_dispatch(F):
     import numpy as np
     assert _key(None) == (0, 0) and _key(np.zeros(3)) == (0, 0) and _key("area") == (1, 0) and _key(5) == (2, 5)
     assert _key("score") == (0, 0)   # any other string also falls through to y2 (nms.lua:41-43)
+
+
+def test_batch_rule_of_the_reference(F):
+    """BatchIterator.lua:166-268: nextTraining(count) keeps adding images until `count` examples are on board
+    (default cfg.batch_size = 256); the benchmark configuration pins one image per call instead."""
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)
+    it = F.SyntheticBatchIterator(model, H=200, W=320, images_per_batch=None, pool=3, device_images=False)
+    per_image = [len(x["positive"]) + len(x["negative"]) for x in it.pool]
+    assert all(n > 0 for n in per_image)
+    batch = it.nextTraining()
+    total = sum(len(x["positive"]) + len(x["negative"]) for x in batch)
+    assert total >= cfg["batch_size"]
+    assert total - (len(batch[-1]["positive"]) + len(batch[-1]["negative"])) < cfg["batch_size"]   # no image too many
+    assert len(it.nextTraining(count=1)) == 1
+    one = F.SyntheticBatchIterator(model, H=200, W=320, images_per_batch=1, pool=2, device_images=False)
+    assert len(one.nextTraining()) == 1
