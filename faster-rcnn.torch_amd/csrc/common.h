@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -63,8 +65,14 @@ bool prof_enabled(int klass);
 void prof_before(int klass, hipStream_t s);
 void prof_after(int klass, double flops, double bytes, hipStream_t s);
 
+#ifdef FR_SKIPTEST   /* tools only: FRCNN_EXP_SKIP=<substring> drops matching launches (critical-path sensitivity) */
+#define FR_SKIP_(kernel) (getenv("FRCNN_EXP_SKIP") && strstr(#kernel, getenv("FRCNN_EXP_SKIP")))
+#else
+#define FR_SKIP_(kernel) false
+#endif
 #define FR_LAUNCH(klass, flops, bytes, stream, kernel, grid, block, shmem, ...)        \
   do {                                                                                 \
+    if (FR_SKIP_(kernel)) break;                                                       \
     if (frcnn::prof_enabled(klass)) frcnn::prof_before((klass), (stream));                  \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
     if (frcnn::prof_enabled(klass)) frcnn::prof_after((klass), (flops), (bytes), (stream)); \
