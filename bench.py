@@ -113,10 +113,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # (debug only: FRCNN_DIST_BACKEND=gloo lets several ranks share one GPU to exercise this branch on a 1-GPU box)
+    backend = os.environ.get("FRCNN_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group(backend)  # "nccl" = RCCL over xGMI
 
     import frcnn_amd as F
     L = F._lib.load()
