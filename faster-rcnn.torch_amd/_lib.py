@@ -35,6 +35,7 @@ vp = C.c_void_p
 _SIGS = {
     "frcnn_version": ([], C.c_int),
     "frcnn_set_option": ([C.c_char_p, C.c_int], C.c_int),
+    "frcnn_get_option": ([C.c_char_p, C.POINTER(C.c_int)], C.c_int),
     "frcnn_last_error": ([], C.c_char_p),
     "frcnn_device_count": ([C.POINTER(C.c_int)], C.c_int),
     "frcnn_set_device": ([C.c_int], C.c_int),

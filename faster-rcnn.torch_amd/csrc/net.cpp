@@ -382,6 +382,13 @@ static bool side_enabled() {
   return g_side_stream != 0;
 }
 
+int frcnn_get_option(const char* name, int* value) {
+  FR_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
+  if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
+  FR_CHECK(false, "get_option: unknown option '%s'", name);
+  return FRCNN_OK;
+}
+
 int frcnn_set_option(const char* name, int value) {
   FR_CHECK(name != nullptr, "set_option: null name");
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }

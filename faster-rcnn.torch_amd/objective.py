@@ -242,7 +242,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 # nets' slice once the side stream's part is joined: their all-reduces run beside the backbone's
                 # backward pass; only the backbone's 3.3 M elements remain for the end
                 pending.append(allreduce_begin(gradient, native.pnet_params, gradient.numel()))
-                if len(batch) == 1 and pnet.backward_heads_join():   # (earlier images of a batch accumulate there too)
+                # The decision must not depend on this rank's data (every rank issues the same collectives): with the
+                # side stream on and one image per batch the slice is final here on every rank -- either the
+                # anchor nets' backward was started early and is joined now, or the image had no example and
+                # contributes nothing to that slice.
+                side = C.c_int(0)
+                _lib.call("frcnn_get_option", b"side_stream", C.byref(side))
+                if len(batch) == 1 and side.value:
+                    pnet.backward_heads_join()
                     lo, hi = pnet.heads_param_range()
                     pending.append(allreduce_begin(gradient, lo, hi))
             pnet.backward(img, delta_outputs)  # :189

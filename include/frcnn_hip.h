@@ -45,6 +45,7 @@ int frcnn_device_name(char *buf_host, int len);
  * pass (anchor nets, weight gradients) are issued on a library-owned second HIP stream and joined before the
  * entry point's results are used on the caller's stream.  0 = strictly serial on the caller's stream. */
 int frcnn_set_option(const char *name, int value);
+int frcnn_get_option(const char *name, int *value_host);
 
 /* ---- device buffers (torch.CudaTensor storage; main.lua:86-89, objective.lua:66,147-149) */
 int frcnn_malloc(void **ptr_out_host, size_t bytes);

@@ -67,12 +67,14 @@ def _step(F, model, weights, gradient, batch, pm, cms):
     return [stats[k][-1] for k in ("pcls", "preg", "dcls", "dreg")]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, empty_rank1=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     F, model, weights, gradient, anchors, images, pm, cms = _setup()
+    if empty_rank1:   # rank 1's image carries no example: its collectives must still match rank 0's
+        images[1] = dict(img=images[1]["img"], positive=[], negative=[])
     st = _step(F, model, weights, gradient, [images[rank]], pm, [cms[rank]])
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, "g%d.npy" % rank), gradient.cpu().numpy())
@@ -99,3 +101,21 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     assert np.abs(w - w_init).max() > 0
     # (first RMSprop step ~ lr * sign(g) / sqrt(0.1): compare against the size of the update, see test_gpu_model)
     assert np.linalg.norm(w0 - w) <= 1e-3 * np.linalg.norm(w - w_init)
+
+
+@pytest.mark.timeout(900)
+def test_rank_without_examples_issues_the_same_collectives(tmp_path):
+    """One rank's image has neither positives nor negatives (objective.lua loops over zero examples): the bucketed
+    exchange must not depend on that (a missing collective on one rank would hang RCCL), and the result equals the
+    single-process step on {image 0, empty image}."""
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    F, model, weights, gradient, anchors, images, pm, cms = _setup()
+    images[1] = dict(img=images[1]["img"], positive=[], negative=[])
+    _step(F, model, weights, gradient, images, pm, [cms[0]])
+    g = gradient.cpu().numpy()
+    assert np.isfinite(g0).all() and np.abs(g0).max() > 0
+    assert np.linalg.norm(g0 - g) <= 1e-5 * np.linalg.norm(g)
