@@ -142,6 +142,11 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     acc_pin = torch.zeros(8, dtype=torch.float64).pin_memory()
     acc_event = torch.cuda.Event()
     L = _lib.load()
+    # Data parallel: the four example counts are host-side numbers known before any kernel runs; they are summed over
+    # the ranks on a CPU (gloo) group of their own, so that the divisor of gradient:div(n) never needs the GPU stream
+    # and the whole step stays asynchronous (no host read-back between the backward pass and the optimiser step).
+    d0 = _dist()
+    host_group = d0.new_group(backend="gloo") if d0 is not None and hasattr(d0, "new_group") else None
 
     def cleanAnchors(examples, outputs):  # objective.lua:32-43
         return [e for e in examples
@@ -161,6 +166,17 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         cnet.training()
         batch = batch_iterator.nextTraining()  # :64
         pending = []
+        counts_cpu = counts_work = None
+        if host_group is not None and _dist() is not None:
+            from .synthetic import clean_examples, output_map_sizes
+            c4 = [0.0, 0.0, 0.0, 0.0]   # cls, reg, creg, ccls exactly as accumulated below (:194-198)
+            for x in batch:
+                shp = x["img"].shape
+                sizes = output_map_sizes(model, shp[1], shp[2])
+                np_, nn_ = len(clean_examples(x["positive"], sizes)), len(clean_examples(x["negative"], sizes))
+                c4[0] += np_ + nn_; c4[1] += np_; c4[2] += np_; c4[3] += 1
+            counts_cpu = torch.tensor(c4, dtype=torch.float64)
+            counts_work = _dist().all_reduce(counts_cpu, group=host_group, async_op=True)
         for x in batch:
             img = to_device(x["img"])  # :66
             outputs = pnet.forward(img)  # :71
@@ -266,6 +282,24 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         counts = (cls_count, reg_count, creg_count, ccls_count)
         if not single:   # the rest of the gradient is final too: its exchange starts before the host read-back below
             pending[:] = allreduce_begin_rest(gradient, pending)
+        if not single and counts_work is not None:
+            # asynchronous data-parallel tail: accumulators reduced on the device, counts already reduced on the host
+            assert [float(v) for v in (cls_count, reg_count, creg_count, ccls_count)] == c4, "count bookkeeping diverged"
+            acc_work = _dist().all_reduce(acc_t, async_op=True)
+            counts_work.wait()
+            gcounts = tuple(counts_cpu.tolist())
+            for pnd in pending:
+                pnd[2].wait()           # NCCL: the current stream waits, the host does not
+            acc_work.wait()
+            gs = 1.0 / gcounts[0] if gcounts[0] > 0 else None
+            if gs is not None and defer != "fold":
+                _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), gs, stream_ptr())  # :200
+            acc_pin.copy_(acc_t, non_blocking=True)
+            acc_event.record()
+            fin = lambda: finish(None, gcounts, (), True, reduced=True)
+            if defer == "fold":
+                return (fin, gs) if gs is not None else fin
+            return fin if defer else (lambda r: (lambda: r))(fin())
         if single and defer:
             acc_pin.copy_(acc_t, non_blocking=True)
             acc_event.record()
@@ -279,13 +313,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
 
     dp_gscale = [None]
 
-    def finish(a, counts, pending, single, fold=False):
+    def finish(a, counts, pending, single, fold=False, reduced=False):
         if a is None:
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
         cls_count, reg_count, creg_count, ccls_count = counts
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
-        tot = allreduce_gradient_and_stats(gradient, tot, pending)  # DP: no-op for a single process
+        if not reduced:   # (asynchronous data-parallel tail: gradient, accumulators and counts are already summed)
+            tot = allreduce_gradient_and_stats(gradient, tot, pending)  # DP: no-op for a single process
         cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count, ccls_loss, ccls_count = tot
         dp_gscale[0] = None
         if not single and cls_count > 0:
