@@ -146,7 +146,13 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     # the ranks on a CPU (gloo) group of their own, so that the divisor of gradient:div(n) never needs the GPU stream
     # and the whole step stays asynchronous (no host read-back between the backward pass and the optimiser step).
     d0 = _dist()
-    host_group = d0.new_group(backend="gloo") if d0 is not None and hasattr(d0, "new_group") else None
+    host_group = None
+    if d0 is not None and hasattr(d0, "new_group") and not os.environ.get("FRCNN_DP_SYNC_TAIL"):
+        try:
+            host_group = d0.new_group(backend="gloo")
+        except Exception as e:  # no usable CPU transport: the (synchronous) all-reduce of the 8 statistics still works
+            sys.stderr.write("frcnn: gloo group unavailable (%s); using the synchronous statistics exchange\n" % e)
+            host_group = None
 
     def cleanAnchors(examples, outputs):  # objective.lua:32-43
         return [e for e in examples
