@@ -12,6 +12,8 @@ rank processes its own images and the flat gradient + the 8 accumulators are all
 before `gradient:div(cls_count)` (objective.lua:200), so the result equals the single-process result
 on the concatenated batch."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 
