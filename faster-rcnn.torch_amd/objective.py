@@ -174,6 +174,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         cnet.training()
         batch = batch_iterator.nextTraining()  # :64
         pending = []
+        early_copy = False
         counts_cpu = counts_work = None
         if host_group is not None and _dist() is not None:
             from .synthetic import clean_examples, output_map_sizes
@@ -276,6 +277,13 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     pnet.backward_heads_join()
                     lo, hi = pnet.heads_param_range()
                     pending.append(allreduce_begin(gradient, lo, hi))
+            if x is batch[-1] and defer and _dist() is None:
+                # the eight statistics are final before the backbone's backward pass: their read-back is queued
+                # here, so the caller's wait ends mid-step and the host queues the next step while this one
+                # is still running (the device never drains between steps)
+                acc_pin.copy_(acc_t, non_blocking=True)
+                acc_event.record()
+                early_copy = True
             pnet.backward(img, delta_outputs)  # :189
             reg_count += npos  # :194-198
             cls_count += npos + nneg
@@ -309,8 +317,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 return (fin, gs) if gs is not None else fin
             return fin if defer else (lambda r: (lambda: r))(fin())
         if single and defer:
-            acc_pin.copy_(acc_t, non_blocking=True)
-            acc_event.record()
+            if not early_copy:
+                acc_pin.copy_(acc_t, non_blocking=True)
+                acc_event.record()
             fin = lambda: finish(None, counts, pending, single)
             return (fin, 1.0 / cls_count) if fold else fin
         if defer == "fold" and not single:   # the all-reduced count is known after finish(): scaling left to the caller
