@@ -76,11 +76,14 @@ _SIGS = {
     "frcnn_model_param_table": ([vp, vp, C.c_int, C.POINTER(C.c_int)], C.c_int),
     "frcnn_model_localizer_layers": ([vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)], C.c_int),
     "frcnn_pnet_forward": ([vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_ulonglong, vp], C.c_int),
+    "frcnn_pnet_forward_async_heads": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp], C.c_int),
     "frcnn_pnet_output": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "frcnn_pnet_delta": ([vp, C.c_int, C.POINTER(vp)], C.c_int),
     "frcnn_pnet_set_sparse_deltas": ([vp, C.c_int, vp, C.c_int], C.c_int),
     "frcnn_pnet_zero_deltas": ([vp, vp], C.c_int),
     "frcnn_pnet_backward_heads_begin": ([vp, vp, vp, vp], C.c_int),
+    "frcnn_pnet_anchor_loss_begin": ([vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp], C.c_int),
+    "frcnn_pnet_anchor_loss_wait": ([vp, vp], C.c_int),
     "frcnn_pnet_backward_heads_join": ([vp, vp, C.POINTER(C.c_int)], C.c_int),
     "frcnn_pnet_backward": ([vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_forward": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp, vp, vp], C.c_int),

@@ -103,6 +103,8 @@ struct frcnn_model {
   bool heads_begun = false;        // anchor-net backward already running on the side stream
   bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
+  hipEvent_t loss_ev = nullptr;    // anchor losses of frcnn_pnet_anchor_loss_begin are final (side stream)
+  bool loss_pending = false;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
@@ -333,6 +335,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+  if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
   if (m->side) (void)hipStreamDestroy(m->side);
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
@@ -400,7 +403,17 @@ static int ensure_side(frcnn_model* m) {
   if (!m->side) {
     FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
   }
+  return FRCNN_OK;
+}
+
+// the caller's stream waits for everything queued on the side stream so far
+static int join_side(frcnn_model* m, hipStream_t s) {
+  if (!m->side || !m->side_busy) return FRCNN_OK;
+  FR_HIP(hipEventRecord(m->join_ev, m->side));
+  FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+  m->side_busy = false;
   return FRCNN_OK;
 }
 
@@ -428,13 +441,15 @@ static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, 
   return FRCNN_OK;
 }
 
-int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
-                       const float* const* drop_masks, unsigned long long seed, void* stream) {
+static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
+                             const float* const* drop_masks, unsigned long long seed, void* stream, bool async_heads) {
   hipStream_t s = S(stream);
+  FR_TRY(join_side(m, s));   // (anchor nets of an abandoned asynchronous forward still read the model's buffers)
   if (H != m->H || W != m->W) FR_TRY(ensure_shapes(m, H, W));
   m->training = training;
-  m->heads_begun = false; m->heads_joined = false;
+  m->heads_begun = false; m->heads_joined = false; m->loss_pending = false;
   const bool use_side = side_enabled();
+  async_heads = async_heads && use_side && training;
   // SpatialDropout scales (device-drawn ones: one launch for all blocks)
   DropoutJobs dj;
   dj.n = 0;
@@ -498,6 +513,7 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     int heavy = -1;
     for (size_t i = 0; i < m->heads.size(); ++i)
       if ((!use_side || m->heads[i].input == last) && (heavy < 0 || m->heads[i].c3.k > m->heads[heavy].c3.k)) heavy = (int)i;
+    if (async_heads) heavy = -1;   // the caller's stream goes on with the last map; every anchor net stays on the side stream
     bool forked = false;
     for (size_t i = 0; use_side && i < m->heads.size(); ++i) {
       if (m->heads[i].input != last || (int)i == heavy) continue;
@@ -510,12 +526,18 @@ int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, 
     for (size_t i = 0; i < m->heads.size(); ++i)
       if ((int)i == heavy || (!use_side)) FR_TRY(head_forward(m, m->heads[i], w, s, 0));
   }
-  if (use_side && m->side_busy) {   // the caller's stream continues after every head is done
-    FR_HIP(hipEventRecord(m->join_ev, m->side));
-    FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
-    m->side_busy = false;
-  }
+  if (use_side && !async_heads) FR_TRY(join_side(m, s));   // the caller's stream continues after every head is done
   return FRCNN_OK;
+}
+
+int frcnn_pnet_forward(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
+                       const float* const* drop_masks, unsigned long long seed, void* stream) {
+  return pnet_forward_impl(m, w, img, H, W, training, drop_masks, seed, stream, false);
+}
+
+int frcnn_pnet_forward_async_heads(frcnn_model* m, const float* w, const float* img, int H, int W,
+                                   const float* const* drop_masks, unsigned long long seed, void* stream) {
+  return pnet_forward_impl(m, w, img, H, W, 1, drop_masks, seed, stream, true);
 }
 
 int frcnn_pnet_output(frcnn_model* m, int i, float** ptr, int* C, int* H, int* W) {
@@ -622,6 +644,46 @@ int frcnn_pnet_backward_heads_begin(frcnn_model* m, const float* w, float* grad,
   return FRCNN_OK;
 }
 
+int frcnn_pnet_anchor_loss_begin(frcnn_model* m, const float* w, float* grad, const int* ex_idx, const double* ex_anchor,
+                                 const double* ex_roi, const int* ex_class, int npos, int nneg, int bgclass,
+                                 double* ex_loss, float* crtarget, float* cctarget, double* acc, void* stream) {
+  hipStream_t s = S(stream);
+  FR_CHECK(m->H > 0 && m->training, "pnet_anchor_loss_begin: needs a preceding training-mode forward");
+  FR_CHECK(m->heads.size() <= 4, "pnet_anchor_loss_begin: at most 4 anchor nets");
+  FR_CHECK(!m->heads_begun, "pnet_anchor_loss_begin: the anchor nets' backward pass has already been started");
+  RpnLayers L;
+  float* deltas[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int l = 0; l < 4; ++l) {
+    const bool have = l < (int)m->heads.size();
+    L.map[l] = have ? m->heads[l].c1.x.f() : nullptr;
+    L.H[l] = have ? m->heads[l].c1.Ho : 0; L.W[l] = have ? m->heads[l].c1.Wo : 0;
+    deltas[l] = have ? m->heads[l].delta.f() : nullptr;
+  }
+  const int E = npos + nneg;
+  if (!side_enabled()) {   // serial: the losses on the caller's stream, the backward part left to frcnn_pnet_backward
+    FR_TRY(rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, s));
+    FR_TRY(loss_accumulate(ex_loss, E, acc, s));
+    return FRCNN_OK;
+  }
+  FR_TRY(fork_side(m, s, m->blocks.size() + 1));   // example tables and zeroed delta buffers are final on s
+  FR_TRY(rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, m->side));
+  FR_TRY(loss_accumulate(ex_loss, E, acc, m->side));
+  FR_HIP(hipEventRecord(m->loss_ev, m->side));
+  m->loss_pending = true;
+  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
+  FR_TRY(backward_heads(m, w, grad, m->side, 1));
+  m->heads_begun = true;
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_anchor_loss_wait(frcnn_model* m, void* stream) {
+  if (m->loss_pending) {
+    FR_HIP(hipStreamWaitEvent(S(stream), m->loss_ev, 0));
+    m->loss_pending = false;
+  }
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
   hipStream_t s = S(stream);
   if (joined) *joined = 0;
@@ -647,6 +709,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     }
     m->heads_begun = false; m->heads_joined = false; m->side_busy = false;
   } else {
+    FR_TRY(join_side(m, s));   // anchor nets of frcnn_pnet_forward_async_heads still in flight (image without examples)
     FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
     FR_TRY(backward_heads(m, w, grad, s, 0));
   }

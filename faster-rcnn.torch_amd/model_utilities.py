@@ -125,7 +125,10 @@ class ProposalNet(object):
     def evaluate(self):
         self.train = False
 
-    def forward(self, img):
+    def forward(self, img, async_heads=False):
+        """pnet:forward(img).  async_heads (training only, used by the objective): the anchor nets stay in flight
+        on the library's side stream -- only the last output is final in stream order until anchor_loss_begin /
+        backward have been called (frcnn_pnet_forward_async_heads)."""
         nat = self.native
         if nat.weights is None:
             raise _lib.FrcnnError("pnet:forward before combine_and_flatten_parameters()")
@@ -134,8 +137,12 @@ class ProposalNet(object):
         _, H, W = img.shape
         arr, keep = _mask_ptrs(self.drop_masks, nat.desc.nblocks)
         nat.seed += 1
-        _lib.call("frcnn_pnet_forward", nat.h, ptr(nat.weights), ptr(img), H, W, 1 if self.train else 0,
-                  C.cast(arr, C.c_void_p) if arr is not None else None, nat.seed, stream_ptr())
+        if async_heads and self.train:
+            _lib.call("frcnn_pnet_forward_async_heads", nat.h, ptr(nat.weights), ptr(img), H, W,
+                      C.cast(arr, C.c_void_p) if arr is not None else None, nat.seed, stream_ptr())
+        else:
+            _lib.call("frcnn_pnet_forward", nat.h, ptr(nat.weights), ptr(img), H, W, 1 if self.train else 0,
+                      C.cast(arr, C.c_void_p) if arr is not None else None, nat.seed, stream_ptr())
         outs = []
         for i in range(1, nat.desc.nheads + 2):
             p = C.c_void_p(); c = C.c_int(); h = C.c_int(); w = C.c_int()
@@ -171,6 +178,19 @@ class ProposalNet(object):
         as delta_outputs[1..nheads] are final (they are, after objective.lua:140), beside the cnet stage."""
         nat = self.native
         _lib.call("frcnn_pnet_backward_heads_begin", nat.h, ptr(nat.weights), ptr(nat.gradient), stream_ptr())
+
+    def anchor_loss_begin(self, d_idx, d_anchor, d_roi, d_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, acc):
+        """objective.lua:91-140 on this net's outputs[1..nheads] / delta_outputs[1..nheads], then the anchor nets'
+        part of :backward, on the library's side stream (frcnn_pnet_anchor_loss_begin).  d_* are device addresses
+        of the example tables (layout of frcnn_rpn_loss)."""
+        nat = self.native
+        _lib.call("frcnn_pnet_anchor_loss_begin", nat.h, ptr(nat.weights), ptr(nat.gradient), C.c_void_p(d_idx),
+                  C.c_void_p(d_anchor), C.c_void_p(d_roi), C.c_void_p(d_class), npos, nneg, bgclass, ptr(ex_loss),
+                  ptr(crtarget), ptr(cctarget), ptr(acc), stream_ptr())
+
+    def anchor_loss_wait(self):
+        """The caller's stream waits for the losses / cnet targets of anchor_loss_begin()."""
+        _lib.call("frcnn_pnet_anchor_loss_wait", self.native.h, stream_ptr())
 
     def backward_heads_join(self):
         """The caller's stream waits for backward_heads_begin()'s work.  True: the anchor nets' gradient slice is

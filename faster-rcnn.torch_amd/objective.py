@@ -188,7 +188,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             counts_work = _dist().all_reduce(counts_cpu, group=host_group, async_op=True)
         for x in batch:
             img = to_device(x["img"])  # :66
-            outputs = pnet.forward(img)  # :71
+            outputs = pnet.forward(img, async_heads=True)  # :71 (the anchor nets stay in flight beside the cnet stage)
             p = cleanAnchors(x["positive"], outputs)  # :74-75
             n = cleanAnchors(x["negative"], outputs)
             delta_outputs = pnet.delta_outputs(zero=True)  # :78-84
@@ -230,20 +230,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, C.c_void_p(dblob.ptr + o), len(sp[l]))
                     o += sp[l].nbytes
                 # ---- RPN loss on the sampled anchors (objective.lua:91-140) ------------------
-                maps = (C.c_void_p * 4)(*[outputs[i].ptr for i in range(4)])
-                deltas = (C.c_void_p * 4)(*[delta_outputs[i].ptr for i in range(4)])
-                Hs = (C.c_int * 4)(*[outputs[i].shape[1] for i in range(4)])
-                Ws = (C.c_int * 4)(*[outputs[i].shape[2] for i in range(4)])
+                # queued behind the anchor nets on the library's side stream, followed by their backward pass
+                # (delta_outputs[1..4] are final after the loop: the fine-tuning stage only touches
+                # delta_outputs[5], :182-185); this stream goes on with the cnet stage on the last map
                 ex_loss = scratch.get("ex_loss", (E, 2), np.float64)
                 crtarget = scratch.get("crtarget", (E, 4))
                 cctarget = scratch.get("cctarget", (E,))
-                _lib.call("frcnn_rpn_loss", maps, deltas, Hs, Ws, C.c_void_p(d_idx), C.c_void_p(d_anchor),
-                          C.c_void_p(d_roi), C.c_void_p(d_class), npos, nneg, bgclass, ptr(ex_loss), ptr(crtarget),
-                          ptr(cctarget), s)
-                _accumulate_losses(ex_loss, E, acc_dev, s)
-                # delta_outputs[1..4] are final (the fine-tuning stage only touches delta_outputs[5], :182-185):
-                # the anchor nets' backward starts now on the side stream, beside the cnet stage
-                pnet.backward_heads_begin()  # (delta_outputs are the model-owned buffers of :78-84)
+                pnet.anchor_loss_begin(d_idx, d_anchor, d_roi, d_class, npos, nneg, bgclass, ex_loss, crtarget,
+                                       cctarget, acc_dev)
                 # ---- ROI pooling of every example in one launch (:117-119, :137-139) ---------
                 cinput = scratch.get("cinput", (E, D))
                 pidx = scratch.get("pidx", (E, D), np.int32)
@@ -254,6 +248,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 crout, ccout = coutputs
                 crdelta = scratch.get("crdelta", (E, 4))
                 ccdelta = scratch.get("ccdelta", (E, ncls))
+                pnet.anchor_loss_wait()   # crtarget is relative to the anchor nets' proposals (:156)
                 _lib.call("frcnn_cnet_losses", ptr(crout), ptr(crtarget), ptr(ccout), ptr(cctarget), E, npos, ncls,
                           ptr(crdelta), ptr(ccdelta), C.c_void_p(acc_dev.ptr + 4 * 8), s)  # :170-177
                 post_roi_delta = cnet.backward(cinput, [crdelta, ccdelta])  # :179

@@ -215,6 +215,14 @@ int frcnn_model_localizer_layers(const frcnn_model *, int output_index, int *lay
 int frcnn_pnet_forward(frcnn_model *, const float *weights, const float *img, int H, int W,
                        int training, const float *const *drop_masks_host, unsigned long long seed,
                        void *stream);
+/* Training-mode pnet:forward (objective.lua:71) that leaves the anchor nets in flight on the library's side
+ * stream: on return only outputs[nheads+1] (the last pooled map) is final in `stream` order, so the
+ * fine-tuning stage (objective.lua:146-186) can start beside them.  outputs[1..nheads] are consumed by
+ * frcnn_pnet_anchor_loss_begin; frcnn_pnet_backward (or the next forward) joins whatever is still running.
+ * With the side stream off this is frcnn_pnet_forward(training=1). */
+int frcnn_pnet_forward_async_heads(frcnn_model *, const float *weights, const float *img, int H, int W,
+                                   const float *const *drop_masks_host, unsigned long long seed,
+                                   void *stream);
 /* outputs[i], i = 1..nheads+1; the buffers are owned by the model and reused by the next
  * forward (callers that keep results must copy: objective.lua:119). */
 int frcnn_pnet_output(frcnn_model *, int i, float **ptr_host, int *C_host, int *H_host,
@@ -233,6 +241,17 @@ int frcnn_pnet_set_sparse_deltas(frcnn_model *, int head, const int *positions, 
  * classification network's forward/backward on `stream`.  frcnn_pnet_backward then joins it.  Without this
  * call frcnn_pnet_backward does everything itself; the result is the same. */
 int frcnn_pnet_backward_heads_begin(frcnn_model *, const float *weights, float *grad, void *stream);
+/* The anchor loop of objective.lua:91-140 on the model's own outputs[1..nheads] / delta_outputs[1..nheads]
+ * (arguments as frcnn_rpn_loss + frcnn_loss_accumulate), followed by the anchor-net part of pnet:backward
+ * (as frcnn_pnet_backward_heads_begin) -- all on the library's side stream, ordered after everything queued
+ * on `stream` so far (example tables, zeroed delta buffers).  frcnn_pnet_anchor_loss_wait makes `stream` wait
+ * until ex_loss / crtarget / cctarget / acc are final (needed before frcnn_cnet_losses, objective.lua:156);
+ * frcnn_pnet_backward joins the rest.  With the side stream off the losses run on `stream` itself. */
+int frcnn_pnet_anchor_loss_begin(frcnn_model *, const float *weights, float *grad, const int *ex_idx,
+                                 const double *ex_anchor, const double *ex_roi, const int *ex_class,
+                                 int npos, int nneg, int bgclass, double *ex_loss, float *crtarget,
+                                 float *cctarget, double *acc, void *stream);
+int frcnn_pnet_anchor_loss_wait(frcnn_model *, void *stream);
 /* Makes `stream` wait for the anchor-net part started by frcnn_pnet_backward_heads_begin.  *joined_host = 1:
  * the anchor nets' slice of `grad` is final in stream order (e.g. for an early all-reduce of that slice beside
  * the remaining backward pass); 0: nothing had been started, frcnn_pnet_backward will compute that part. */
