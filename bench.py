@@ -120,6 +120,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: the host-side (gloo) subgroup of the objective binds to loopback instead of resolving the hostname
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend)  # "nccl" = RCCL over xGMI
 
     import frcnn_amd as F
