@@ -40,6 +40,18 @@ class MT19937(object):
         y ^= y >> 18
         return y & 0xFFFFFFFF
 
+    def uniform(self):
+        """[0, 1) double from one draw (TH's THRandom_uniform); stands in for LuaJIT's math.random()."""
+        return self.random() * (1.0 / 4294967296.0)
+
+    def randperm(self, n):
+        """torch.randperm(n) (TH: Fisher-Yates from the front with random() % (n - i)), 1-based."""
+        r = list(range(n))
+        for i in range(n - 1):
+            z = self.random() % (n - i)
+            r[i], r[z + i] = r[z + i], r[i]
+        return [v + 1 for v in r]
+
 
 _default_rng = MT19937()
 

@@ -1,0 +1,246 @@
+"""BatchIterator.lua:1-317 -- training / validation batch assembly with the image preparation on the device
+(SURVEY 8f-1).  The reference loads a JPEG with `image.load`, converts the colour space and runs
+`processImage` on the CPU; here the decoded frame goes to HBM once and every step of processImage is a HIP
+kernel (frcnn_image_*: rgb2yuv, image.scale, crop + flips, per-channel centring / scaling, contrastive
+normalisation of the luminance channel), so the frame is never touched by the host again before pnet:forward.
+
+Differences that are stated rather than hidden:
+  * no image codec in this environment: `load_image(fn)` is a callable supplied by the user that returns the
+    DECODED float RGB frame [3][H][W] in 0..1 (what image.load(fn, 3, 'float') returns); the default reads
+    `.npy` files.  Only color_space 'yuv' (both shipped configs) and 'rgb' are implemented.
+  * `math.random` is LuaJIT's own PRNG (not reproducible outside LuaJIT): every draw comes from the MT19937
+    stream also used for torch.random / torch.randperm (same substitution as Anchors.sampleNegative).
+The sequence of draws follows the reference line by line (BatchIterator.lua:112-143, :7-25)."""
+import ctypes as C
+import math
+import sys
+
+import numpy as np
+
+from . import _lib
+from .Anchors import Anchors, MT19937
+from .Rect import Rect
+from .synthetic import assemble_examples
+from .tensor import DeviceTensor, ptr, stream_ptr, to_device
+
+
+def find_target_size(orig_w, orig_h, target_smaller_side, max_pixel_size):  # utilities.lua:188-203
+    if orig_h < orig_w:
+        w = min(orig_w * target_smaller_side / orig_h, max_pixel_size)
+        h = math.floor(orig_h * w / orig_w + 0.5)
+        w = math.floor(w + 0.5)
+    else:
+        h = min(orig_h * target_smaller_side / orig_w, max_pixel_size)
+        w = math.floor(orig_w * h / orig_h + 0.5)
+        h = math.floor(h + 0.5)
+    assert w >= 1 and h >= 1
+    return int(w), int(h)
+
+
+def gaussian1D(size, sigma=0.25, amplitude=1.0, mean=0.5):
+    """image.gaussian1D with its defaults (float tensor under main.lua:51)."""
+    center = mean * size + 0.5
+    return np.array([amplitude * math.exp(-(((i - center) / (sigma * size)) ** 2) / 2) for i in range(1, size + 1)],
+                    dtype=np.float32)
+
+
+class _Ring(object):
+    """Device buffers recycled per shape (hipMalloc is synchronous): the last `depth` results of a shape stay
+    valid, older ones are overwritten -- enough for the images of a few batches in flight."""
+
+    def __init__(self, depth):
+        self.depth, self.bufs, self.pos = depth, {}, {}
+
+    def get(self, shape):
+        lst = self.bufs.setdefault(shape, [])
+        if len(lst) < self.depth:
+            lst.append(DeviceTensor.empty(shape))
+            return lst[-1]
+        i = self.pos.get(shape, 0)
+        self.pos[shape] = (i + 1) % self.depth
+        return lst[i]
+
+
+def _transform_rois(rois, froi, old_w, old_h, new_w, new_h):  # BatchIterator.lua:27-47 (the roi half)
+    result = []
+    img_rect = Rect(0, 0, new_w, new_h)
+    for roi in rois or []:
+        r = froi(roi.rect, old_w, old_h)
+        if r is not None:
+            r = r.clip(img_rect)
+            if not r.isEmpty():
+                roi.rect = r
+                result.append(roi)
+    return result
+
+
+class BatchIterator(object):
+    def __init__(self, model, training_data, load_image=None, seed=5489, ring=32):  # BatchIterator.lua:82-99
+        cfg = model["cfg"]
+        self.cfg = cfg
+        self.ground_truth = training_data["ground_truth"]
+        nz = cfg["normalization"]
+        self.kernel = gaussian1D(nz["width"]) if nz.get("method") == "contrastive" else None  # :88-92
+        self.anchors = Anchors(model["pnet"], cfg["scales"])
+        self.rng = MT19937(seed)
+        self.load_image_fn = load_image or (lambda fn: np.load(fn))
+        self.training = dict(order=[], list=list(training_data["training_set"]))
+        self.validation = dict(order=[], list=list(training_data.get("validation_set", [])))
+        self.background = dict(order=[], list=list(training_data.get("background_files") or []))
+        self._randomize_order(self.training, self.validation, self.background)
+        self.ring = _Ring(ring)
+        self.scratch = {}
+        self.log = lambda msg: None   # the reference prints one line per image (:249); silent by default
+
+    # ---- BatchIterator.lua:7-25
+    def _randomize_order(self, *sets):
+        for x in sets:
+            if x["list"]:
+                x["order"] = self.rng.randperm(len(x["list"]))
+            x["i"] = 1
+
+    def _next_entry(self, s):
+        if s["i"] > len(s["list"]):
+            self._randomize_order(s)
+        fn = s["list"][s["order"][s["i"] - 1] - 1]
+        s["i"] += 1
+        return fn
+
+    def _tmp(self, name, n):
+        t = self.scratch.get(name)
+        if t is None or t.numel() < n:
+            t = self.scratch[name] = DeviceTensor.empty((max(n, 1),))
+        return t
+
+    # ---- utilities.lua load_image: decoded RGB frame -> device, colour space conversion
+    def load_image(self, fn):
+        img = to_device(self.load_image_fn(fn))
+        if len(img.shape) != 3 or img.shape[0] != 3:
+            return img   # the caller reports the unexpected channel count (:185-188)
+        cs = self.cfg.get("color_space", "rgb")
+        if cs == "yuv":
+            out = self.ring.get(tuple(img.shape))
+            _lib.call("frcnn_image_rgb2yuv", ptr(img), ptr(out), img.shape[1], img.shape[2], stream_ptr())
+            return out
+        if cs != "rgb":
+            raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
+        return img
+
+    # ---- BatchIterator.lua:101-164
+    def processImage(self, img, rois=None):
+        cfg, aug, s = self.cfg, self.cfg["augmentation"], stream_ptr()
+        img = to_device(img)
+        Cn, H, W = img.shape
+        tw, th = find_target_size(W, H, cfg["target_smaller_side"], cfg["max_pixel_size"])
+        scale_X, scale_Y = tw / W, th / H
+        if aug.get("random_scaling") and aug["random_scaling"] > 0:   # :112-115 (restated as written)
+            scale_X = tw * (self.rng.uniform() - 0.5) * aug["random_scaling"] / W
+            scale_Y = scale_X + (self.rng.uniform() - 0.5) * aug["aspect_jitter"]
+        # scale (:117, :49-55): the destination size is truncated by the tensor constructor
+        sw, sh = int(max(1, W * scale_X)), int(max(1, H * scale_Y))
+        cur = self.ring.get((Cn, sh, sw))
+        _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)), s)
+        rois = _transform_rois(rois, lambda r, w, h: r.scale(scale_X, scale_Y), W, H, sw, sh)
+        # crop to the target size if a dimension was up-sampled beyond it (:119-130)
+        cw, ch, x0, y0 = sw, sh, 0, 0
+        if sw > tw or sh > th:
+            cw, ch = min(tw, sw), min(th, sh)
+            x0 = int(math.floor(self.rng.uniform() * (sw - cw)))
+            y0 = int(math.floor(self.rng.uniform() * (sh - ch)))
+            rect = Rect.fromXYWidthHeight(x0, y0, cw, ch)
+            rois = _transform_rois(rois, lambda r, w, h: r.clip(rect).offset(-rect.minX, -rect.minY), sw, sh, cw, ch)
+        hf = vf = False
+        if aug.get("hflip") and aug["hflip"] > 0 and self.rng.uniform() < aug["hflip"]:   # :132-137
+            hf = True
+            rois = _transform_rois(rois, lambda r, w, h: Rect(w - r.maxX, r.minY, w - r.minX, r.maxY), cw, ch, cw, ch)
+        if aug.get("vflip") and aug["vflip"] > 0 and self.rng.uniform() < aug["vflip"]:   # :139-144
+            vf = True
+            rois = _transform_rois(rois, lambda r, w, h: Rect(r.minX, h - r.maxY, r.maxX, h - r.minY), cw, ch, cw, ch)
+        if hf or vf or (cw, ch) != (sw, sh):   # crop and both flips are one gather
+            nxt = self.ring.get((Cn, ch, cw))
+            _lib.call("frcnn_image_crop_flip", ptr(cur), Cn, sh, sw, x0, y0, cw, ch, int(hf), int(vf), ptr(nxt), s)
+            cur = nxt
+        nz = cfg["normalization"]
+        if nz.get("centering") or nz.get("scaling"):   # :146-160
+            wsb = _lib.load().frcnn_image_normalize_workspace_bytes(Cn)
+            ws = self._tmp("norm", (wsb + 3) // 4)
+            _lib.call("frcnn_image_normalize", ptr(cur), Cn, ch, cw, int(bool(nz.get("centering"))),
+                      int(bool(nz.get("scaling"))), ptr(ws), wsb, s)
+        if self.kernel is not None:   # :162 img[1] = normalization:forward(img[{{1}}])
+            y = cur.offset_view(0, (ch, cw))
+            _lib.call("frcnn_image_contrastive_norm", ptr(y), ch, cw, self.kernel.ctypes.data_as(C.c_void_p),
+                      len(self.kernel), 1e-4, ptr(y), ptr(self._tmp("cn", ch * cw)), s)
+        return cur, rois
+
+    # ---- BatchIterator.lua:166-277
+    def nextTraining(self, count=None):
+        cfg = self.cfg
+        batch = []
+        count = count or cfg["batch_size"]
+
+        def checked_load(fn, what):
+            try:
+                img = self.load_image(fn)
+            except Exception as e:   # pcall: ImageNet contains invalid files (:176-181)
+                self.log("Invalid image '%s': %s" % (fn, e))
+                return None
+            if len(img.shape) != 3 or img.shape[0] != 3:
+                self.log("Warning: Skipping image '%s'. Unexpected channel count" % fn)
+                return None
+            return img
+
+        def try_add_next():
+            fn = self._next_entry(self.training)
+            rois = [type(r)(r.rect.clone(), r.class_index) for r in self.ground_truth[fn]["rois"]]   # deep_copy (:172)
+            img = checked_load(fn, "training")
+            if img is None:
+                return 0
+            img, rois = self.processImage(img, rois)
+            _, h, w = img.shape
+            if h < 128 or w < 128:   # :192-196
+                self.log("Warning: Skipping image '%s'. Invalid size after process: (%dx%d)" % (fn, w, h))
+                return 0
+            positive, negative = assemble_examples(self.anchors, cfg, rois, w, h, self.rng)   # :198-225
+            batch.append(dict(img=img, positive=positive, negative=negative))
+            self.log("'%s' (%dx%d); p: %d; n: %d" % (fn, w, h, len(positive), len(negative)))
+            return len(positive) + len(negative)
+
+        if self.background["list"]:   # one background image per batch with 5 % of the examples (:253-270)
+            fn = self._next_entry(self.background)
+            img = checked_load(fn, "background")
+            if img is not None:
+                img, _ = self.processImage(img)
+                _, h, w = img.shape
+                if h >= 128 and w >= 128:
+                    negative = self.anchors.sampleNegative(Rect(0, 0, w, h), [], 0, int(math.floor(count * 0.05)), self.rng)
+                    batch.append(dict(img=img, positive=[], negative=negative))
+                    count -= len(negative)
+        guard = 0
+        while count > 0:
+            n = try_add_next()
+            count -= n
+            guard = guard + 1 if n == 0 else 0
+            if guard > 10 * max(1, len(self.training["list"])):   # (the reference would spin forever on an unusable set)
+                raise _lib.FrcnnError("nextTraining: no usable training image")
+        return batch
+
+    # ---- BatchIterator.lua:279-317
+    def nextValidation(self, count=1):
+        batch = []
+        while count > 0:
+            fn = self._next_entry(self.validation)
+            try:
+                img = self.load_image(fn)
+            except Exception as e:
+                self.log("Invalid image '%s': %s" % (fn, e))
+                continue
+            if len(img.shape) != 3 or img.shape[0] != 3:
+                continue
+            rois = [type(r)(r.rect.clone(), r.class_index) for r in self.ground_truth[fn]["rois"]]
+            img, rois = self.processImage(img, rois)
+            _, h, w = img.shape
+            if h < 128 or w < 128:
+                continue
+            batch.append(dict(img=img, rois=rois))
+            count -= 1
+        return batch

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libfrcnn_hip.so")
 
 KC_NAMES = ["conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "gemm", "elemwise",
-            "roi", "rpn", "nms", "optim"]
+            "roi", "rpn", "nms", "optim", "image"]
 
 
 class FrcnnError(RuntimeError):
@@ -90,6 +90,12 @@ _SIGS = {
     "frcnn_cnet_backward": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_losses": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_decode": ([vp, C.c_int, C.c_int, vp, vp, vp], C.c_int),
+    "frcnn_image_rgb2yuv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
+    "frcnn_image_scale": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp], C.c_int),
+    "frcnn_image_crop_flip": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
+    "frcnn_image_normalize_workspace_bytes": ([C.c_int], C.c_size_t),
+    "frcnn_image_normalize": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp], C.c_int),
+    "frcnn_image_contrastive_norm": ([vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp], C.c_int),
 }
 
 _lib = None

@@ -273,4 +273,26 @@ int frcnn_cnet_decode(const float* cls_out, int R, int ncls, int* cls, float* co
   return cnet_decode(cls_out, R, ncls, cls, conf, S(stream));
 }
 
+// ---------------------------------------------------------------- image preparation (image.hip)
+int frcnn_image_rgb2yuv(const float* rgb, float* yuv, int H, int W, void* stream) {
+  FR_CHECK(rgb != yuv, "image_rgb2yuv: in-place conversion is not supported");
+  return image_rgb2yuv(rgb, yuv, H, W, S(stream));
+}
+int frcnn_image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, void* stream) {
+  return image_scale(src, C, H, W, dst, dH, dW, tmp, S(stream));
+}
+int frcnn_image_crop_flip(const float* src, int C, int H, int W, int x0, int y0, int w, int h, int hflip, int vflip,
+                          float* dst, void* stream) {
+  return image_crop_flip(src, C, H, W, x0, y0, w, h, hflip, vflip, dst, S(stream));
+}
+size_t frcnn_image_normalize_workspace_bytes(int C) { return image_normalize_workspace_bytes(C); }
+int frcnn_image_normalize(float* img, int C, int H, int W, int centering, int scaling, void* ws, size_t ws_bytes,
+                          void* stream) {
+  return image_normalize(img, C, H, W, centering, scaling, ws, ws_bytes, S(stream));
+}
+int frcnn_image_contrastive_norm(const float* in, int H, int W, const float* kernel_host, int K, float threshold,
+                                 float* out, float* tmp, void* stream) {
+  return image_contrastive_norm(in, H, W, kernel_host, K, threshold, out, tmp, S(stream));
+}
+
 }  // extern "C"

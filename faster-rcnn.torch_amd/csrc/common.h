@@ -58,6 +58,7 @@ enum KClass {
   KC_RPN,
   KC_NMS,
   KC_OPTIM,
+  KC_IMAGE,               // BatchIterator:processImage kernels (image.hip)
   KC_COUNT
 };
 

@@ -122,4 +122,17 @@ int cnet_losses(float* crout, const float* crtarget, const float* ccout, const f
 int log_softmax_backward(const float* gy, const float* lsm, int R, int n, float* gx, hipStream_t s);
 int cnet_decode(const float* cls_lsm, int R, int ncls, int* cls_out, float* conf_out, hipStream_t s);
 
+// ---------------------------------------------------------------- image (image.hip): BatchIterator:processImage
+int image_rgb2yuv(const float* rgb, float* yuv, int H, int W, hipStream_t s);
+// image.scale 'bilinear': src [C][H][W] -> dst [C][dH][dW]; tmp holds C*H*dW floats
+int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, hipStream_t s);
+// dst [C][h][w] = flips(crop(src, x0, y0, w, h))
+int image_crop_flip(const float* src, int C, int H, int W, int x0, int y0, int w, int h, int hflip, int vflip,
+                    float* dst, hipStream_t s);
+size_t image_normalize_workspace_bytes(int C);
+int image_normalize(float* img, int C, int H, int W, int centering, int scaling, void* ws, size_t ws_bytes,
+                    hipStream_t s);
+int image_contrastive_norm(const float* in, int H, int W, const float* kernel_host, int K, float threshold, float* out,
+                           float* tmp, hipStream_t s);
+
 }  // namespace frcnn

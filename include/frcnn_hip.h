@@ -277,6 +277,32 @@ int frcnn_cnet_losses(float *crout, const float *crtarget, const float *ccout,
 /* Detector.lua:110-113: class (1-based argmax) and confidence (max log-prob) per row */
 int frcnn_cnet_decode(const float *cls_out, int R, int ncls, int *cls, float *conf, void *stream);
 
+/* ---- image preparation: BatchIterator:processImage (BatchIterator.lua:101-164) ----
+ * The arithmetic the reference delegates to the torch `image` / `nn` packages, on a decoded float frame
+ * [C][H][W] resident in device memory.  All calls are asynchronous on `stream`. */
+/* image.rgb2yuv (utilities.lua load_image, color_space 'yuv'): rgb, yuv float[3][H][W] (may not alias). */
+int frcnn_image_rgb2yuv(const float *rgb, float *yuv, int H, int W, void *stream);
+/* image.scale(img, dW, dH), 'bilinear' (BatchIterator.lua:51): rows then columns; up-scaling interpolates
+ * linearly, down-scaling averages the covered source interval.  tmp: device float[C*H*dW]. */
+int frcnn_image_scale(const float *src, int C, int H, int W, float *dst, int dH, int dW, float *tmp,
+                      void *stream);
+/* image.crop(img, x0, y0, x0+w, y0+h) followed by image.hflip / image.vflip when the flags are set
+ * (BatchIterator.lua:57-80), one pass: dst float[C][h][w]. */
+int frcnn_image_crop_flip(const float *src, int C, int H, int W, int x0, int y0, int w, int h, int hflip,
+                          int vflip, float *dst, void *stream);
+/* img[i]:add(-img[i]:mean()) for every channel (centering != 0), then img[i]:div(img[i]:std()) where
+ * std > 1e-8 (scaling != 0), in place (BatchIterator.lua:146-160); mean and the unbiased standard deviation
+ * accumulate in fp64 in a fixed order.  workspace: frcnn_image_normalize_workspace_bytes(C) device bytes. */
+size_t frcnn_image_normalize_workspace_bytes(int C);
+int frcnn_image_normalize(float *img, int C, int H, int W, int centering, int scaling, void *workspace,
+                          size_t workspace_bytes, void *stream);
+/* nn.SpatialContrastiveNormalization(1, kernel) on one plane (BatchIterator.lua:162, kernel =
+ * image.gaussian1D(cfg.normalization.width)): subtractive then divisive normalisation with the 1-D kernel
+ * (K odd, <= 15, host pointer) applied along x then y over a zero-padded plane, border-corrected by the
+ * response to a plane of ones; threshold = thresval (1e-4 in the reference).  tmp: device float[H*W]. */
+int frcnn_image_contrastive_norm(const float *in, int H, int W, const float *kernel_host, int K,
+                                 float threshold, float *out, float *tmp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
