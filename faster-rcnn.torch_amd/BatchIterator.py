@@ -74,6 +74,15 @@ def _transform_rois(rois, froi, old_w, old_h, new_w, new_h):  # BatchIterator.lu
     return result
 
 
+class _RgbFrame(object):
+    """A decoded RGB frame in HBM whose image.rgb2yuv conversion is still pending: processImage folds it into the
+    row pass of image.scale (frcnn_image_scale, rgb2yuv = 1) instead of materialising the full-resolution YUV frame."""
+
+    def __init__(self, rgb):
+        self.rgb = rgb
+        self.shape = tuple(rgb.shape)
+
+
 class BatchIterator(object):
     def __init__(self, model, training_data, load_image=None, seed=5489, ring=32):  # BatchIterator.lua:82-99
         cfg = model["cfg"]
@@ -113,12 +122,14 @@ class BatchIterator(object):
         return t
 
     # ---- utilities.lua load_image: decoded RGB frame -> device, colour space conversion
-    def load_image(self, fn):
+    def load_image(self, fn, materialize=False):
         img = to_device(self.load_image_fn(fn))
         if len(img.shape) != 3 or img.shape[0] != 3:
             return img   # the caller reports the unexpected channel count (:185-188)
         cs = self.cfg.get("color_space", "rgb")
         if cs == "yuv":
+            if not materialize:
+                return _RgbFrame(img)   # converted inside processImage's first pass
             out = self.ring.get(tuple(img.shape))
             _lib.call("frcnn_image_rgb2yuv", ptr(img), ptr(out), img.shape[1], img.shape[2], stream_ptr())
             return out
@@ -129,7 +140,8 @@ class BatchIterator(object):
     # ---- BatchIterator.lua:101-164
     def processImage(self, img, rois=None):
         cfg, aug, s = self.cfg, self.cfg["augmentation"], stream_ptr()
-        img = to_device(img)
+        to_yuv = isinstance(img, _RgbFrame)
+        img = img.rgb if to_yuv else to_device(img)
         Cn, H, W = img.shape
         tw, th = find_target_size(W, H, cfg["target_smaller_side"], cfg["max_pixel_size"])
         scale_X, scale_Y = tw / W, th / H
@@ -139,7 +151,8 @@ class BatchIterator(object):
         # scale (:117, :49-55): the destination size is truncated by the tensor constructor
         sw, sh = int(max(1, W * scale_X)), int(max(1, H * scale_Y))
         cur = self.ring.get((Cn, sh, sw))
-        _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)), s)
+        _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
+                  int(to_yuv), s)
         rois = _transform_rois(rois, lambda r, w, h: r.scale(scale_X, scale_Y), W, H, sw, sh)
         # crop to the target size if a dimension was up-sampled beyond it (:119-130)
         cw, ch, x0, y0 = sw, sh, 0, 0

@@ -278,8 +278,9 @@ int frcnn_image_rgb2yuv(const float* rgb, float* yuv, int H, int W, void* stream
   FR_CHECK(rgb != yuv, "image_rgb2yuv: in-place conversion is not supported");
   return image_rgb2yuv(rgb, yuv, H, W, S(stream));
 }
-int frcnn_image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, void* stream) {
-  return image_scale(src, C, H, W, dst, dH, dW, tmp, S(stream));
+int frcnn_image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
+                      void* stream) {
+  return image_scale(src, C, H, W, dst, dH, dW, tmp, rgb2yuv, S(stream));
 }
 int frcnn_image_crop_flip(const float* src, int C, int H, int W, int x0, int y0, int w, int h, int hflip, int vflip,
                           float* dst, void* stream) {

@@ -85,8 +85,72 @@ __global__ void scale_axis_kernel(const float* __restrict__ src, float* __restri
   }
 }
 
-int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, hipStream_t s) {
+// The row pass with image.rgb2yuv applied to every source sample on the fly (same arithmetic as rgb2yuv_kernel, so
+// the result equals converting first): one thread produces the three channels of one output sample.
+__device__ __forceinline__ void yuv_at(const float* __restrict__ r, long hw, long i, float* o) {
+  const float R = r[i], G = r[hw + i], B = r[2 * hw + i];
+  o[0] = 0.299f * R + 0.587f * G + 0.114f * B;
+  o[1] = -0.14713f * R - 0.28886f * G + 0.436f * B;
+  o[2] = 0.615f * R - 0.51499f * G - 0.10001f * B;
+}
+__global__ void scale_rows_rgb2yuv_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int dW) {
+  const long total = (long)H * dW, hw = (long)H * W, ohw = (long)H * dW;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(t % dW);
+    const long row = (t / dW) * W;
+    float v[3], a[3], b[3];
+    if (dW > W) {
+      if (W == 1 || d == dW - 1) {
+        yuv_at(src, hw, row + W - 1, v);
+      } else {
+        const float scale = (float)(W - 1) / (float)(dW - 1);
+        float sf = (float)d * scale;
+        const long si = (long)sf;
+        sf -= (float)si;
+        yuv_at(src, hw, row + si, a);
+        yuv_at(src, hw, row + si + 1, b);
+        for (int c = 0; c < 3; ++c) v[c] = (1.f - sf) * a[c] + sf * b[c];
+      }
+    } else if (dW < W) {
+      const float scale = (float)W / (float)dW;
+      float s0f = (float)d * scale;
+      const long s0 = (long)s0f;
+      s0f -= (float)s0;
+      float s1f = (float)(d + 1) * scale;
+      const long s1 = (long)s1f;
+      s1f -= (float)s1;
+      yuv_at(src, hw, row + s0, a);
+      float acc[3] = {(1.f - s0f) * a[0], (1.f - s0f) * a[1], (1.f - s0f) * a[2]};
+      float n = 1.f - s0f;
+      for (long si = s0 + 1; si < s1; ++si) {
+        yuv_at(src, hw, row + si, a);
+        for (int c = 0; c < 3; ++c) acc[c] += a[c];
+        n += 1.f;
+      }
+      if (s1 < W) {
+        yuv_at(src, hw, row + s1, a);
+        for (int c = 0; c < 3; ++c) acc[c] += s1f * a[c];
+        n += s1f;
+      }
+      for (int c = 0; c < 3; ++c) v[c] = acc[c] / n;
+    } else {
+      yuv_at(src, hw, row + d, v);
+    }
+    for (int c = 0; c < 3; ++c) dst[c * ohw + t] = v[c];
+  }
+}
+
+int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
+                hipStream_t s) {
   FR_CHECK(C > 0 && H > 0 && W > 0 && dH > 0 && dW > 0, "image_scale: empty image (%dx%dx%d -> %dx%d)", C, H, W, dH, dW);
+  FR_CHECK(!rgb2yuv || C == 3, "image_scale: the fused rgb2yuv conversion needs 3 channels");
+  if (rgb2yuv) {
+    const long total = (long)H * dW;
+    int grid = (int)std::min<long>(cdivl(total, 256), 8192);
+    FR_LAUNCH(KC_IMAGE, 0, ((double)C * H * W + C * total) * 4.0, s, scale_rows_rgb2yuv_kernel, dim3(grid), dim3(256), 0, src,
+              tmp, H, W, dW);
+    FR_LAUNCH_CHECK();
+  } else
   // rows: [C*H][W] -> [C*H][dW]
   {
     const long total = (long)C * H * dW;
@@ -148,66 +212,65 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
   __syncthreads();
   return r;
 }
-__global__ void channel_partial_kernel(const float* __restrict__ img, long hw, int mode, const double* __restrict__ stat,
-                                       double* __restrict__ part) {
-  __shared__ double sh[4];
-  const int c = blockIdx.y;
-  const float* p = img + (long)c * hw;
-  const double m = mode ? stat[c] : 0.0;
-  double acc = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
-    const double x = (double)p[i];
-    acc += mode ? (x - m) * (x - m) : x;
-  }
-  const double r = block_sum_f64(acc, sh);
-  if (threadIdx.x == 0) part[c * IMG_NB + blockIdx.x] = r;
-}
-// mode 0: stat[c] = sum/n (mean); mode 1: stat[c] = sqrt(sum/(n-1)) (std)
-__global__ void channel_finish_kernel(const double* __restrict__ part, long hw, int mode, double* __restrict__ stat) {
-  const int c = threadIdx.x;
+// fixed-order fold of a channel's IMG_NB partials (every block of a consumer kernel repeats it: same order, same value)
+__device__ __forceinline__ double fold_partials(const double* __restrict__ part, int c) {
   double t = 0.0;
   for (int i = 0; i < IMG_NB; ++i) t += part[c * IMG_NB + i];
-  stat[c] = mode ? sqrt(t / (double)(hw - 1)) : t / (double)hw;
+  return t;
 }
-// mode 0: x += (float)(-mean[c]); mode 1: x /= (float)std[c] when std > 1e-8
-__global__ void channel_apply_kernel(float* __restrict__ img, long hw, int mode, const double* __restrict__ stat) {
+// One pass over a channel per launch, grid (IMG_NB, C), fp64 partial sums out:
+//   STEP 0: out = sum(x)
+//   STEP 1: mean = fold(in)/n;  x += (float)(-mean)  (centring);  out = sum(x)      [apply = 0: only out = sum(x)]
+//   STEP 2: m = fold(in)/n;  out = sum((x - m)^2)
+//   STEP 3: sd = sqrt(fold(in)/(n-1));  x /= (float)sd when sd > 1e-8
+template <int STEP>
+__global__ void channel_pass_kernel(float* __restrict__ img, long hw, int apply, const double* __restrict__ in,
+                                    double* __restrict__ out) {
+  __shared__ double sh[4];
   const int c = blockIdx.y;
   float* p = img + (long)c * hw;
-  const double v = stat[c];
-  if (mode && !(v > 1e-8)) return;
-  const float f = mode ? (float)v : (float)(-v);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x)
-    p[i] = mode ? p[i] / f : p[i] + f;
+  double m = 0.0;
+  float f = 0.f;
+  if (STEP == 1 && apply) f = (float)(-(fold_partials(in, c) / (double)hw));
+  if (STEP == 2) m = fold_partials(in, c) / (double)hw;
+  if (STEP == 3) {
+    const double sd = sqrt(fold_partials(in, c) / (double)(hw - 1));
+    if (!(sd > 1e-8)) return;
+    f = (float)sd;
+  }
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    float x = p[i];
+    if (STEP == 1 && apply) { x = x + f; p[i] = x; }
+    if (STEP == 3) { p[i] = x / f; continue; }
+    const double xd = (double)x;
+    acc += STEP == 2 ? (xd - m) * (xd - m) : xd;
+  }
+  if (STEP == 3) return;
+  const double r = block_sum_f64(acc, sh);
+  if (threadIdx.x == 0) out[c * IMG_NB + blockIdx.x] = r;
 }
 
-size_t image_normalize_workspace_bytes(int C) { return (size_t)C * (IMG_NB + 1) * sizeof(double); }
+size_t image_normalize_workspace_bytes(int C) { return (size_t)C * IMG_NB * 2 * sizeof(double); }
 
 int image_normalize(float* img, int C, int H, int W, int centering, int scaling, void* ws, size_t ws_bytes,
                     hipStream_t s) {
   const long hw = (long)H * W;
   FR_CHECK(C > 0 && C <= 64 && hw > 0, "image_normalize: bad shape %dx%dx%d", C, H, W);
   FR_CHECK(ws_bytes >= image_normalize_workspace_bytes(C), "image_normalize: workspace too small");
-  double* part = (double*)ws;
-  double* stat = part + (size_t)C * IMG_NB;
+  FR_CHECK(!scaling || hw > 1, "image_normalize: std of a single pixel");
+  double* pa = (double*)ws;
+  double* pb = pa + (size_t)C * IMG_NB;
   const dim3 grid(IMG_NB, C);
-  const int ag = (int)std::min<long>(cdivl(hw, 256), 1024);
-  if (centering) {
-    FR_LAUNCH(KC_IMAGE, 0, C * hw * 4.0, s, channel_partial_kernel, grid, dim3(256), 0, (const float*)img, hw, 0,
-              (const double*)stat, part);
-    FR_LAUNCH(KC_IMAGE, 0, 0.0, s, channel_finish_kernel, dim3(1), dim3(C), 0, (const double*)part, hw, 0, stat);
-    FR_LAUNCH(KC_IMAGE, 0, C * hw * 8.0, s, channel_apply_kernel, dim3(ag, C), dim3(256), 0, img, hw, 0,
-              (const double*)stat);
-  }
+  const double bytes = C * hw * 4.0;
+  if (centering)   // sum(x), then centring fused with the sum of the centred values (the mean that std() recomputes)
+    FR_LAUNCH(KC_IMAGE, 0, bytes, s, channel_pass_kernel<0>, grid, dim3(256), 0, img, hw, 0, (const double*)pb, pa);
+  if (centering || scaling)
+    FR_LAUNCH(KC_IMAGE, 0, bytes * (centering ? 2 : 1), s, channel_pass_kernel<1>, grid, dim3(256), 0, img, hw, centering,
+              (const double*)pa, pb);
   if (scaling) {
-    FR_CHECK(hw > 1, "image_normalize: std of a single pixel");
-    FR_LAUNCH(KC_IMAGE, 0, C * hw * 4.0, s, channel_partial_kernel, grid, dim3(256), 0, (const float*)img, hw, 0,
-              (const double*)stat, part);
-    FR_LAUNCH(KC_IMAGE, 0, 0.0, s, channel_finish_kernel, dim3(1), dim3(C), 0, (const double*)part, hw, 0, stat);
-    FR_LAUNCH(KC_IMAGE, 0, C * hw * 4.0, s, channel_partial_kernel, grid, dim3(256), 0, (const float*)img, hw, 1,
-              (const double*)stat, part);
-    FR_LAUNCH(KC_IMAGE, 0, 0.0, s, channel_finish_kernel, dim3(1), dim3(C), 0, (const double*)part, hw, 1, stat);
-    FR_LAUNCH(KC_IMAGE, 0, C * hw * 8.0, s, channel_apply_kernel, dim3(ag, C), dim3(256), 0, img, hw, 1,
-              (const double*)stat);
+    FR_LAUNCH(KC_IMAGE, 0, bytes, s, channel_pass_kernel<2>, grid, dim3(256), 0, img, hw, 0, (const double*)pb, pa);
+    FR_LAUNCH(KC_IMAGE, 0, bytes * 2, s, channel_pass_kernel<3>, grid, dim3(256), 0, img, hw, 0, (const double*)pa, pb);
   }
   FR_LAUNCH_CHECK();
   return FRCNN_OK;

@@ -283,9 +283,11 @@ int frcnn_cnet_decode(const float *cls_out, int R, int ncls, int *cls, float *co
 /* image.rgb2yuv (utilities.lua load_image, color_space 'yuv'): rgb, yuv float[3][H][W] (may not alias). */
 int frcnn_image_rgb2yuv(const float *rgb, float *yuv, int H, int W, void *stream);
 /* image.scale(img, dW, dH), 'bilinear' (BatchIterator.lua:51): rows then columns; up-scaling interpolates
- * linearly, down-scaling averages the covered source interval.  tmp: device float[C*H*dW]. */
+ * linearly, down-scaling averages the covered source interval.  tmp: device float[C*H*dW].
+ * rgb2yuv != 0 (C == 3): src is the RGB frame and every source sample goes through image.rgb2yuv on the fly --
+ * the result of frcnn_image_rgb2yuv followed by the scaling, without the full-resolution round trip. */
 int frcnn_image_scale(const float *src, int C, int H, int W, float *dst, int dH, int dW, float *tmp,
-                      void *stream);
+                      int rgb2yuv, void *stream);
 /* image.crop(img, x0, y0, x0+w, y0+h) followed by image.hflip / image.vflip when the flags are set
  * (BatchIterator.lua:57-80), one pass: dst float[C][h][w]. */
 int frcnn_image_crop_flip(const float *src, int C, int H, int W, int x0, int y0, int w, int h, int hflip,

@@ -37,7 +37,7 @@ def test_scale_matches_oracle(F, src, dst):
     img = rng.randn(*src).astype(np.float32)
     out = F.DeviceTensor.empty((Cn, dH, dW)); tmp = F.DeviceTensor.empty((Cn * H * dW,))
     d = _dev(F, img)
-    F._lib.call("frcnn_image_scale", F.ptr(d), Cn, H, W, F.ptr(out), dH, dW, F.ptr(tmp), F.stream_ptr())
+    F._lib.call("frcnn_image_scale", F.ptr(d), Cn, H, W, F.ptr(out), dH, dW, F.ptr(tmp), 0, F.stream_ptr())
     want = OI.scale_bilinear(img, dW, dH)
     got = out.numpy()
     assert got.shape == want.shape
@@ -55,13 +55,25 @@ def test_scale_full_size_properties(F):
     def run(x):
         out = F.DeviceTensor.empty((3, dH, dW))
         d = _dev(F, x)
-        F._lib.call("frcnn_image_scale", F.ptr(d), 3, H, W, F.ptr(out), dH, dW, F.ptr(tmp), F.stream_ptr())
+        F._lib.call("frcnn_image_scale", F.ptr(d), 3, H, W, F.ptr(out), dH, dW, F.ptr(tmp), 0, F.stream_ptr())
         return out.numpy()
     ra, rb, rab = run(a), run(b), run(a + 2 * b)
     assert_close(rab, ra + 2 * rb, 1e-5, "linearity")
     assert_close(run(np.full((3, H, W), 0.375, np.float32)), np.full((3, dH, dW), 0.375, np.float32), 1e-6, "constant")
     want = OI.scale_bilinear(a[:1], dW, dH)
     assert_close(ra[:1], want, 1e-6, "1080p -> 800x450 channel 0")
+
+
+def test_scale_with_fused_rgb2yuv_is_bit_identical(F):
+    rng = np.random.RandomState(9)
+    for (H, W, dH, dW) in [(108, 192, 45, 80), (40, 64, 90, 150), (50, 70, 50, 70), (1080, 1920, 450, 800)]:
+        rgb = rng.rand(3, H, W).astype(np.float32)
+        d = _dev(F, rgb); yuv = F.DeviceTensor.empty((3, H, W)); tmp = F.DeviceTensor.empty((3 * H * dW,))
+        a = F.DeviceTensor.empty((3, dH, dW)); b = F.DeviceTensor.empty((3, dH, dW))
+        F._lib.call("frcnn_image_rgb2yuv", F.ptr(d), F.ptr(yuv), H, W, F.stream_ptr())
+        F._lib.call("frcnn_image_scale", F.ptr(yuv), 3, H, W, F.ptr(a), dH, dW, F.ptr(tmp), 0, F.stream_ptr())
+        F._lib.call("frcnn_image_scale", F.ptr(d), 3, H, W, F.ptr(b), dH, dW, F.ptr(tmp), 1, F.stream_ptr())
+        assert np.array_equal(a.numpy(), b.numpy())
 
 
 def test_crop_flip_exact(F):
