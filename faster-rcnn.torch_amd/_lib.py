@@ -86,6 +86,7 @@ _SIGS = {
     "frcnn_pnet_anchor_loss_wait": ([vp, vp], C.c_int),
     "frcnn_pnet_backward_heads_join": ([vp, vp, C.POINTER(C.c_int)], C.c_int),
     "frcnn_pnet_backward": ([vp, vp, vp, vp], C.c_int),
+    "frcnn_pnet_wait_block_gradients": ([vp, C.c_int, vp], C.c_int),
     "frcnn_cnet_forward": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_backward": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_losses": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),

@@ -104,6 +104,8 @@ struct frcnn_model {
   bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
   hipEvent_t loss_ev = nullptr;    // anchor losses of frcnn_pnet_anchor_loss_begin are final (side stream)
+  std::vector<hipEvent_t> block_ev;   // block b's parameter gradients are final (recorded by frcnn_pnet_backward)
+  bool block_ev_valid = false;
   bool loss_pending = false;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
@@ -336,6 +338,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
   if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
+  for (auto e : m->block_ev) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
@@ -697,6 +700,13 @@ int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
   return FRCNN_OK;
 }
 
+int frcnn_pnet_wait_block_gradients(frcnn_model* m, int block, void* stream) {
+  FR_CHECK(block >= 1 && block <= (int)m->blocks.size(), "pnet_wait_block_gradients: block %d out of range", block);
+  FR_CHECK(m->block_ev_valid && (size_t)block <= m->block_ev.size(), "pnet_wait_block_gradients: call frcnn_pnet_backward first");
+  FR_HIP(hipStreamWaitEvent(S(stream), m->block_ev[block - 1], 0));
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* stream) {
   hipStream_t s = S(stream);
   FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
@@ -748,6 +758,15 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       }
       if (use_side) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
       FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
+      if (st == 0) {   // every gradient of block b's parameters is final once this launch has run (its fork also
+                       // covers the bias / slope sums that act_backward accumulates on the caller's stream)
+        while (m->block_ev.size() < (size_t)nb) {
+          hipEvent_t e;
+          FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          m->block_ev.push_back(e);
+        }
+        FR_HIP(hipEventRecord(m->block_ev[b], ws));
+      }
       if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       if (st > 0) {
@@ -760,6 +779,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       }
     }
   }
+  m->block_ev_valid = true;
   if (use_side) {   // the caller's stream continues after every weight gradient has landed
     FR_HIP(hipEventRecord(m->join_ev, ws));
     FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));

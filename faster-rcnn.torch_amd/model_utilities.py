@@ -199,6 +199,19 @@ class ProposalNet(object):
         _lib.call("frcnn_pnet_backward_heads_join", self.native.h, stream_ptr(), C.byref(joined))
         return bool(joined.value)
 
+    def block_param_range(self, b):
+        """[lo, hi) of backbone block b's parameters (0-based b) in the flat vector: three tensors per convolution."""
+        d = self.native.desc
+        first = sum(int(d.conv_steps[i]) for i in range(b))
+        n = int(d.conv_steps[b])
+        t = self.native.param_table
+        last = t[3 * (first + n) - 1]
+        return int(t[3 * first][0]), int(last[0]) + int(last[1])
+
+    def wait_block_gradients(self, b):
+        """The CURRENT stream waits until block b's (0-based) gradients of the queued backward pass are final."""
+        _lib.call("frcnn_pnet_wait_block_gradients", self.native.h, b + 1, stream_ptr())
+
     def heads_param_range(self):
         """[lo, hi) of the anchor nets' parameters in the flat vector (they follow the backbone convolutions)."""
         d = self.native.desc

@@ -156,6 +156,15 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             sys.stderr.write("frcnn: gloo group unavailable (%s); using the synchronous statistics exchange\n" % e)
             host_group = None
 
+    # data parallel: the slices of the deep backbone blocks are final long before the backward pass ends (the deepest
+    # block's weight gradients come first); their all-reduces start behind a per-block event on an auxiliary stream
+    early_blocks = []
+    aux_stream = [None]
+    if os.environ.get("FRCNN_DP_EARLY_BLOCKS", "1") != "0":
+        nblk = int(native.desc.nblocks)
+        early_blocks = [b for b in range(nblk - 1, 0, -1)
+                        if pnet.block_param_range(b)[1] - pnet.block_param_range(b)[0] >= (1 << 18)]
+
     def cleanAnchors(examples, outputs):  # objective.lua:32-43
         return [e for e in examples
                 if not (e[0].index[1] > outputs[e[0].layer - 1].shape[1] or e[0].index[2] > outputs[e[0].layer - 1].shape[2])]
@@ -280,6 +289,14 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 acc_event.record()
                 early_copy = True
             pnet.backward(img, delta_outputs)  # :189
+            if x is batch[-1] and _dist() is not None and early_blocks and getattr(gradient, "is_cuda", False):
+                if aux_stream[0] is None:
+                    aux_stream[0] = torch.cuda.Stream()
+                for b in early_blocks:   # deepest first: the order in which their gradients become final
+                    lo, hi = pnet.block_param_range(b)
+                    with torch.cuda.stream(aux_stream[0]):
+                        pnet.wait_block_gradients(b)
+                        pending.append(allreduce_begin(gradient, lo, hi))
             reg_count += npos  # :194-198
             cls_count += npos + nneg
             creg_count += npos

@@ -260,6 +260,12 @@ int frcnn_pnet_backward_heads_join(frcnn_model *, void *stream, int *joined_host
  * The (unused) input gradient of the first convolution is not computed. */
 int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *stream);
 
+/* After frcnn_pnet_backward has been queued: makes `stream` (any stream) wait until every gradient of backbone
+ * block `block` (1-based; its convolutions' weights, biases and PReLU slopes -- a contiguous slice of the flat
+ * vector) is final.  The deepest block finishes first, long before the call's own stream reaches the end of the
+ * pass: a data-parallel caller starts that slice's all-reduce behind this wait, beside the remaining backward pass. */
+int frcnn_pnet_wait_block_gradients(frcnn_model *, int block, void *stream);
+
 /* cnet:forward(cinput) (objective.lua:164, Detector.lua:101).  weights/grad point at the START
  * of the flat vectors.  bn_running: float[2*n] {mean,var} per BatchNorm layer (updated when
  * training).  drop_masks_host[l]: device float[R][n_l] keep masks or NULL (seeded RNG). */

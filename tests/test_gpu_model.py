@@ -402,3 +402,7 @@ def test_bucketed_exchange_path_on_one_gpu(F, setup, monkeypatch):
     assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:])), r
     lo, hi = model["pnet"].heads_param_range()
     assert (nat.pnet_params, nat.total_params) in first_ranges and (lo, hi) in first_ranges and lo == 3321095
+    # ... and the two deep backbone blocks, started behind frcnn_pnet_wait_block_gradients beside the rest of the pass
+    b3, b2 = model["pnet"].block_param_range(3), model["pnet"].block_param_range(2)
+    assert b3 in first_ranges and b2 in first_ranges and b3[1] == lo and b2[1] == b3[0]
+    assert b3[1] - b3[0] == 256 * 384 * 9 + 384 * 384 * 9 + 2 * (384 + 1)
