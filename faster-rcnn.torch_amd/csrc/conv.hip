@@ -205,6 +205,7 @@ struct IgemmArgs {
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 3 split-K slab
+  int dma_patch;          // input patch by LDS-DMA (no activation to fuse, tensor < 2 GiB)
 };
 
 #ifndef IG_TRACE
@@ -279,6 +280,16 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
     gok[it] = e < plane && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     gofs[it] = gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u;   // clamped: loads are unconditional, zero fill by select
   }
+  // LDS-DMA variant of the patch staging (launches whose input needs no PReLU / dropout scale): `buffer_load_dword
+  // ... lds` moves one patch position per lane straight into Bs[cc][it*256 + tid] -- one instruction per 64 values
+  // instead of load + select + ds_write, no staging registers.  Positions outside the image (and channels >= Cin)
+  // fall outside the buffer resource's range and arrive as zeros.
+  const bool dma_patch = MODE == 0 && p.dma_patch != 0;
+  unsigned dofs[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) dofs[it] = gok[it] ? gofs[it] : 0x7FFFFFFFu;
+  const __amdgpu_buffer_rsrc_t in_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, dma_patch ? p.Cin * HW * 4 : 0, 0x00020000);
   const bool has_slope = p.in_slope != nullptr, has_scale = p.in_scale != nullptr;
   const float slope = has_slope ? *p.in_slope : 1.f;
 
@@ -331,6 +342,16 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
                                          (__attribute__((address_space(3))) void*)(dstA + i * 4 * RPW * BM), 16, 0, 0);
     }
     const int c0 = chunk * CC;
+    if (dma_patch) {
+      float* dstB = buf + aFloats + wave_u * 64;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(dstB + cc * planeP + it * 256),
+                                                   4, dofs[it], (unsigned)(c0 + cc) * (unsigned)hw_bytes, 0, 0);
+      return;
+    }
     const char* srcB = reinterpret_cast<const char*>(p.in + (size_t)c0 * HW);
     if (c0 + CC <= p.Cin) {
 #pragma unroll
@@ -365,6 +386,10 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
     }
   };
   auto stage_store = [&](int chunk, float* bufB) {
+    if (dma_patch) {   // (the compiler does not count LDS-DMA as pending LDS writes at the barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     const int nvalid = p.Cin - chunk * CC;   // >= CC except in a partial last chunk
     if (has_slope) {
       if (has_scale) store_as(bufB, std::true_type{}, std::true_type{}, nvalid);
@@ -605,6 +630,8 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
     FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 1));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
+  static const int ig_dma = getenv("FRCNN_IG_DMA") ? atoi(getenv("FRCNN_IG_DMA")) : 1;
+  a.dma_patch = ig_dma && k > 1 && !in_slope && !in_scale && (double)Cin * H * W * 4.0 < 2147483647.0 ? 1 : 0;
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_IGEMM_K3 : KC_CONV_IGEMM_OTHER;
   int rc;
