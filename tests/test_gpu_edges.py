@@ -125,3 +125,59 @@ def _keep(F, a):
     t = F.DeviceTensor.from_numpy(a)
     _KEEP.append(t)
     return t
+
+
+def test_async_heads_forward_equals_plain_forward(F, setup):
+    """frcnn_pnet_forward_async_heads leaves the anchor nets on the side stream; once joined (frcnn_pnet_backward, a
+    new forward, or a device synchronisation) every output equals the plain training-mode forward.  An abandoned
+    asynchronous forward followed by a plain one must be safe (the next forward joins first)."""
+    import torch
+    s = setup
+    rng = np.random.RandomState(31)
+    img = F.synthetic_image(140, 190, 9)
+    pnet = s["model"]["pnet"]
+    pnet.training(); pnet.drop_masks = _masks(rng, s["model"])
+    try:
+        plain = [o.numpy().copy() for o in pnet.forward(img)]
+        outs = pnet.forward(img, async_heads=True)
+        torch.cuda.synchronize()                      # (device-wide: covers the library's side stream)
+        for a, b in zip(plain, outs):
+            assert np.array_equal(a, b.numpy())
+        pnet.forward(img, async_heads=True)           # abandoned: never joined by the caller
+        again = [o.numpy().copy() for o in pnet.forward(img)]
+        for a, b in zip(plain, again):
+            assert np.array_equal(a, b)
+    finally:
+        pnet.drop_masks = None
+
+
+def test_wait_block_gradients_contract(F, setup):
+    """frcnn_pnet_wait_block_gradients: rejected before any backward pass and for blocks that do not exist; after a
+    backward pass the waiting stream sees the block's final gradient slice."""
+    import torch
+    s = setup
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)                          # a fresh model: no backward pass has run on it yet
+    w, g = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=5)
+    pnet = model["pnet"]
+    with pytest.raises(F.FrcnnError):
+        pnet.wait_block_gradients(3)
+    img = F.synthetic_image(140, 190, 3)
+    pnet.training()
+    outs = pnet.forward(img)
+    deltas = pnet.delta_outputs(zero=True)
+    rng = np.random.RandomState(2)
+    for d in deltas:
+        d.copy_from_numpy((rng.randn(*d.shape) / np.sqrt(d.numel())).astype(np.float32))
+    g.zero_()
+    pnet.backward(img, deltas)
+    aux = torch.cuda.Stream()
+    lo, hi = pnet.block_param_range(3)
+    with torch.cuda.stream(aux):
+        pnet.wait_block_gradients(3)
+        early = g[lo:hi].clone()                      # copied on the auxiliary stream, behind the block's event only
+    torch.cuda.synchronize()
+    assert torch.equal(early, g[lo:hi]) and float(early.abs().max()) > 0
+    with pytest.raises(F.FrcnnError):
+        F._lib.call("frcnn_pnet_wait_block_gradients", model["native"].h, 9, F.stream_ptr())
+    assert pnet.block_param_range(0)[0] == 0 and pnet.block_param_range(3)[1] == pnet.heads_param_range()[0]
