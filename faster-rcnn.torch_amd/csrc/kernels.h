@@ -29,7 +29,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
                double algo_flops, hipStream_t s, int ws_slot = 0);  // ws_slot: split-K workspace (0 | 1)
 
-// gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (atomic accumulation)
+// gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (split-K slabs in `ws`, folded in a fixed order)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
