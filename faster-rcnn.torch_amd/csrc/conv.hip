@@ -206,6 +206,12 @@ struct IgemmArgs {
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 3 split-K slab
   int dma_patch;          // input patch by LDS-DMA (no activation to fuse, tensor < 2 GiB)
+  // fused 2x2 stride-2 ceil-mode max pool of act(out) (tile fixed to TH=4 x TW=32, single K split): null = off
+  float* pool_out;             // [M][Hp][Wp]
+  unsigned char* pool_idx;     // arg-max code dy*2+dx, first maximum wins
+  const float* pool_slope;     // PReLU slope of the pooled activation (device scalar) or null
+  const float* pool_scale;     // dropout scale [M] or null
+  int Hp, Wp;
 };
 
 #ifndef IG_TRACE
@@ -503,9 +509,55 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
       }
     }
   };
+  // Epilogue with the block's max pool fused (last convolution of a backbone block): with the 4 x 32 tile a wave holds
+  // two vertically adjacent output rows in acc[0][0] / acc[0][1] of the same lane and the horizontal neighbour in
+  // lane^1, so a 2x2 window is two registers + two lane exchanges.  x = conv + bias is stored as usual (the backward
+  // pass needs it); the pooled map takes act(x) = scale[m] * prelu(x) in the window order (0,0),(0,1),(1,0),(1,1),
+  // first maximum wins -- the arithmetic of maxpool_act_forward_kernel.
+  auto store_tile_pool = [&]() {
+    const int oy0 = ty0 + wn * 2, ox = tx0 + li;
+    const bool colok = ox < p.Wo, col1ok = ox + 1 < p.Wo, row0ok = oy0 < p.Ho, row1ok = oy0 + 1 < p.Ho;
+    const float aslope = p.pool_slope ? *p.pool_slope : 1.f;
+    const bool has_ps = p.pool_slope != nullptr;
+    const size_t pofs = (size_t)(oy0 >> 1) * p.Wp + (ox >> 1);
+    const size_t HpWp = (size_t)p.Hp * p.Wp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+      const bool mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      const float b = p.bias ? p.bias[mc] : 0.f;
+      const float sc = p.pool_scale ? p.pool_scale[mc] : 1.f;
+      const float v0 = acc[0][0][r] + b, v1 = acc[0][1][r] + b;
+      if (mok && colok) {
+        float* dst = p.out + (size_t)m * HoWo + (size_t)oy0 * p.Wo + ox;
+        if (row0ok) dst[0] = v0;
+        if (row1ok) dst[p.Wo] = v1;
+      }
+      float a0 = v0, a1 = v1;
+      if (has_ps) { a0 = a0 > 0.f ? a0 : aslope * a0; a1 = a1 > 0.f ? a1 : aslope * a1; }
+      if (p.pool_scale) { a0 *= sc; a1 *= sc; }
+      const float n0 = __shfl_xor(a0, 1, 64), n1 = __shfl_xor(a1, 1, 64);
+      if (!(li & 1) && mok && colok && row0ok) {
+        float best = a0;
+        int bi = 0;
+        if (col1ok && n0 > best) { best = n0; bi = 1; }
+        if (row1ok) {
+          if (a1 > best) { best = a1; bi = 2; }
+          if (col1ok && n1 > best) { best = n1; bi = 3; }
+        }
+        p.pool_out[(size_t)m * HpWp + pofs] = best;
+        p.pool_idx[(size_t)m * HpWp + pofs] = (unsigned char)bi;
+      }
+    }
+  };
+  if constexpr (MT == 1 && NTW == 2 && KS == 3) {
+    if (p.pool_out) { store_tile_pool(); goto done; }
+  }
   if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
   else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
   else store_tile(std::integral_constant<int, 3>{});
+done:;
 #if IG_TRACE
   if (tid == 0 && blockIdx.x < 4096) {
     unsigned long long* t = g_ig_trace + 16 * blockIdx.x;
@@ -594,8 +646,10 @@ static int launch_igemm(IgemmArgs& a, int klass, double flops, hipStream_t s) {
 
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
-               double algo_flops, hipStream_t s, int ws_slot) {
+               double algo_flops, hipStream_t s, int ws_slot, const IgemmPool* pool, bool* pool_fused) {
   IgemmArgs a;
+  a.pool_out = nullptr; a.pool_idx = nullptr; a.pool_slope = nullptr; a.pool_scale = nullptr; a.Hp = a.Wp = 0;
+  if (pool_fused) *pool_fused = false;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.Mpad = conv_mpad(M);
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1; a.pad = pad;
@@ -607,16 +661,40 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   // 64-row tiles are 0-14% faster than 128-row tiles).  1x1 keeps 128 rows (large K chunks, LDS double buffer).
   static const int ig_bm128 = getenv("FRCNN_IG_BM128") ? atoi(getenv("FRCNN_IG_BM128")) : 0;
   const int BM = (a.Mpad == 64 || (k > 1 && !ig_bm128)) ? 64 : 128;
-  choose_tile(a.Ho, a.Wo, k, 64 * IG_NTW, &a.TH, &a.TW);
-  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
-  a.mTiles = a.Mpad / BM;
   const int cc = conv_cc(k);
   a.nChunks = cdiv(Cin, cc);
-  long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
+  a.mTiles = a.Mpad / BM;
   // split K until one wave of blocks fills the resident slots, keeping >= ~200 K rows per split
   const long slots = BM == 64 && k > 1 ? 256 * IG_BPC : 768;
   const int minChunks = k == 1 ? 2 : std::max(1, cdiv(200, cc * k * k));
-  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), 24), std::max(1, a.nChunks / minChunks));
+  auto splits_for = [&](long blocks) {
+    return (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), 24), std::max(1, a.nChunks / minChunks));
+  };
+  // fused max pool: needs the 4 x 32 tile (two rows per wave, neighbours in lane^1), 64-row M tiles, a plain store and
+  // a single K split (the pooled map is a function of the complete sum)
+  static const int ig_pool = getenv("FRCNN_IG_POOL") ? atoi(getenv("FRCNN_IG_POOL")) : 1;
+  bool fuse = false;
+  if (pool && ig_pool && k == 3 && BM == 64 && IG_NTW == 2 && out_mode == OUT_STORE && !getenv("FRCNN_IG_SPLITK")) {
+    const long blocks = (long)cdiv(a.Wo, 32) * cdiv(a.Ho, 4) * a.mTiles;
+    fuse = (Cin <= 4 ? 1 : splits_for(blocks)) == 1;
+    // ... and the fixed tile must not cost a round of blocks: 200x113 in 4x32 tiles is 812 blocks = up to 4 per CU where the
+    // free choice (760) needs 3 -- measured 305 us instead of 235 + 8.5 (pool) on that layer
+    int fth, ftw;
+    choose_tile(a.Ho, a.Wo, k, 64 * IG_NTW, &fth, &ftw);
+    const long free_blocks = (long)cdiv(a.Wo, ftw) * cdiv(a.Ho, fth) * a.mTiles;
+    if (cdivl(blocks, 256) > cdivl(free_blocks, 256)) fuse = false;
+  }
+  if (fuse) {
+    a.TH = 4; a.TW = 32;
+    a.pool_out = pool->out; a.pool_idx = pool->idx; a.pool_slope = pool->slope; a.pool_scale = pool->scale;
+    a.Hp = (a.Ho - 2 + 1) / 2 + 1; a.Wp = (a.Wo - 2 + 1) / 2 + 1;
+    if (pool_fused) *pool_fused = true;
+  } else {
+    choose_tile(a.Ho, a.Wo, k, 64 * IG_NTW, &a.TH, &a.TW);
+  }
+  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
+  long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
+  int splitK = splits_for(blocks);
   if (const char* e = getenv("FRCNN_IG_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);

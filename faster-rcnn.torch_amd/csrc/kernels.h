@@ -25,9 +25,14 @@ int conv_pack_weights_multi(const float* weights, const PackJob* jobs_dev, int n
 enum { OUT_STORE = 0, OUT_ADD = 1 };
 // out[M][Ho][Wo] (=|+=) conv(act(in)[Cin][H][W], wp) (+ bias).  act(x) = scale[c]*prelu(x, *slope)
 // when the pointers are non-null.  Ho = H + 2*pad - k + 1.
+// Optional `pool`: also produce maxpool_act_forward(out) (2x2, stride 2, ceil mode, act = scale[m] * prelu(., *slope)) from the
+// accumulators; *pool_fused tells whether the launch could do it (3x3, plain store, one K split) -- otherwise the caller
+// runs maxpool_act_forward itself.
+struct IgemmPool { float* out; unsigned char* idx; const float* slope; const float* scale; };
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
-               double algo_flops, hipStream_t s, int ws_slot = 0);  // ws_slot: split-K workspace (0 | 1)
+               double algo_flops, hipStream_t s, int ws_slot = 0,  // ws_slot: split-K workspace (0 | 1)
+               const IgemmPool* pool = nullptr, bool* pool_fused = nullptr);
 
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (split-K slabs in `ws`, folded in a fixed order)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.

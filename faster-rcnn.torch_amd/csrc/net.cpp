@@ -483,17 +483,23 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
   const float* cur_scale = nullptr;
   for (size_t b = 0; b < m->blocks.size(); ++b) {
     Block& blk = m->blocks[b];
+    bool pooled_in_conv = false;
     for (int st = 0; st < blk.nconv; ++st) {
       Conv& c = m->convs[blk.first_conv + st];
+      const bool last = st == blk.nconv - 1;
+      // the block's max pool rides in the epilogue of its last convolution when that launch is a single K split
+      IgemmPool pl = {blk.pooled.f(), (unsigned char*)blk.pidx.p, w + c.a_off,
+                      (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
       FR_TRY(conv_igemm(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wf.f(), w + c.b_off, c.Cout, c.k, c.pad,
-                        c.x.f(), OUT_STORE, 0, s));
+                        c.x.f(), OUT_STORE, 0, s, 0, last ? &pl : nullptr, last ? &pooled_in_conv : nullptr));
       cur = c.x.f();
       cur_slope = w + c.a_off;
       cur_scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;  // model_utilities.lua:20
     }
     const Conv& lc = m->convs[blk.first_conv + blk.nconv - 1];
-    FR_TRY(maxpool_act_forward(cur, lc.Cout, lc.Ho, lc.Wo, cur_slope, cur_scale, blk.pooled.f(),
-                               (unsigned char*)blk.pidx.p, s));
+    if (!pooled_in_conv)
+      FR_TRY(maxpool_act_forward(cur, lc.Cout, lc.Ho, lc.Wo, cur_slope, cur_scale, blk.pooled.f(),
+                                 (unsigned char*)blk.pidx.p, s));
     cur = blk.pooled.f();
     cur_slope = nullptr;
     cur_scale = nullptr;
