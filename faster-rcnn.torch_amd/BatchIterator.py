@@ -11,6 +11,7 @@ Differences that are stated rather than hidden:
   * `math.random` is LuaJIT's own PRNG (not reproducible outside LuaJIT): every draw comes from the MT19937
     stream also used for torch.random / torch.randperm (same substitution as Anchors.sampleNegative).
 The sequence of draws follows the reference line by line (BatchIterator.lua:112-143, :7-25)."""
+import copy
 import ctypes as C
 import math
 import sys
@@ -59,6 +60,15 @@ class _Ring(object):
         i = self.pos.get(shape, 0)
         self.pos[shape] = (i + 1) % self.depth
         return lst[i]
+
+
+def _copy_rois(rois):  # deep_copy(self.ground_truth[fn].rois) (BatchIterator.lua:172): the rects are rewritten below
+    out = []
+    for r in rois:
+        c = copy.copy(r)
+        c.rect = r.rect.clone()
+        out.append(c)
+    return out
 
 
 def _transform_rois(rois, froi, old_w, old_h, new_w, new_h):  # BatchIterator.lua:27-47 (the roi half)
@@ -204,7 +214,7 @@ class BatchIterator(object):
 
         def try_add_next():
             fn = self._next_entry(self.training)
-            rois = [type(r)(r.rect.clone(), r.class_index) for r in self.ground_truth[fn]["rois"]]   # deep_copy (:172)
+            rois = _copy_rois(self.ground_truth[fn]["rois"])
             img = checked_load(fn, "training")
             if img is None:
                 return 0
@@ -249,7 +259,7 @@ class BatchIterator(object):
                 continue
             if len(img.shape) != 3 or img.shape[0] != 3:
                 continue
-            rois = [type(r)(r.rect.clone(), r.class_index) for r in self.ground_truth[fn]["rois"]]
+            rois = _copy_rois(self.ground_truth[fn]["rois"])
             img, rois = self.processImage(img, rois)
             _, h, w = img.shape
             if h < 128 or w < 128:

@@ -13,7 +13,7 @@ from .model_utilities import create_model
 from .nms import nms
 from .objective import allreduce_begin, allreduce_begin_rest, allreduce_gradient_and_stats, create_objective, extract_roi_pooling_input, roi_window, roi_windows
 from .Rect import Rect
-from . import t7
+from . import t7, traindata
 from .t7 import load_obj, restore_weights, save_model, save_obj
 from .synthetic import Roi, SyntheticBatchIterator, assemble_examples, clean_examples, output_map_sizes, synthetic_image, synthetic_rois
 from .tensor import DeviceTensor, ptr, stream_ptr, to_device
@@ -21,6 +21,6 @@ from .utilities import combine_and_flatten_parameters, rmsprop
 from .vgg_large import vgg_large
 from .vgg_small import vgg_small
 
-__all__ = ["t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
+__all__ = ["traindata", "t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
            "create_model", "create_objective", "duplo_cfg", "extract_roi_pooling_input", "imgnet_cfg", "manualSeed", "nms",
            "rmsprop", "roi_window", "roi_windows", "vgg_large", "vgg_small"]

@@ -117,6 +117,16 @@ class Writer(object):
             self.int(TYPE_STRING); self.string(o)
         elif isinstance(o, np.ndarray):
             self.tensor(o)
+        elif type(o).__name__ == "Rect" and hasattr(o, "minX") or isinstance(o, T7Object):
+            cls = "Rect" if not isinstance(o, T7Object) else o.torch_class
+            fields = dict(o) if isinstance(o, T7Object) else dict(minX=o.minX, minY=o.minY, maxX=o.maxX, maxY=o.maxY)
+            self.int(TYPE_TORCH)
+            idx, first = self._index(o)
+            self.int(idx)
+            if first:
+                self.string("V 1"); self.string(cls)
+                self.keep.append(fields)
+                self.object(fields)
         elif isinstance(o, (dict, list, tuple)):
             self.int(TYPE_TABLE)
             idx, first = self._index(o)
@@ -228,11 +238,30 @@ class Reader(object):
                 else:
                     a = np.lib.stride_tricks.as_strided(st[off:], shape=tuple(int(s) for s in size),
                                                         strides=tuple(int(s) * st.itemsize for s in stride)).copy()
-            else:
+            elif cls.startswith("torch.") or cls.startswith("nn.") or cls.startswith("cudnn."):
                 raise ValueError("t7: unsupported class '%s'" % cls)
+            else:
+                # a torch.class object without a write() method (e.g. the reference's `Rect`, Rect.lua:5): File.lua
+                # serialises the object's fields as one table
+                fields = self.object()
+                a = _make_object(cls, fields)
             self.objects[idx] = a
             return a
         raise ValueError("t7: unknown type tag %d" % t)
+
+
+class T7Object(dict):
+    """Fields of a torch.class object of an unknown class (`.torch_class` holds its name)."""
+    torch_class = None
+
+
+def _make_object(cls, fields):
+    if cls == "Rect" and isinstance(fields, dict) and all(k in fields for k in ("minX", "minY", "maxX", "maxY")):
+        from .Rect import Rect
+        return Rect(fields["minX"], fields["minY"], fields["maxX"], fields["maxY"])
+    o = T7Object(fields if isinstance(fields, dict) else {"value": fields})
+    o.torch_class = cls
+    return o
 
 
 def save_obj(file_name, obj, ascii=True):  # utilities.lua:113-117 (ASCII is DiskFile's default mode)

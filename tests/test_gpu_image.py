@@ -211,3 +211,33 @@ def test_next_training_batches(F, small_cfg):
     f = F.create_objective(model, w, g, make(5), stats)
     loss, grad = f(w)
     assert np.isfinite(loss) and bool(grad.isfinite().all())
+
+
+def test_training_data_file_feeds_batch_iterator(F, small_cfg, tmp_path):
+    """The whole loader chain of SURVEY 8f: boxes.csv -> create_training_data -> torch object file -> load_training_data
+    -> BatchIterator.nextTraining (frames decoded elsewhere) -> lossAndGradient."""
+    rng = np.random.RandomState(11)
+    rows = []
+    frames = {}
+    for i in range(4):
+        name = "img%d.png" % i
+        frames[name] = rng.rand(3, 540, 960).astype(np.float32)
+        for j in range(2):
+            x0, y0 = 100 + 200 * j + 10 * i, 80 + 60 * j
+            rows.append('"%s", %d, %d, %d, %d, "Brick%d", %d, "Red", 4' % (name, x0, y0, x0 + 220, y0 + 200, j, j + 1))
+    (tmp_path / "boxes.csv").write_text("\n".join(rows) + "\n")
+    fn = str(tmp_path / "duplo.t7")
+    F.traindata.create_training_data("unit", str(tmp_path / "boxes.csv"), None, fn, validation_size=1, seed=2)
+    data = F.traindata.load_training_data(fn)
+    assert len(data["training_set"]) == 3 and len(data["validation_set"]) == 1
+    model = F.vgg_small(small_cfg)
+    it = F.BatchIterator(model, data, load_image=lambda f: frames[f], seed=4)
+    batch = it.nextTraining(64)
+    assert batch and all(x["img"].shape == (3, 450, 800) for x in batch) and sum(len(x["positive"]) for x in batch) > 0
+    assert all(p[1].class_index in (1, 2) for x in batch for p in x["positive"])
+    w, g = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=1)
+    f = F.create_objective(model, w, g, F.BatchIterator(model, data, load_image=lambda f: frames[f], seed=4),
+                           dict(pcls=[], preg=[], dcls=[], dreg=[]))
+    small_cfg2 = dict(small_cfg)
+    loss, grad = f(w)
+    assert np.isfinite(loss) and bool(grad.isfinite().all())
