@@ -48,6 +48,9 @@ void prof_after(int klass, double flops, double bytes, hipStream_t s) {
 
 using namespace frcnn;
 
+static_assert(frcnn::KC_COUNT == FRCNN_KC_COUNT && frcnn::KC_IMAGE == FRCNN_KC_IMAGE && frcnn::KC_OPTIM == FRCNN_KC_OPTIM &&
+              frcnn::KC_CONV_IGEMM_K3 == FRCNN_KC_CONV_IGEMM_K3, "kernel classes of common.h and frcnn_hip.h differ");
+
 extern "C" {
 
 int frcnn_version(void) { return 100; }

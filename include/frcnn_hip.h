@@ -68,7 +68,8 @@ int frcnn_scale(float *x, long long n, float s, void *stream);    /* gradient:di
 #define FRCNN_KC_RPN 7
 #define FRCNN_KC_NMS 8
 #define FRCNN_KC_OPTIM 9
-#define FRCNN_KC_COUNT 10
+#define FRCNN_KC_IMAGE 10
+#define FRCNN_KC_COUNT 11
 /* class_mask: bit k set -> every launch of kernel class k is bracketed by two hipEvents on its
  * launch stream (0 = profiling off). */
 int frcnn_prof_enable(int class_mask);

@@ -64,3 +64,15 @@ def test_lua_binding_in_sync_with_header():
     assert declared == set(_header_symbols())
     used = set(re.findall(r"C\.(frcnn_[a-z0-9_]+)", lua))
     assert used <= declared, used - declared
+
+
+def test_kernel_class_table_matches_header():
+    """frcnn_prof_collect fills FRCNN_KC_COUNT entries: the header's constants and the Python name table must agree."""
+    import re
+    from frcnn_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    consts = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"#define FRCNN_KC_(\w+) (\d+)", hdr))
+    count = consts.pop("COUNT")
+    assert count == len(_lib.KC_NAMES) == len(consts)
+    for name, idx in consts.items():
+        assert _lib.KC_NAMES[idx].upper() == name, (name, idx, _lib.KC_NAMES[idx])
