@@ -5,15 +5,16 @@ kernel (frcnn_image_*: rgb2yuv, image.scale, crop + flips, per-channel centring 
 normalisation of the luminance channel), so the frame is never touched by the host again before pnet:forward.
 
 Differences that are stated rather than hidden:
-  * no image codec in this environment: `load_image(fn)` is a callable supplied by the user that returns the
-    DECODED float RGB frame [3][H][W] in 0..1 (what image.load(fn, 3, 'float') returns); the default reads
-    `.npy` files.  Only color_space 'yuv' (both shipped configs) and 'rgb' are implemented.
+  * decoding stays on the host: `load_image(fn)` is a callable that returns the DECODED float RGB frame [3][H][W] in
+    0..1 (what image.load(fn, 3, 'float') returns); the default decodes with Pillow (`.npy` arrays are read as they
+    are).  Only color_space 'yuv' (both shipped configs) and 'rgb' are implemented.
   * `math.random` is LuaJIT's own PRNG (not reproducible outside LuaJIT): every draw comes from the MT19937
     stream also used for torch.random / torch.randperm (same substitution as Anchors.sampleNegative).
 The sequence of draws follows the reference line by line (BatchIterator.lua:112-143, :7-25)."""
 import copy
 import ctypes as C
 import math
+import os
 import sys
 
 import numpy as np
@@ -43,6 +44,21 @@ def gaussian1D(size, sigma=0.25, amplitude=1.0, mean=0.5):
     center = mean * size + 0.5
     return np.array([amplitude * math.exp(-(((i - center) / (sigma * size)) ** 2) / 2) for i in range(1, size + 1)],
                     dtype=np.float32)
+
+
+def decode_image(fn):
+    """image.load(fn, 3, 'float') (utilities.lua load_image): the decoded frame as float RGB [3][H][W] in 0..1.
+    `.npy` files hold that array directly; everything else goes through Pillow (8-bit samples / 255, grey and
+    palette images expanded to three channels, alpha dropped -- what image.load does for depth 3)."""
+    if fn.lower().endswith(".npy"):
+        return np.load(fn)
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise _lib.FrcnnError("decoding '%s' needs Pillow (or pass load_image=... / use .npy frames): %s" % (fn, e))
+    with Image.open(fn) as im:
+        a = np.asarray(im.convert("RGB"), dtype=np.float32) * np.float32(1.0 / 255.0)
+    return np.ascontiguousarray(a.transpose(2, 0, 1))
 
 
 class _Ring(object):
@@ -102,7 +118,8 @@ class BatchIterator(object):
         self.kernel = gaussian1D(nz["width"]) if nz.get("method") == "contrastive" else None  # :88-92
         self.anchors = Anchors(model["pnet"], cfg["scales"])
         self.rng = MT19937(seed)
-        self.load_image_fn = load_image or (lambda fn: np.load(fn))
+        base = cfg.get("examples_base_path") or ""
+        self.load_image_fn = load_image or (lambda fn: decode_image(fn if os.path.isabs(fn) or not base else os.path.join(base, fn)))
         self.training = dict(order=[], list=list(training_data["training_set"]))
         self.validation = dict(order=[], list=list(training_data.get("validation_set", [])))
         self.background = dict(order=[], list=list(training_data.get("background_files") or []))

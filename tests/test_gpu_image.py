@@ -241,3 +241,25 @@ def test_training_data_file_feeds_batch_iterator(F, small_cfg, tmp_path):
     small_cfg2 = dict(small_cfg)
     loss, grad = f(w)
     assert np.isfinite(loss) and bool(grad.isfinite().all())
+
+
+def test_batch_iterator_decodes_image_files(F, small_cfg, tmp_path):
+    """Default loader: PNG files under cfg.examples_base_path are decoded on the host (Pillow), everything after that
+    runs on the device; the prepared frame equals the oracle's processImage of the decoded pixels."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(13)
+    px = rng.randint(0, 256, size=(270, 480, 3)).astype(np.uint8)
+    Image.fromarray(px).save(str(tmp_path / "frame.png"))
+    cfg = dict(small_cfg); cfg["examples_base_path"] = str(tmp_path)
+    cfg["augmentation"] = dict(vflip=0, hflip=0, random_scaling=0.0, aspect_jitter=0.0)
+    model = F.vgg_small(cfg)
+    data = dict(ground_truth={"frame.png": dict(rois=[F.Roi(F.Rect(40, 30, 200, 150), 1)])}, training_set=["frame.png"],
+                validation_set=["frame.png"], background_files=[])
+    it = F.BatchIterator(model, data)
+    val = it.nextValidation(1)
+    img = val[0]["img"]
+    want = OI.process_image(OI.rgb2yuv((px.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1)), cfg)
+    assert img.shape == want.shape == (3, 450, 800)
+    assert_close(img.numpy(), want, 2e-5, "decoded + prepared frame")
+    r = val[0]["rois"][0].rect
+    assert np.allclose([r.minX, r.minY, r.maxX, r.maxY], [40 * 800 / 480, 30 * 450 / 270, 200 * 800 / 480, 150 * 450 / 270])

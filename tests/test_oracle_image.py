@@ -128,3 +128,21 @@ def test_randperm_is_a_permutation_and_seeded():
     assert MT19937(3).randperm(1) == [1]
     u = [MT19937(5).uniform() for _ in range(3)]
     assert all(0.0 <= v < 1.0 for v in u)
+
+
+def test_decode_image(tmp_path):
+    """image.load(fn, 3, 'float'): 8-bit samples / 255 as float RGB planes; grey images expanded; .npy passed through."""
+    import pytest
+    Image = pytest.importorskip("PIL.Image")
+    from frcnn_amd import decode_image
+    rng = np.random.RandomState(3)
+    px = rng.randint(0, 256, size=(7, 9, 3)).astype(np.uint8)
+    Image.fromarray(px).save(str(tmp_path / "a.png"))
+    a = decode_image(str(tmp_path / "a.png"))
+    assert a.shape == (3, 7, 9) and a.dtype == np.float32
+    assert np.array_equal(a, (px.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1))
+    Image.fromarray(px[:, :, 0]).save(str(tmp_path / "g.png"))
+    g = decode_image(str(tmp_path / "g.png"))
+    assert g.shape == (3, 7, 9) and np.array_equal(g[0], g[1]) and np.array_equal(g[1], g[2])
+    np.save(str(tmp_path / "f.npy"), a)
+    assert np.array_equal(decode_image(str(tmp_path / "f.npy")), a)
