@@ -119,6 +119,27 @@ class Anchors(object):
                         found.append(self.get(y[0], y[1], y[2], x[2]))
         return found
 
+    def findNearbyArrays(self, centerX, centerY):
+        """findNearby as arrays, in the same order: meta int[n][4] = (layer, aspect, y, x) 1-based and rects float64[n][4]
+        = (minX, minY, maxX, maxY).  Cached per pair of bins (the anchors of a bin pair never change)."""
+        key = (math.floor(centerX / BIN_SIZE), math.floor(centerY / BIN_SIZE))
+        cache = self.__dict__.setdefault("_nearby_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            xl = self.cx.get(key[0]); yl = self.cy.get(key[1])
+            meta = []
+            if xl and yl:
+                for y in yl:
+                    for x in xl:
+                        if y[0] == x[0] and y[1] == x[1]:
+                            meta.append((y[0], y[1], y[2], x[2]))
+            meta = np.array(meta, dtype=np.int64).reshape(-1, 4)
+            w, h = self._w64, self._h64
+            li, ai, yi, xi = meta[:, 0] - 1, meta[:, 1] - 1, meta[:, 2] - 1, meta[:, 3] - 1
+            rects = np.stack([w[li, ai, xi, 0], h[li, ai, yi, 0], w[li, ai, xi, 1], h[li, ai, yi, 1]], 1) if len(meta) else np.zeros((0, 4))
+            hit = cache[key] = (meta, rects)
+        return hit
+
     def findRangesXY(self, rect, clip_rect=None):  # Anchors.lua:86-145
         def lower_bound(t, value):  # first index (1-based) with t >= value
             return int(np.searchsorted(t, value, side="left")) + 1
@@ -152,6 +173,11 @@ class Anchors(object):
             garea = g.area()
             for r in self.findRangesXY(g, clip_rect):
                 xs, ys = r["xs"], r["ys"]
+                # every anchor of a (layer, aspect) range has the same size, and IoU <= min(area) / max(area): ranges whose
+                # anchors are too small or too large to pass the lower threshold cannot contribute (exact pruning)
+                a0 = (xs[0, 1] - xs[0, 0]) * (ys[0, 1] - ys[0, 0])
+                if min(a0, garea) < max(a0, garea) * min(pos_threshold, neg_threshold) * (1.0 - 1e-9):
+                    continue
                 # Rect.IoU(roi.rect, anchor) for the whole candidate grid, same operation order
                 ix = np.minimum(g.maxX, xs[None, :, 1]) - np.maximum(g.minX, xs[None, :, 0])
                 iy = np.minimum(g.maxY, ys[:, None, 1]) - np.maximum(g.minY, ys[:, None, 0])

@@ -61,6 +61,69 @@ def decode_image(fn):
     return np.ascontiguousarray(a.transpose(2, 0, 1))
 
 
+def decode_image_u8(fn):
+    """The decoder's own output: 8-bit interleaved RGB [H][W][3] (the device converts it, frcnn_image_scale_u8)."""
+    from PIL import Image
+    with Image.open(fn) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+
+
+class _U8Frame(object):
+    """A decoded frame in HBM as 8-bit interleaved RGB; `event` marks the end of its upload on the copy stream."""
+
+    def __init__(self, dev, H, W, event):
+        self.dev, self.event = dev, event
+        self.shape = (3, H, W)
+
+
+class _DecodeAhead(object):
+    """Worker threads decode upcoming files (Pillow releases the GIL while it decodes) and upload the 8-bit frames
+    through pinned buffers on a copy stream of their own; the consumer only ever waits for an event.  At 200+ images/s
+    per GPU a single-threaded decode (10-20 ms per 1080p JPEG) would otherwise be the bottleneck of the step."""
+
+    def __init__(self, workers, resolve):
+        import concurrent.futures
+        import threading
+        import torch
+        self.torch = torch
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+        self.copy_stream = torch.cuda.Stream()
+        self.resolve = resolve
+        self.jobs = {}
+        self.lock = threading.Lock()
+        self.pinned = {}
+
+    def _pinned(self, shape):
+        with self.lock:
+            lst = self.pinned.setdefault(shape, [])
+            if lst:
+                return lst.pop()
+        return self.torch.empty(shape, dtype=self.torch.uint8).pin_memory()
+
+    def _work(self, fn):
+        torch = self.torch
+        a = decode_image_u8(self.resolve(fn))
+        pin = self._pinned(a.shape)
+        pin.numpy()[...] = a
+        with torch.cuda.stream(self.copy_stream):
+            dev = torch.empty(a.shape, dtype=torch.uint8, device="cuda")
+            dev.copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        ev.synchronize()            # (worker thread: the pinned buffer may be reused once the copy has landed)
+        with self.lock:
+            self.pinned[a.shape].append(pin)
+        return _U8Frame(dev, a.shape[0], a.shape[1], ev)
+
+    def request(self, fn):
+        if fn not in self.jobs:
+            self.jobs[fn] = self.pool.submit(self._work, fn)
+
+    def get(self, fn):
+        self.request(fn)
+        return self.jobs.pop(fn).result()
+
+
 class _Ring(object):
     """Device buffers recycled per shape (hipMalloc is synchronous): the last `depth` results of a shape stay
     valid, older ones are overwritten -- enough for the images of a few batches in flight."""
@@ -110,7 +173,9 @@ class _RgbFrame(object):
 
 
 class BatchIterator(object):
-    def __init__(self, model, training_data, load_image=None, seed=5489, ring=32):  # BatchIterator.lua:82-99
+    def __init__(self, model, training_data, load_image=None, seed=5489, ring=32, workers=0, prefetch=8):
+        # BatchIterator.lua:82-99.  workers > 0 (default loader only): image files are decoded `prefetch` entries ahead by
+        # a pool of threads and uploaded as 8-bit frames (see _DecodeAhead)
         cfg = model["cfg"]
         self.cfg = cfg
         self.ground_truth = training_data["ground_truth"]
@@ -124,6 +189,10 @@ class BatchIterator(object):
         self.validation = dict(order=[], list=list(training_data.get("validation_set", [])))
         self.background = dict(order=[], list=list(training_data.get("background_files") or []))
         self._randomize_order(self.training, self.validation, self.background)
+        self.ahead = None
+        if workers > 0 and load_image is None:
+            self.ahead = _DecodeAhead(workers, lambda fn: fn if os.path.isabs(fn) or not base else os.path.join(base, fn))
+            self.prefetch = prefetch
         self.ring = _Ring(ring)
         self.scratch = {}
         self.log = lambda msg: None   # the reference prints one line per image (:249); silent by default
@@ -140,6 +209,9 @@ class BatchIterator(object):
             self._randomize_order(s)
         fn = s["list"][s["order"][s["i"] - 1] - 1]
         s["i"] += 1
+        if self.ahead is not None:   # decode the following entries of this epoch's order ahead of time (no RNG involved)
+            for k in range(s["i"], min(s["i"] + self.prefetch, len(s["list"]) + 1)):
+                self.ahead.request(s["list"][s["order"][k - 1] - 1])
         return fn
 
     def _tmp(self, name, n):
@@ -150,6 +222,11 @@ class BatchIterator(object):
 
     # ---- utilities.lua load_image: decoded RGB frame -> device, colour space conversion
     def load_image(self, fn, materialize=False):
+        if self.ahead is not None and not materialize:
+            cs = self.cfg.get("color_space", "rgb")
+            if cs not in ("yuv", "rgb"):
+                raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
+            return self.ahead.get(fn)
         img = to_device(self.load_image_fn(fn))
         if len(img.shape) != 3 or img.shape[0] != 3:
             return img   # the caller reports the unexpected channel count (:185-188)
@@ -167,8 +244,10 @@ class BatchIterator(object):
     # ---- BatchIterator.lua:101-164
     def processImage(self, img, rois=None):
         cfg, aug, s = self.cfg, self.cfg["augmentation"], stream_ptr()
+        u8 = img if isinstance(img, _U8Frame) else None
         to_yuv = isinstance(img, _RgbFrame)
-        img = img.rgb if to_yuv else to_device(img)
+        if u8 is None:
+            img = img.rgb if to_yuv else to_device(img)
         Cn, H, W = img.shape
         tw, th = find_target_size(W, H, cfg["target_smaller_side"], cfg["max_pixel_size"])
         scale_X, scale_Y = tw / W, th / H
@@ -178,8 +257,15 @@ class BatchIterator(object):
         # scale (:117, :49-55): the destination size is truncated by the tensor constructor
         sw, sh = int(max(1, W * scale_X)), int(max(1, H * scale_Y))
         cur = self.ring.get((Cn, sh, sw))
-        _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
-                  int(to_yuv), s)
+        if u8 is not None:   # 8-bit frame from the decode-ahead pool: float conversion (+ yuv) fused into the row pass
+            import torch
+            torch.cuda.current_stream().wait_event(u8.event)
+            _lib.call("frcnn_image_scale_u8", ptr(u8.dev), H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
+                      int(cfg.get("color_space", "rgb") == "yuv"), s)
+            u8.dev.record_stream(torch.cuda.current_stream())
+        else:
+            _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
+                      int(to_yuv), s)
         rois = _transform_rois(rois, lambda r, w, h: r.scale(scale_X, scale_Y), W, H, sw, sh)
         # crop to the target size if a dimension was up-sampled beyond it (:119-130)
         cw, ch, x0, y0 = sw, sh, 0, 0

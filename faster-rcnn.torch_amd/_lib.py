@@ -93,6 +93,7 @@ _SIGS = {
     "frcnn_cnet_decode": ([vp, C.c_int, C.c_int, vp, vp, vp], C.c_int),
     "frcnn_image_rgb2yuv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
     "frcnn_image_scale": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
+    "frcnn_image_scale_u8": ([vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
     "frcnn_image_crop_flip": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
     "frcnn_image_normalize_workspace_bytes": ([C.c_int], C.c_size_t),
     "frcnn_image_normalize": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp], C.c_int),

@@ -285,6 +285,10 @@ int frcnn_image_scale(const float* src, int C, int H, int W, float* dst, int dH,
                       void* stream) {
   return image_scale(src, C, H, W, dst, dH, dW, tmp, rgb2yuv, S(stream));
 }
+int frcnn_image_scale_u8(const unsigned char* src_hwc, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
+                         void* stream) {
+  return image_scale_u8(src_hwc, H, W, dst, dH, dW, tmp, rgb2yuv, S(stream));
+}
 int frcnn_image_crop_flip(const float* src, int C, int H, int W, int x0, int y0, int w, int h, int hflip, int vflip,
                           float* dst, void* stream) {
   return image_crop_flip(src, C, H, W, x0, y0, w, h, hflip, vflip, dst, S(stream));

@@ -87,13 +87,29 @@ __global__ void scale_axis_kernel(const float* __restrict__ src, float* __restri
 
 // The row pass with image.rgb2yuv applied to every source sample on the fly (same arithmetic as rgb2yuv_kernel, so
 // the result equals converting first): one thread produces the three channels of one output sample.
-__device__ __forceinline__ void yuv_at(const float* __restrict__ r, long hw, long i, float* o) {
-  const float R = r[i], G = r[hw + i], B = r[2 * hw + i];
-  o[0] = 0.299f * R + 0.587f * G + 0.114f * B;
-  o[1] = -0.14713f * R - 0.28886f * G + 0.436f * B;
-  o[2] = 0.615f * R - 0.51499f * G - 0.10001f * B;
+// SRC 0: planar float RGB [3][H][W];  SRC 1: interleaved 8-bit RGB [H][W][3] as decoders deliver it, converted with
+// v * (1/255) exactly like image.load(fn, 3, 'float').  YUV 0: the sample stays RGB.
+template <int SRC, int YUV>
+__device__ __forceinline__ void yuv_at(const void* __restrict__ src, long hw, long i, float* o) {
+  float R, G, B;
+  if (SRC == 0) {
+    const float* r = (const float*)src;
+    R = r[i]; G = r[hw + i]; B = r[2 * hw + i];
+  } else {
+    const unsigned char* u = (const unsigned char*)src + 3 * i;
+    const float k = 1.0f / 255.0f;
+    R = (float)u[0] * k; G = (float)u[1] * k; B = (float)u[2] * k;
+  }
+  if (YUV) {
+    o[0] = 0.299f * R + 0.587f * G + 0.114f * B;
+    o[1] = -0.14713f * R - 0.28886f * G + 0.436f * B;
+    o[2] = 0.615f * R - 0.51499f * G - 0.10001f * B;
+  } else {
+    o[0] = R; o[1] = G; o[2] = B;
+  }
 }
-__global__ void scale_rows_rgb2yuv_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int dW) {
+template <int SRC, int YUV>
+__global__ void scale_rows_rgb2yuv_kernel(const void* __restrict__ src, float* __restrict__ dst, int H, int W, int dW) {
   const long total = (long)H * dW, hw = (long)H * W, ohw = (long)H * dW;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int d = (int)(t % dW);
@@ -101,14 +117,14 @@ __global__ void scale_rows_rgb2yuv_kernel(const float* __restrict__ src, float* 
     float v[3], a[3], b[3];
     if (dW > W) {
       if (W == 1 || d == dW - 1) {
-        yuv_at(src, hw, row + W - 1, v);
+        yuv_at<SRC, YUV>(src, hw, row + W - 1, v);
       } else {
         const float scale = (float)(W - 1) / (float)(dW - 1);
         float sf = (float)d * scale;
         const long si = (long)sf;
         sf -= (float)si;
-        yuv_at(src, hw, row + si, a);
-        yuv_at(src, hw, row + si + 1, b);
+        yuv_at<SRC, YUV>(src, hw, row + si, a);
+        yuv_at<SRC, YUV>(src, hw, row + si + 1, b);
         for (int c = 0; c < 3; ++c) v[c] = (1.f - sf) * a[c] + sf * b[c];
       }
     } else if (dW < W) {
@@ -119,22 +135,22 @@ __global__ void scale_rows_rgb2yuv_kernel(const float* __restrict__ src, float* 
       float s1f = (float)(d + 1) * scale;
       const long s1 = (long)s1f;
       s1f -= (float)s1;
-      yuv_at(src, hw, row + s0, a);
+      yuv_at<SRC, YUV>(src, hw, row + s0, a);
       float acc[3] = {(1.f - s0f) * a[0], (1.f - s0f) * a[1], (1.f - s0f) * a[2]};
       float n = 1.f - s0f;
       for (long si = s0 + 1; si < s1; ++si) {
-        yuv_at(src, hw, row + si, a);
+        yuv_at<SRC, YUV>(src, hw, row + si, a);
         for (int c = 0; c < 3; ++c) acc[c] += a[c];
         n += 1.f;
       }
       if (s1 < W) {
-        yuv_at(src, hw, row + s1, a);
+        yuv_at<SRC, YUV>(src, hw, row + s1, a);
         for (int c = 0; c < 3; ++c) acc[c] += s1f * a[c];
         n += s1f;
       }
       for (int c = 0; c < 3; ++c) v[c] = acc[c] / n;
     } else {
-      yuv_at(src, hw, row + d, v);
+      yuv_at<SRC, YUV>(src, hw, row + d, v);
     }
     for (int c = 0; c < 3; ++c) dst[c * ohw + t] = v[c];
   }
@@ -147,8 +163,8 @@ int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int d
   if (rgb2yuv) {
     const long total = (long)H * dW;
     int grid = (int)std::min<long>(cdivl(total, 256), 8192);
-    FR_LAUNCH(KC_IMAGE, 0, ((double)C * H * W + C * total) * 4.0, s, scale_rows_rgb2yuv_kernel, dim3(grid), dim3(256), 0, src,
-              tmp, H, W, dW);
+    FR_LAUNCH(KC_IMAGE, 0, ((double)C * H * W + C * total) * 4.0, s, (scale_rows_rgb2yuv_kernel<0, 1>), dim3(grid), dim3(256), 0,
+              (const void*)src, tmp, H, W, dW);
     FR_LAUNCH_CHECK();
   } else
   // rows: [C*H][W] -> [C*H][dW]
@@ -165,6 +181,32 @@ int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int d
     int grid = (int)std::min<long>(cdivl(total, 256), 8192);
     FR_LAUNCH(KC_IMAGE, 0, ((double)C * H * dW + total) * 4.0, s, scale_axis_kernel, dim3(grid), dim3(256), 0,
               (const float*)tmp, dst, (long)C, H, dH, (long)dW);
+    FR_LAUNCH_CHECK();
+  }
+  return FRCNN_OK;
+}
+
+// The same two passes for a frame that is still the decoder's 8-bit interleaved RGB: the conversion to float (and to
+// YUV when asked) happens on the fly in the row pass -- 6 MB instead of 25 MB cross PCIe and no full-resolution
+// float frame is ever written.
+int image_scale_u8(const unsigned char* src_hwc, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
+                   hipStream_t s) {
+  FR_CHECK(H > 0 && W > 0 && dH > 0 && dW > 0, "image_scale_u8: empty image (%dx%d -> %dx%d)", H, W, dH, dW);
+  {
+    const long total = (long)H * dW;
+    int grid = (int)std::min<long>(cdivl(total, 256), 8192);
+    const double bytes = 3.0 * H * W + 12.0 * total;
+    if (rgb2yuv)
+      FR_LAUNCH(KC_IMAGE, 0, bytes, s, (scale_rows_rgb2yuv_kernel<1, 1>), dim3(grid), dim3(256), 0, (const void*)src_hwc, tmp, H, W, dW);
+    else
+      FR_LAUNCH(KC_IMAGE, 0, bytes, s, (scale_rows_rgb2yuv_kernel<1, 0>), dim3(grid), dim3(256), 0, (const void*)src_hwc, tmp, H, W, dW);
+    FR_LAUNCH_CHECK();
+  }
+  {
+    const long total = 3L * dH * dW;
+    int grid = (int)std::min<long>(cdivl(total, 256), 8192);
+    FR_LAUNCH(KC_IMAGE, 0, (3.0 * H * dW + total) * 4.0, s, scale_axis_kernel, dim3(grid), dim3(256), 0, (const float*)tmp, dst, 3L,
+              H, dH, (long)dW);
     FR_LAUNCH_CHECK();
   }
   return FRCNN_OK;

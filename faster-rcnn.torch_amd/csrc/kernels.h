@@ -132,6 +132,9 @@ int image_rgb2yuv(const float* rgb, float* yuv, int H, int W, hipStream_t s);
 // image.scale 'bilinear': src [C][H][W] -> dst [C][dH][dW]; tmp holds C*H*dW floats
 int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
                 hipStream_t s);
+// the same for the decoder's 8-bit interleaved RGB frame [H][W][3] (converted with v/255, optionally to YUV, on the fly)
+int image_scale_u8(const unsigned char* src_hwc, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
+                   hipStream_t s);
 // dst [C][h][w] = flips(crop(src, x0, y0, w, h))
 int image_crop_flip(const float* src, int C, int H, int W, int x0, int y0, int w, int h, int hflip, int vflip,
                     float* dst, hipStream_t s);

@@ -46,12 +46,26 @@ def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16):
     negative = anchors.sampleNegative(img_rect, rois, cfg["negative_threshold"], negatives, rng)
     count = len(positive) + len(negative)
     if cfg.get("nearby_aversion"):
+        # every anchor that shares a bin pair with a positive's centre and overlaps it by less than the negative threshold
+        # (BatchIterator.lua:204-216).  Vectorised: the candidates of all positives in one IoU evaluation (Rect.IoU's
+        # arithmetic in float64, candidates in the order of the nested Lua loops); Rect objects are only built for the
+        # few candidates that survive the shuffle.
         nearby = []
-        for p in positive:
-            cx, cy = p[0].center()
-            for a in anchors.findNearby(cx, cy):
-                if Rect.IoU(p[0], a) < cfg["negative_threshold"]:
-                    nearby.append((a,))
+        if positive:
+            parts = [anchors.findNearbyArrays(*p[0].center()) for p in positive]
+            cnt = np.array([len(m) for m, _ in parts])
+            if cnt.sum():
+                M = np.concatenate([m for m, _ in parts]); R = np.concatenate([r for _, r in parts])
+                P = np.repeat(np.array([(p[0].minX, p[0].minY, p[0].maxX, p[0].maxY) for p in positive], dtype=np.float64), cnt, axis=0)
+                minx = np.maximum(P[:, 0], R[:, 0]); miny = np.maximum(P[:, 1], R[:, 1])
+                maxx = np.minimum(P[:, 2], R[:, 2]); maxy = np.minimum(P[:, 3], R[:, 3])
+                ok = (maxx >= minx) & (maxy >= miny)
+                inter = np.where(ok, (maxx - minx) * (maxy - miny), 0.0)
+                area = lambda A: (A[:, 2] - A[:, 0]) * (A[:, 3] - A[:, 1])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    iou = inter / (area(P) + area(R) - inter)
+                Mk = M[iou < cfg["negative_threshold"]]
+                nearby = list(range(len(Mk)))   # (the shuffle permutes positions; the rows are looked up afterwards)
         c = min(len(positive), count)
         c = min(c, len(nearby))
         # shuffle_n (utilities.lua:31-42) with the MT19937 stream instead of LuaJIT's math.random
@@ -60,7 +74,7 @@ def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16):
             j = rng.random() % r + i
             nearby[i], nearby[j] = nearby[j], nearby[i]
             r -= 1
-        negative.extend(nearby[:c])
+        negative.extend((anchors.get(*(int(v) for v in Mk[t])),) for t in nearby[:c])
     return positive, negative
 
 

@@ -295,6 +295,11 @@ int frcnn_image_rgb2yuv(const float *rgb, float *yuv, int H, int W, void *stream
  * the result of frcnn_image_rgb2yuv followed by the scaling, without the full-resolution round trip. */
 int frcnn_image_scale(const float *src, int C, int H, int W, float *dst, int dH, int dW, float *tmp,
                       int rgb2yuv, void *stream);
+/* image.load(fn, 3, 'float') + (optionally) image.rgb2yuv + image.scale for a frame that is still the decoder's
+ * 8-bit interleaved RGB [H][W][3] in device memory: samples are converted with v * (1/255) on the fly in the row
+ * pass (6 MB instead of 25 MB per 1080p frame cross PCIe).  dst float[3][dH][dW]; tmp: device float[3*H*dW]. */
+int frcnn_image_scale_u8(const unsigned char *src_hwc, int H, int W, float *dst, int dH, int dW,
+                         float *tmp, int rgb2yuv, void *stream);
 /* image.crop(img, x0, y0, x0+w, y0+h) followed by image.hflip / image.vflip when the flags are set
  * (BatchIterator.lua:57-80), one pass: dst float[C][h][w]. */
 int frcnn_image_crop_flip(const float *src, int C, int H, int W, int x0, int y0, int w, int h, int hflip,

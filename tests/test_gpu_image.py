@@ -263,3 +263,14 @@ def test_batch_iterator_decodes_image_files(F, small_cfg, tmp_path):
     assert_close(img.numpy(), want, 2e-5, "decoded + prepared frame")
     r = val[0]["rois"][0].rect
     assert np.allclose([r.minX, r.minY, r.maxX, r.maxY], [40 * 800 / 480, 30 * 450 / 270, 200 * 800 / 480, 150 * 450 / 270])
+    # decode-ahead pool: worker threads decode, the frame crosses PCIe as 8-bit RGB and is converted inside the row pass
+    # (frcnn_image_scale_u8) -- the same arithmetic, so the prepared frame is bit-identical
+    it2 = F.BatchIterator(model, data, workers=3, prefetch=4)
+    for _ in range(3):
+        v2 = it2.nextValidation(1)
+        assert np.array_equal(v2[0]["img"].numpy(), img.numpy())
+    cfg_rgb = dict(cfg); cfg_rgb["color_space"] = "rgb"
+    m2 = dict(model); m2["cfg"] = cfg_rgb
+    a = F.BatchIterator(m2, data).nextValidation(1)[0]["img"].numpy()
+    b = F.BatchIterator(m2, data, workers=2).nextValidation(1)[0]["img"].numpy()
+    assert np.array_equal(a, b)
