@@ -3,6 +3,7 @@ ground-truth -> anchor labelling, negative sampling and the bbox parameterisatio
 mirror of Anchors.lua with the same method names.  Tables are fp32 (`torch.Tensor` under
 main.lua:51) and are consumed as doubles, exactly like the reference.  The tables are also what the
 device-side RPN scan (frcnn_rpn_scan) reads."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -17,23 +18,31 @@ class MT19937(object):
     """torch.random(): raw 32-bit Mersenne-Twister draws (TH's THRandom_random, [ext])."""
 
     def __init__(self, seed=5489):
-        self.mt = [0] * 624
-        self.mt[0] = seed & 0xFFFFFFFF
+        mt = [0] * 624
+        mt[0] = seed & 0xFFFFFFFF
         for j in range(1, 624):
-            self.mt[j] = (1812433253 * (self.mt[j - 1] ^ (self.mt[j - 1] >> 30)) + j) & 0xFFFFFFFF
-        self.idx = 624
+            mt[j] = (1812433253 * (mt[j - 1] ^ (mt[j - 1] >> 30)) + j) & 0xFFFFFFFF
+        # the state lives in a uint32 array + a C int so that the native example assembly (frcnn_anchors_assemble)
+        # draws from the very same stream in place
+        self.state = np.array(mt, dtype=np.uint32)
+        self.cidx = C.c_int(624)
+
+    @property
+    def idx(self):
+        return self.cidx.value
 
     def random(self):
-        if self.idx >= 624:
-            mt = self.mt
+        if self.cidx.value >= 624:
+            mt = self.state.tolist()
             for k in range(624):
                 y = (mt[k] & 0x80000000) | (mt[(k + 1) % 624] & 0x7FFFFFFF)
                 v = mt[(k + 397) % 624] ^ (y >> 1)
                 if y & 1:
                     v ^= 0x9908B0DF
                 mt[k] = v
-            self.idx = 0
-        y = self.mt[self.idx]; self.idx += 1
+            self.state[:] = mt
+            self.cidx.value = 0
+        y = int(self.state[self.cidx.value]); self.cidx.value += 1
         y ^= y >> 11
         y ^= (y << 7) & 0x9D2C5680
         y ^= (y << 15) & 0xEFC60000
@@ -69,6 +78,9 @@ class Anchors(object):
         self.w = np.zeros((n, 3, width, 2), dtype=np.float32)
         self.h = np.zeros((n, 3, height, 2), dtype=np.float32)
         self.cx, self.cy = {}, {}
+        self._cxx = np.zeros((n, 3, width), dtype=np.float64)   # anchor centres (the keys of the 16-px bins)
+        self._cyy = np.zeros((n, 3, height), dtype=np.float64)
+        self._native = None
 
         def add(m, i, j, v, x):
             m.setdefault(math.floor(x / BIN_SIZE), []).append((i, j, v))
@@ -85,6 +97,7 @@ class Anchors(object):
                     self.h[i, j, y - 1, 0] = r.minY
                     self.h[i, j, y - 1, 1] = r.maxY
                     add(self.cy, i + 1, j + 1, y, cyy)
+                    self._cyy[i, j, y - 1] = cyy
                 for x in range(1, width + 1):
                     r = loc.featureToInputRect(x - 1, 0, x, 0)
                     cxx, cyy = r.center()
@@ -92,6 +105,7 @@ class Anchors(object):
                     self.w[i, j, x - 1, 0] = r.minX
                     self.w[i, j, x - 1, 1] = r.maxX
                     add(self.cx, i + 1, j + 1, x, cxx)
+                    self._cxx[i, j, x - 1] = cxx
         self._w64 = self.w.astype(np.float64)
         self._h64 = self.h.astype(np.float64)
 
@@ -118,6 +132,26 @@ class Anchors(object):
                     if y[0] == x[0] and y[1] == x[1]:
                         found.append(self.get(y[0], y[1], y[2], x[2]))
         return found
+
+    def native(self):
+        """Handle of the native twin of these tables (frcnn_anchors_create) for frcnn_anchors_assemble."""
+        if self._native is None:
+            from . import _lib
+            h = C.c_void_p()
+            _lib.call("frcnn_anchors_create", self.w.ctypes.data_as(C.c_void_p), self.h.ctypes.data_as(C.c_void_p),
+                      self._cxx.ctypes.data_as(C.c_void_p), self._cyy.ctypes.data_as(C.c_void_p), self.w.shape[0], self.w.shape[2],
+                      C.byref(h))
+            self._native = h
+        return self._native
+
+    def __del__(self):
+        if getattr(self, "_native", None) is not None:
+            try:
+                from . import _lib
+                _lib.load().frcnn_anchors_destroy(self._native)
+            except Exception:
+                pass
+            self._native = None
 
     def findNearbyArrays(self, centerX, centerY):
         """findNearby as arrays, in the same order: meta int[n][4] = (layer, aspect, y, x) 1-based and rects float64[n][4]

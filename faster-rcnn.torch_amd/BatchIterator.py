@@ -71,8 +71,8 @@ def decode_image_u8(fn):
 class _U8Frame(object):
     """A decoded frame in HBM as 8-bit interleaved RGB; `event` marks the end of its upload on the copy stream."""
 
-    def __init__(self, dev, H, W, event):
-        self.dev, self.event = dev, event
+    def __init__(self, dev, H, W, event, slot=None):
+        self.dev, self.event, self.slot = dev, event, slot
         self.shape = (3, H, W)
 
 
@@ -81,17 +81,26 @@ class _DecodeAhead(object):
     through pinned buffers on a copy stream of their own; the consumer only ever waits for an event.  At 200+ images/s
     per GPU a single-threaded decode (10-20 ms per 1080p JPEG) would otherwise be the bottleneck of the step."""
 
-    def __init__(self, workers, resolve):
+    def __init__(self, workers, resolve, depth=64):
         import concurrent.futures
         import threading
         import torch
         self.torch = torch
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+        # the consumer thread re-acquires the GIL after every C-ABI call; with the default 5 ms switch interval it can wait
+        # that long behind a decoding thread that is in a Python-level stretch (convoy effect)
+        if sys.getswitchinterval() > 2e-4:
+            sys.setswitchinterval(2e-4)
         self.copy_stream = torch.cuda.Stream()
         self.resolve = resolve
         self.jobs = {}
         self.lock = threading.Lock()
         self.pinned = {}
+        # device frames come from a ring per shape (no allocator traffic -- and no hipMalloc synchronisation -- in the
+        # steady state); a slot is overwritten only after the kernels that read its previous frame (event `consumed`)
+        self.depth = depth
+        self.slots = {}
+        self.inflight = []
 
     def _pinned(self, shape):
         with self.lock:
@@ -101,27 +110,42 @@ class _DecodeAhead(object):
         return self.torch.empty(shape, dtype=self.torch.uint8).pin_memory()
 
     def _work(self, fn):
+        """worker thread: decode into a pinned host buffer -- no HIP call here (the runtime's locks are shared with the
+        consumer thread's kernel launches; uploads issued from 16 threads slowed the training step down)"""
         torch = self.torch
         a = decode_image_u8(self.resolve(fn))
         pin = self._pinned(a.shape)
-        pin.numpy()[...] = a
-        with torch.cuda.stream(self.copy_stream):
-            dev = torch.empty(a.shape, dtype=torch.uint8, device="cuda")
-            dev.copy_(pin, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        ev.synchronize()            # (worker thread: the pinned buffer may be reused once the copy has landed)
-        with self.lock:
-            self.pinned[a.shape].append(pin)
-        return _U8Frame(dev, a.shape[0], a.shape[1], ev)
+        C.memmove(pin.data_ptr(), a.ctypes.data, a.nbytes)   # (a foreign call: the GIL is released for the 6 MB copy)
+        return pin, a.shape
 
     def request(self, fn):
         if fn not in self.jobs:
             self.jobs[fn] = self.pool.submit(self._work, fn)
 
     def get(self, fn):
+        """consumer thread: wait for the decode, queue the upload on the copy stream, hand out the frame + its event"""
+        torch = self.torch
         self.request(fn)
-        return self.jobs.pop(fn).result()
+        pin, shape = self.jobs.pop(fn).result()
+        ring = self.slots.setdefault(shape, dict(bufs=[], pos=0))
+        if len(ring["bufs"]) < self.depth:
+            ring["bufs"].append(dict(dev=torch.empty(shape, dtype=torch.uint8, device="cuda"), consumed=None))
+            slot = ring["bufs"][-1]
+        else:
+            slot = ring["bufs"][ring["pos"]]
+            ring["pos"] = (ring["pos"] + 1) % self.depth
+        with torch.cuda.stream(self.copy_stream):
+            if slot["consumed"] is not None:
+                self.copy_stream.wait_event(slot["consumed"])
+            slot["dev"].copy_(pin, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.inflight.append((pin, shape, ev))
+        while self.inflight and self.inflight[0][2].query():   # pinned buffers whose upload has landed go back to the pool
+            p, shp, _ = self.inflight.pop(0)
+            with self.lock:
+                self.pinned[shp].append(p)
+        return _U8Frame(slot["dev"], shape[0], shape[1], ev, slot)
 
 
 class _Ring(object):
@@ -262,7 +286,8 @@ class BatchIterator(object):
             torch.cuda.current_stream().wait_event(u8.event)
             _lib.call("frcnn_image_scale_u8", ptr(u8.dev), H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
                       int(cfg.get("color_space", "rgb") == "yuv"), s)
-            u8.dev.record_stream(torch.cuda.current_stream())
+            done = torch.cuda.Event(); done.record()
+            u8.slot["consumed"] = done   # the ring slot may be overwritten once this launch has read the frame
         else:
             _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
                       int(to_yuv), s)

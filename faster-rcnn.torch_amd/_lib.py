@@ -91,6 +91,10 @@ _SIGS = {
     "frcnn_cnet_backward": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_losses": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_decode": ([vp, C.c_int, C.c_int, vp, vp, vp], C.c_int),
+    "frcnn_anchors_create": ([vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
+    "frcnn_anchors_destroy": ([vp], C.c_int),
+    "frcnn_anchors_assemble": ([vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, vp,
+                               C.POINTER(C.c_int), vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "frcnn_image_rgb2yuv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
     "frcnn_image_scale": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
     "frcnn_image_scale_u8": ([vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),

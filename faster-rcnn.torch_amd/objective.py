@@ -181,7 +181,8 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         cls_count = reg_count = creg_count = ccls_count = 0
         pnet.training()  # :61-62
         cnet.training()
-        batch = batch_iterator.nextTraining()  # :64
+        batch = next_batch[0] if next_batch[0] is not None else batch_iterator.nextTraining()  # :64
+        next_batch[0] = None
         pending = []
         early_copy = False
         counts_cpu = counts_work = None
@@ -341,9 +342,16 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
 
     dp_gscale = [None]
+    next_batch = [None]
+    prefetch_batches = os.environ.get("FRCNN_PREFETCH_BATCH", "1") != "0"
 
     def finish(a, counts, pending, single, fold=False, reduced=False):
         if a is None:
+            # deferred read-back: the whole step is queued, the device is busy -- the next batch (image decoding hand-over,
+            # processImage launches, example assembly: host work of the loader) is drawn now instead of at the start of
+            # the next call, where the device would wait for it.  Same call sequence on the iterator, one call early.
+            if next_batch[0] is None and prefetch_batches:
+                next_batch[0] = batch_iterator.nextTraining()
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
         cls_count, reg_count, creg_count, ccls_count = counts

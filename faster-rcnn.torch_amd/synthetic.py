@@ -39,8 +39,34 @@ def synthetic_image(H, W, index=0):
     return np.random.RandomState(1000 + index).randn(3, H, W).astype(np.float32)
 
 
-def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16):
-    """BatchIterator.lua:198-225 for one image."""
+def assemble_examples_native(anchors, cfg, rois, W, H, rng, negatives=16):
+    """BatchIterator.lua:198-225 for one image through frcnn_anchors_assemble (host-side native code, the same lists as
+    the Python path below draw for draw)."""
+    import ctypes as C
+    from . import _lib
+    nroi = len(rois)
+    ra = np.array([(r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY) for r in rois], dtype=np.float64).reshape(-1, 4)
+    cap = 8192
+    ex = np.empty((cap, 5), dtype=np.int32); er = np.empty((cap, 4), dtype=np.float64)
+    npos, nneg = C.c_int(0), C.c_int(0)
+    _lib.call("frcnn_anchors_assemble", anchors.native(), ra.ctypes.data_as(C.c_void_p), nroi, float(W), float(H),
+              float(cfg["positive_threshold"]), float(cfg["negative_threshold"]), int(bool(cfg["best_match"])),
+              int(bool(cfg.get("nearby_aversion"))), int(negatives), rng.state.ctypes.data_as(C.c_void_p), C.byref(rng.cidx),
+              ex.ctypes.data_as(C.c_void_p), er.ctypes.data_as(C.c_void_p), cap, C.byref(npos), C.byref(nneg))
+    tag = Anchors._tag
+    exl, erl = ex[:npos.value + nneg.value].tolist(), er[:npos.value + nneg.value].tolist()
+    positive = [(tag(Rect(*erl[k]), exl[k][0], exl[k][1], exl[k][2], exl[k][3]), rois[exl[k][4] - 1]) for k in range(npos.value)]
+    negative = [(tag(Rect(*erl[k]), exl[k][0], exl[k][1], exl[k][2], exl[k][3]),) for k in range(npos.value, npos.value + nneg.value)]
+    return positive, negative
+
+
+def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16, native=None):
+    """BatchIterator.lua:198-225 for one image.  native=None: the native twin unless FRCNN_NATIVE_ASSEMBLE=0."""
+    import os
+    if native is None:
+        native = os.environ.get("FRCNN_NATIVE_ASSEMBLE", "1") != "0"
+    if native:
+        return assemble_examples_native(anchors, cfg, rois, W, H, rng, negatives)
     img_rect = Rect(0, 0, W, H)
     positive = anchors.findPositive(rois, img_rect, cfg["positive_threshold"], cfg["negative_threshold"], cfg["best_match"])
     negative = anchors.sampleNegative(img_rect, rois, cfg["negative_threshold"], negatives, rng)

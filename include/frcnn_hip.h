@@ -317,6 +317,24 @@ int frcnn_image_normalize(float *img, int C, int H, int W, int centering, int sc
 int frcnn_image_contrastive_norm(const float *in, int H, int W, const float *kernel_host, int K,
                                  float threshold, float *out, float *tmp, void *stream);
 
+/* ---- example assembly on the host: Anchors.lua:69-235 + BatchIterator.lua:198-225 ----
+ * Host-only native code (no device work), for loaders that must keep up with 200+ images/s per GPU.
+ * frcnn_anchors_create: w_tab / h_tab = the fp32 tables of Anchors.lua:18-19 ([nscales][3][width][2]), cx / cy = the
+ * anchor centres that key the 16-pixel bins of findNearby (double[nscales][3][width]); all host pointers. */
+typedef struct frcnn_anchors frcnn_anchors;
+int frcnn_anchors_create(const float *w_tab_host, const float *h_tab_host, const double *cx_host,
+                         const double *cy_host, int nscales, int width, frcnn_anchors **out_host);
+int frcnn_anchors_destroy(frcnn_anchors *);
+/* One image of nextTraining: findPositive(rois, image, pos_thr, neg_thr, best_match), sampleNegative(image, rois,
+ * neg_thr, negatives) and, when nearby_aversion != 0, the nearby anchors below neg_thr shuffled with shuffle_n
+ * (min(#positive, #candidates) of them).  rois_host double[nroi][4].  Random draws come from the MT19937 state
+ * mt_state_host[624] / *mt_index_host (torch.random's generator), updated in place.  Output, positives first:
+ * ex_host int[cap][5] = {layer, aspect, y, x, roi (1-based; 0 for negatives)} 1-based, ex_rect_host double[cap][4]. */
+int frcnn_anchors_assemble(frcnn_anchors *, const double *rois_host, int nroi, double img_w, double img_h,
+                           double pos_thr, double neg_thr, int best_match, int nearby_aversion,
+                           int negatives, unsigned int *mt_state_host, int *mt_index_host, int *ex_host,
+                           double *ex_rect_host, int cap, int *npos_host, int *nneg_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,39 @@ def test_batch_rule_of_the_reference(F):
     assert len(it.nextTraining(count=1)) == 1
     one = F.SyntheticBatchIterator(model, H=200, W=320, images_per_batch=1, pool=2, device_images=False)
     assert len(one.nextTraining()) == 1
+
+
+def test_native_example_assembly_equals_python_mirror(F, small_cfg):
+    """frcnn_anchors_assemble (anchors.cpp) against synthetic.assemble_examples' Python path: identical positives,
+    negatives (tags, rects, ROI links) and an identical MT19937 state afterwards, over many images, ROI layouts,
+    thresholds and both configs of the best-match / nearby-aversion switches."""
+    model = F.vgg_small(small_cfg)
+    anchors = F.Anchors(model["pnet"], small_cfg["scales"])
+    rng_np = np.random.RandomState(4)
+    for trial in range(24):
+        cfg = dict(small_cfg)
+        cfg["best_match"] = bool(trial % 2)
+        cfg["nearby_aversion"] = bool((trial // 2) % 2)
+        if trial % 5 == 4:
+            cfg["positive_threshold"], cfg["negative_threshold"] = 0.6, 0.3
+        W, H = [(800, 450), (450, 800), (640, 480), (1000, 600)][trial % 4]
+        n = trial % 5     # incl. images without any ROI
+        rois = []
+        for _ in range(n):
+            w = rng_np.uniform(20, 0.8 * W); h = rng_np.uniform(20, 0.8 * H)
+            x = rng_np.uniform(0, W - w); y = rng_np.uniform(0, H - h)
+            rois.append(F.Roi(F.Rect(x, y, x + w, y + h), int(rng_np.randint(1, 17))))
+        a, b = F.MT19937(100 + trial), F.MT19937(100 + trial)
+        for _ in range(trial):            # (start somewhere inside the stream, incl. across a state regeneration)
+            a.random(); b.random()
+        if trial == 7:
+            for _ in range(700):
+                a.random(); b.random()
+        p1, n1 = F.assemble_examples(anchors, cfg, rois, W, H, a, negatives=16, native=False)
+        p2, n2 = F.assemble_examples(anchors, cfg, rois, W, H, b, negatives=16, native=True)
+        key = lambda r: (r.layer, r.aspect, r.index, r.minX, r.minY, r.maxX, r.maxY)
+        assert [key(e[0]) for e in p1] == [key(e[0]) for e in p2], trial
+        assert [e[1] is f[1] for e, f in zip(p1, p2)] == [True] * len(p1)
+        assert [key(e[0]) for e in n1] == [key(e[0]) for e in n2], trial
+        assert a.idx == b.idx and np.array_equal(a.state, b.state)
+        assert a.random() == b.random()
