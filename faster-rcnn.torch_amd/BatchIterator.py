@@ -22,7 +22,6 @@ import numpy as np
 from . import _lib
 from .Anchors import Anchors, MT19937
 from .Rect import Rect
-from .synthetic import assemble_examples
 from .tensor import DeviceTensor, ptr, stream_ptr, to_device
 
 
@@ -185,6 +184,73 @@ def _transform_rois(rois, froi, old_w, old_h, new_w, new_h):  # BatchIterator.lu
                 roi.rect = r
                 result.append(roi)
     return result
+
+
+# ---- BatchIterator.lua:198-225: the examples of one image -----------------------------------------------
+def assemble_examples_native(anchors, cfg, rois, W, H, rng, negatives=16):
+    """BatchIterator.lua:198-225 for one image through frcnn_anchors_assemble (host-side native code, the same lists as
+    the Python path below draw for draw)."""
+    import ctypes as C
+    from . import _lib
+    nroi = len(rois)
+    ra = np.array([(r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY) for r in rois], dtype=np.float64).reshape(-1, 4)
+    cap = 8192
+    ex = np.empty((cap, 5), dtype=np.int32); er = np.empty((cap, 4), dtype=np.float64)
+    npos, nneg = C.c_int(0), C.c_int(0)
+    _lib.call("frcnn_anchors_assemble", anchors.native(), ra.ctypes.data_as(C.c_void_p), nroi, float(W), float(H),
+              float(cfg["positive_threshold"]), float(cfg["negative_threshold"]), int(bool(cfg["best_match"])),
+              int(bool(cfg.get("nearby_aversion"))), int(negatives), rng.state.ctypes.data_as(C.c_void_p), C.byref(rng.cidx),
+              ex.ctypes.data_as(C.c_void_p), er.ctypes.data_as(C.c_void_p), cap, C.byref(npos), C.byref(nneg))
+    tag = Anchors._tag
+    exl, erl = ex[:npos.value + nneg.value].tolist(), er[:npos.value + nneg.value].tolist()
+    positive = [(tag(Rect(*erl[k]), exl[k][0], exl[k][1], exl[k][2], exl[k][3]), rois[exl[k][4] - 1]) for k in range(npos.value)]
+    negative = [(tag(Rect(*erl[k]), exl[k][0], exl[k][1], exl[k][2], exl[k][3]),) for k in range(npos.value, npos.value + nneg.value)]
+    return positive, negative
+
+
+def assemble_examples(anchors, cfg, rois, W, H, rng, negatives=16, native=None):
+    """BatchIterator.lua:198-225 for one image.  native=None: the native twin unless FRCNN_NATIVE_ASSEMBLE=0."""
+    import os
+    if native is None:
+        native = os.environ.get("FRCNN_NATIVE_ASSEMBLE", "1") != "0"
+    if native:
+        return assemble_examples_native(anchors, cfg, rois, W, H, rng, negatives)
+    img_rect = Rect(0, 0, W, H)
+    positive = anchors.findPositive(rois, img_rect, cfg["positive_threshold"], cfg["negative_threshold"], cfg["best_match"])
+    negative = anchors.sampleNegative(img_rect, rois, cfg["negative_threshold"], negatives, rng)
+    count = len(positive) + len(negative)
+    if cfg.get("nearby_aversion"):
+        # every anchor that shares a bin pair with a positive's centre and overlaps it by less than the negative threshold
+        # (BatchIterator.lua:204-216).  Vectorised: the candidates of all positives in one IoU evaluation (Rect.IoU's
+        # arithmetic in float64, candidates in the order of the nested Lua loops); Rect objects are only built for the
+        # few candidates that survive the shuffle.
+        nearby = []
+        if positive:
+            parts = [anchors.findNearbyArrays(*p[0].center()) for p in positive]
+            cnt = np.array([len(m) for m, _ in parts])
+            if cnt.sum():
+                M = np.concatenate([m for m, _ in parts]); R = np.concatenate([r for _, r in parts])
+                P = np.repeat(np.array([(p[0].minX, p[0].minY, p[0].maxX, p[0].maxY) for p in positive], dtype=np.float64), cnt, axis=0)
+                minx = np.maximum(P[:, 0], R[:, 0]); miny = np.maximum(P[:, 1], R[:, 1])
+                maxx = np.minimum(P[:, 2], R[:, 2]); maxy = np.minimum(P[:, 3], R[:, 3])
+                ok = (maxx >= minx) & (maxy >= miny)
+                inter = np.where(ok, (maxx - minx) * (maxy - miny), 0.0)
+                area = lambda A: (A[:, 2] - A[:, 0]) * (A[:, 3] - A[:, 1])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    iou = inter / (area(P) + area(R) - inter)
+                Mk = M[iou < cfg["negative_threshold"]]
+                nearby = list(range(len(Mk)))   # (the shuffle permutes positions; the rows are looked up afterwards)
+        c = min(len(positive), count)
+        c = min(c, len(nearby))
+        # shuffle_n (utilities.lua:31-42) with the MT19937 stream instead of LuaJIT's math.random
+        r = len(nearby)
+        for i in range(c):
+            j = rng.random() % r + i
+            nearby[i], nearby[j] = nearby[j], nearby[i]
+            r -= 1
+        negative.extend((anchors.get(*(int(v) for v in Mk[t])),) for t in nearby[:c])
+    return positive, negative
+
 
 
 class _RgbFrame(object):
