@@ -1,6 +1,6 @@
 """BatchIterator.processImage on the device: time per 1080p frame -> 800x450 prepared frame,
 per-kernel HIP-event time of the image class, algorithmic HBM bytes, and the numpy restatement on the host CPU
-beside it.  usage: python tools/bench_image.py [H W]"""
+beside it.  usage: python tests/perf_image.py [H W]"""
 import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

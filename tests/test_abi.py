@@ -47,7 +47,12 @@ def test_product_path_never_imports_the_oracle():
         for fn in files:
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
-                assert "pyoracle" not in txt and "frcnn_oracle" not in txt and "naive_np" not in txt, fn
+                assert "pyoracle" not in txt and "frcnn_oracle" not in txt and "naive_np" not in txt and "orc_image" not in txt, fn
+    # tools/ and the entry points: only bench.py (cpu_baseline leg) and __graft_entry__ (build / smoke) may touch oracle/
+    for fn in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if fn.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", fn)).read()
+            assert "pyoracle" not in txt and "orc_image" not in txt and "naive_np" not in txt and "/oracle" not in txt, fn
 
 
 def test_lua_binding_in_sync_with_header():
