@@ -82,7 +82,45 @@ def layer_fixture():
                 x_shape=list(x.shape), w_shape=list(w.shape), y_shape=list(y.shape), pool_shape=list(p.shape))
 
 
+def image_fixture():
+    """processImage pieces on a tiny frame: numpy restatement (oracle/orc_image.py); the up-scaling branch of image.scale is
+    cross-checked with PyTorch's bilinear interpolation with align_corners=True (the same (src-1)/(dst-1) rule), the
+    contrastive normalisation with a direct float64 evaluation of the two modules."""
+    import torch
+    import torch.nn.functional as Fn
+    import orc_image as OI
+    rng = np.random.RandomState(21)
+    rgb = rng.rand(3, 10, 14).astype(np.float32)
+    yuv = OI.rgb2yuv(rgb)
+    up = OI.scale_bilinear(yuv, 20, 15)
+    ut = Fn.interpolate(torch.from_numpy(yuv).double()[None], size=(15, 20), mode="bilinear", align_corners=True)[0].numpy()
+    assert np.abs(up - ut).max() < 1e-5
+    down = OI.scale_bilinear(yuv, 9, 7)
+    norm = OI.center_and_scale(down)
+    k = OI.gaussian1d(7)
+    cn = OI.contrastive_norm(norm[0], k)
+    kk = k.astype(np.float64) / k.astype(np.float64).sum()
+    H, W = norm[0].shape
+
+    def est(x):
+        o = np.zeros((H, W))
+        for y in range(H):
+            for xx in range(W):
+                for jy in range(7):
+                    for jx in range(7):
+                        sy, sx = y + jy - 3, xx + jx - 3
+                        if 0 <= sy < H and 0 <= sx < W:
+                            o[y, xx] += kk[jy] * kk[jx] * x[sy, sx]
+        return o
+    coef = est(np.ones((H, W))); sub = norm[0] - est(norm[0].astype(np.float64)) / coef
+    sd = np.sqrt(est(sub * sub)) / coef
+    assert np.abs(cn - sub / np.where(sd > 1e-4, sd, 1e-4)).max() < 1e-4
+    return dict(rgb=rgb.ravel().tolist(), yuv=yuv.ravel().tolist(), up_15x20=up.ravel().tolist(), down_7x9=down.ravel().tolist(),
+                normalized=norm.ravel().tolist(), contrastive_y=cn.ravel().tolist(), gaussian1d_7=k.tolist())
+
+
 if __name__ == "__main__":
+    json.dump(image_fixture(), open(os.path.join(HERE, "image_small.json"), "w"))
     json.dump(nms_cases(), open(os.path.join(HERE, "nms_cases.json"), "w"))
     json.dump(anchors_fixture(), open(os.path.join(HERE, "anchors_vgg_small.json"), "w"))
     json.dump(layer_fixture(), open(os.path.join(HERE, "layers_small.json"), "w"))

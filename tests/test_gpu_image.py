@@ -274,3 +274,24 @@ def test_batch_iterator_decodes_image_files(F, small_cfg, tmp_path):
     a = F.BatchIterator(m2, data).nextValidation(1)[0]["img"].numpy()
     b = F.BatchIterator(m2, data, workers=2).nextValidation(1)[0]["img"].numpy()
     assert np.array_equal(a, b)
+
+
+def test_golden_image_fixture_on_device(F):
+    """The committed golden vectors (tests/golden/image_small.json) through the kernels."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "image_small.json")))
+    rgb = np.array(g["rgb"], np.float32).reshape(3, 10, 14)
+    d = _dev(F, rgb); tmp = F.DeviceTensor.empty((3 * 10 * 20,))
+    up = F.DeviceTensor.empty((3, 15, 20)); down = F.DeviceTensor.empty((3, 7, 9))
+    F._lib.call("frcnn_image_scale", F.ptr(d), 3, 10, 14, F.ptr(up), 15, 20, F.ptr(tmp), 1, F.stream_ptr())
+    F._lib.call("frcnn_image_scale", F.ptr(d), 3, 10, 14, F.ptr(down), 7, 9, F.ptr(tmp), 1, F.stream_ptr())
+    assert_close(up.numpy().ravel(), np.array(g["up_15x20"], np.float32), 1e-6, "golden up-scaling")
+    assert_close(down.numpy().ravel(), np.array(g["down_7x9"], np.float32), 1e-6, "golden down-scaling")
+    wsb = F._lib.load().frcnn_image_normalize_workspace_bytes(3)
+    ws = F.DeviceTensor.empty(((wsb + 3) // 4,))
+    F._lib.call("frcnn_image_normalize", F.ptr(down), 3, 7, 9, 1, 1, F.ptr(ws), wsb, F.stream_ptr())
+    assert_close(down.numpy().ravel(), np.array(g["normalized"], np.float32), 1e-5, "golden centring / scaling")
+    y = down.offset_view(0, (7, 9)); t2 = F.DeviceTensor.empty((7, 9))
+    k = np.array(g["gaussian1d_7"], np.float32)
+    F._lib.call("frcnn_image_contrastive_norm", F.ptr(y), 7, 9, k.ctypes.data_as(C.c_void_p), 7, 1e-4, F.ptr(y), F.ptr(t2), F.stream_ptr())
+    assert_close(y.numpy().ravel(), np.array(g["contrastive_y"], np.float32), 1e-4, "golden contrastive normalisation")

@@ -146,3 +146,19 @@ def test_decode_image(tmp_path):
     assert g.shape == (3, 7, 9) and np.array_equal(g[0], g[1]) and np.array_equal(g[1], g[2])
     np.save(str(tmp_path / "f.npy"), a)
     assert np.array_equal(decode_image(str(tmp_path / "f.npy")), a)
+
+
+def test_golden_image_fixture():
+    """tests/golden/image_small.json (make_golden.py: restatement cross-checked with PyTorch's align_corners bilinear
+    up-scaling and a direct float64 evaluation of the normalisation modules) is what the restatement still produces."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "image_small.json")))
+    rgb = np.array(g["rgb"], np.float32).reshape(3, 10, 14)
+    yuv = OI.rgb2yuv(rgb)
+    assert np.array_equal(yuv.ravel(), np.array(g["yuv"], np.float32))
+    assert np.array_equal(OI.scale_bilinear(yuv, 20, 15).ravel(), np.array(g["up_15x20"], np.float32))
+    down = OI.scale_bilinear(yuv, 9, 7)
+    assert np.array_equal(down.ravel(), np.array(g["down_7x9"], np.float32))
+    norm = OI.center_and_scale(down)
+    assert np.allclose(norm.ravel(), np.array(g["normalized"], np.float32), rtol=0, atol=1e-6)
+    assert np.allclose(OI.contrastive_norm(norm[0], OI.gaussian1d(7)).ravel(), np.array(g["contrastive_y"], np.float32), rtol=0, atol=1e-5)
