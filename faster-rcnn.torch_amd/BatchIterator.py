@@ -70,8 +70,8 @@ def decode_image_u8(fn):
 class _U8Frame(object):
     """A decoded frame in HBM as 8-bit interleaved RGB; `event` marks the end of its upload on the copy stream."""
 
-    def __init__(self, dev, H, W, event, slot=None):
-        self.dev, self.event, self.slot = dev, event, slot
+    def __init__(self, dev, H, W, event, slot=None, recycle=None):
+        self.dev, self.event, self.slot, self.recycle = dev, event, slot, recycle
         self.shape = (3, H, W)
 
 
@@ -80,9 +80,8 @@ class _DecodeAhead(object):
     through pinned buffers on a copy stream of their own; the consumer only ever waits for an event.  At 200+ images/s
     per GPU a single-threaded decode (10-20 ms per 1080p JPEG) would otherwise be the bottleneck of the step."""
 
-    def __init__(self, workers, resolve, depth=64):
+    def __init__(self, workers, resolve, cache_bytes=2 << 30):
         import concurrent.futures
-        import threading
         import torch
         self.torch = torch
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
@@ -93,75 +92,130 @@ class _DecodeAhead(object):
         self.copy_stream = torch.cuda.Stream()
         self.resolve = resolve
         self.jobs = {}
-        self.lock = threading.Lock()
-        self.pinned = {}
-        # device frames come from a ring per shape (no allocator traffic -- and no hipMalloc synchronisation -- in the
-        # steady state); a slot is overwritten only after the kernels that read its previous frame (event `consumed`)
-        self.depth = depth
-        self.slots = {}
+        # Device frames and pinned staging buffers are recycled by capacity bucket with a bound on what is kept (no
+        # allocator traffic -- and no hipMalloc synchronisation -- in the steady state, no growth with the number of
+        # distinct frame sizes of the data set); a device frame is overwritten only after the kernels that read its
+        # previous content (event `consumed`, waited for by the copy stream).
+        self.dev_pool = _BufferPool(lambda n: dict(dev=torch.empty((n,), dtype=torch.uint8, device="cuda"), consumed=None),
+                                    cache_bytes)
+        self.pin_pool = _BufferPool(lambda n: torch.empty((n,), dtype=torch.uint8).pin_memory(), max(cache_bytes // 4, 64 << 20))
         self.inflight = []
 
-    def _pinned(self, shape):
-        with self.lock:
-            lst = self.pinned.setdefault(shape, [])
-            if lst:
-                return lst.pop()
-        return self.torch.empty(shape, dtype=self.torch.uint8).pin_memory()
-
-    def _work(self, fn):
+    def _work(self, fn, base):
         """worker thread: decode into a pinned host buffer -- no HIP call here (the runtime's locks are shared with the
         consumer thread's kernel launches; uploads issued from 16 threads slowed the training step down)"""
-        torch = self.torch
-        a = decode_image_u8(self.resolve(fn))
-        pin = self._pinned(a.shape)
+        a = decode_image_u8(self.resolve(fn, base))
+        pin, pb = self.pin_pool.take(a.nbytes)
         C.memmove(pin.data_ptr(), a.ctypes.data, a.nbytes)   # (a foreign call: the GIL is released for the 6 MB copy)
-        return pin, a.shape
+        return pin, pb, a.shape
 
-    def request(self, fn):
-        if fn not in self.jobs:
-            self.jobs[fn] = self.pool.submit(self._work, fn)
+    def request(self, fn, base=""):
+        if (fn, base) not in self.jobs:
+            self.jobs[(fn, base)] = self.pool.submit(self._work, fn, base)
 
-    def get(self, fn):
+    def get(self, fn, base=""):
         """consumer thread: wait for the decode, queue the upload on the copy stream, hand out the frame + its event"""
         torch = self.torch
-        self.request(fn)
-        pin, shape = self.jobs.pop(fn).result()
-        ring = self.slots.setdefault(shape, dict(bufs=[], pos=0))
-        if len(ring["bufs"]) < self.depth:
-            ring["bufs"].append(dict(dev=torch.empty(shape, dtype=torch.uint8, device="cuda"), consumed=None))
-            slot = ring["bufs"][-1]
-        else:
-            slot = ring["bufs"][ring["pos"]]
-            ring["pos"] = (ring["pos"] + 1) % self.depth
+        self.request(fn, base)
+        pin, pb, shape = self.jobs.pop((fn, base)).result()
+        nbytes = int(shape[0]) * int(shape[1]) * int(shape[2])
+        slot, sb = self.dev_pool.take(nbytes)
         with torch.cuda.stream(self.copy_stream):
             if slot["consumed"] is not None:
                 self.copy_stream.wait_event(slot["consumed"])
-            slot["dev"].copy_(pin, non_blocking=True)
+                slot["consumed"] = None
+            slot["dev"][:nbytes].copy_(pin[:nbytes], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        self.inflight.append((pin, shape, ev))
+        self.inflight.append((pin, pb, ev))
         while self.inflight and self.inflight[0][2].query():   # pinned buffers whose upload has landed go back to the pool
-            p, shp, _ = self.inflight.pop(0)
-            with self.lock:
-                self.pinned[shp].append(p)
-        return _U8Frame(slot["dev"], shape[0], shape[1], ev, slot)
+            p, b, _ = self.inflight.pop(0)
+            self.pin_pool.give(p, b)
+        return _U8Frame(slot["dev"], shape[0], shape[1], ev, slot, lambda: self.dev_pool.give(slot, sb))
 
 
-class _Ring(object):
-    """Device buffers recycled per shape (hipMalloc is synchronous): the last `depth` results of a shape stay
-    valid, older ones are overwritten -- enough for the images of a few batches in flight."""
+def _bucket(nbytes):
+    """Capacity bucket of a request: the next value of the form (8 + k) / 8 * 2^e (k = 0..7) -- at most 12.5 % slack, and
+    frames of nearly the same size (every ImageNet file has its own) share buffers instead of each caching its own."""
+    n = max(int(nbytes), 4096)
+    e = n.bit_length() - 4          # 8 <= n >> e < 16
+    m = -(-n >> e)                  # ceil
+    return m << e
 
-    def __init__(self, depth):
-        self.depth, self.bufs, self.pos = depth, {}, {}
 
-    def get(self, shape):
-        lst = self.bufs.setdefault(shape, [])
-        if len(lst) < self.depth:
-            lst.append(DeviceTensor.empty(shape))
-            return lst[-1]
-        i = self.pos.get(shape, 0)
-        self.pos[shape] = (i + 1) % self.depth
-        return lst[i]
+class _BufferPool(object):
+    """Recycles device (or pinned host) buffers by capacity bucket (hipMalloc / hipFree synchronise the device, so the
+    steady state must not allocate) with a BOUND on what it keeps: buffers handed back are cached until the cached bytes
+    exceed `max_bytes`, then the least recently used buckets are released.  A buffer is handed back either explicitly
+    (intermediates, once the launch that read them is queued on the same stream) or when the last reference to the tensor
+    built on it is dropped (`_PooledTensor.__del__`: the batch that held the frame is gone) -- reuse is then ordered
+    behind the consumer's kernels by the stream itself."""
+
+    def __init__(self, alloc, max_bytes, release=None):
+        import collections
+        import threading
+        self.alloc, self.release, self.max_bytes = alloc, release, int(max_bytes)
+        self.free = collections.OrderedDict()    # bucket -> [buffers], least recently used bucket first
+        self.cached = 0
+        self.allocated = 0                        # bytes handed out + cached (for tests / diagnostics)
+        self.lock = threading.Lock()
+
+    def take(self, nbytes):
+        b = _bucket(nbytes)
+        with self.lock:
+            lst = self.free.get(b)
+            if lst:
+                buf = lst.pop()
+                self.cached -= b
+                if lst:
+                    self.free.move_to_end(b)
+                else:
+                    del self.free[b]
+                return buf, b
+            self.allocated += b
+        return self.alloc(b), b
+
+    def give(self, buf, b):
+        drop = []
+        with self.lock:
+            self.free.setdefault(b, []).append(buf)
+            self.free.move_to_end(b)
+            self.cached += b
+            while self.cached > self.max_bytes and self.free:
+                ob, lst = next(iter(self.free.items()))
+                drop.append(lst.pop())
+                self.cached -= ob
+                self.allocated -= ob
+                if not lst:
+                    del self.free[ob]
+        for d in drop:
+            if self.release is not None:
+                self.release(d)
+
+
+class _PooledTensor(DeviceTensor):
+    """A DeviceTensor on a pool buffer; the buffer returns to the pool with the last reference."""
+
+    def __init__(self, pool, shape, dtype=np.float32):
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        self._pool = pool
+        self._buf, self._bucket = pool.take(nbytes)
+        DeviceTensor.__init__(self, self._buf.ptr, shape, dtype, owner=self._buf)
+
+    def release(self):
+        pool, self._pool = self._pool, None
+        if pool is not None:
+            pool.give(self._buf, self._bucket)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def _device_pool(max_bytes):
+    return _BufferPool(lambda n: DeviceTensor.empty((n,), np.uint8), max_bytes)   # (dropping the DeviceTensor frees it)
 
 
 def _copy_rois(rois):  # deep_copy(self.ground_truth[fn].rois) (BatchIterator.lua:172): the rects are rewritten below
@@ -263,9 +317,10 @@ class _RgbFrame(object):
 
 
 class BatchIterator(object):
-    def __init__(self, model, training_data, load_image=None, seed=5489, ring=32, workers=0, prefetch=8):
+    def __init__(self, model, training_data, load_image=None, seed=5489, workers=0, prefetch=8, cache_bytes=2 << 30):
         # BatchIterator.lua:82-99.  workers > 0 (default loader only): image files are decoded `prefetch` entries ahead by
-        # a pool of threads and uploaded as 8-bit frames (see _DecodeAhead)
+        # a pool of threads and uploaded as 8-bit frames (see _DecodeAhead).  cache_bytes bounds the device memory kept
+        # for recycling (frames of a batch are held by the batch itself and return to the pool when it is dropped).
         cfg = model["cfg"]
         self.cfg = cfg
         self.ground_truth = training_data["ground_truth"]
@@ -274,16 +329,20 @@ class BatchIterator(object):
         self.anchors = Anchors(model["pnet"], cfg["scales"])
         self.rng = MT19937(seed)
         base = cfg.get("examples_base_path") or ""
-        self.load_image_fn = load_image or (lambda fn: decode_image(fn if os.path.isabs(fn) or not base else os.path.join(base, fn)))
+        bg_base = cfg.get("background_base_path") or ""     # background files have their own base (BatchIterator.lua:255)
+        resolve = lambda fn, b: fn if os.path.isabs(fn) or not b else os.path.join(b, fn)
+        self.base_of = {"examples": base, "background": bg_base}
+        self.load_image_fn = load_image or (lambda fn, b=base: decode_image(resolve(fn, b)))
+        self._custom_loader = load_image is not None
         self.training = dict(order=[], list=list(training_data["training_set"]))
         self.validation = dict(order=[], list=list(training_data.get("validation_set", [])))
         self.background = dict(order=[], list=list(training_data.get("background_files") or []))
         self._randomize_order(self.training, self.validation, self.background)
         self.ahead = None
         if workers > 0 and load_image is None:
-            self.ahead = _DecodeAhead(workers, lambda fn: fn if os.path.isabs(fn) or not base else os.path.join(base, fn))
+            self.ahead = _DecodeAhead(workers, resolve, cache_bytes=cache_bytes)
             self.prefetch = prefetch
-        self.ring = _Ring(ring)
+        self.pool = _device_pool(cache_bytes)
         self.scratch = {}
         self.log = lambda msg: None   # the reference prints one line per image (:249); silent by default
 
@@ -300,8 +359,9 @@ class BatchIterator(object):
         fn = s["list"][s["order"][s["i"] - 1] - 1]
         s["i"] += 1
         if self.ahead is not None:   # decode the following entries of this epoch's order ahead of time (no RNG involved)
+            base = self.base_of["background" if s is self.background else "examples"]
             for k in range(s["i"], min(s["i"] + self.prefetch, len(s["list"]) + 1)):
-                self.ahead.request(s["list"][s["order"][k - 1] - 1])
+                self.ahead.request(s["list"][s["order"][k - 1] - 1], base)
         return fn
 
     def _tmp(self, name, n):
@@ -311,20 +371,22 @@ class BatchIterator(object):
         return t
 
     # ---- utilities.lua load_image: decoded RGB frame -> device, colour space conversion
-    def load_image(self, fn, materialize=False):
+    def load_image(self, fn, materialize=False, what="examples"):
+        """what: 'examples' (cfg.examples_base_path) or 'background' (cfg.background_base_path, BatchIterator.lua:255)."""
+        base = self.base_of[what]
         if self.ahead is not None and not materialize:
             cs = self.cfg.get("color_space", "rgb")
             if cs not in ("yuv", "rgb"):
                 raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
-            return self.ahead.get(fn)
-        img = to_device(self.load_image_fn(fn))
+            return self.ahead.get(fn, base)
+        img = to_device(self.load_image_fn(fn) if self._custom_loader else self.load_image_fn(fn, base))
         if len(img.shape) != 3 or img.shape[0] != 3:
             return img   # the caller reports the unexpected channel count (:185-188)
         cs = self.cfg.get("color_space", "rgb")
         if cs == "yuv":
             if not materialize:
                 return _RgbFrame(img)   # converted inside processImage's first pass
-            out = self.ring.get(tuple(img.shape))
+            out = _PooledTensor(self.pool, tuple(img.shape))
             _lib.call("frcnn_image_rgb2yuv", ptr(img), ptr(out), img.shape[1], img.shape[2], stream_ptr())
             return out
         if cs != "rgb":
@@ -346,14 +408,16 @@ class BatchIterator(object):
             scale_Y = scale_X + (self.rng.uniform() - 0.5) * aug["aspect_jitter"]
         # scale (:117, :49-55): the destination size is truncated by the tensor constructor
         sw, sh = int(max(1, W * scale_X)), int(max(1, H * scale_Y))
-        cur = self.ring.get((Cn, sh, sw))
+        cur = _PooledTensor(self.pool, (Cn, sh, sw))
         if u8 is not None:   # 8-bit frame from the decode-ahead pool: float conversion (+ yuv) fused into the row pass
             import torch
             torch.cuda.current_stream().wait_event(u8.event)
             _lib.call("frcnn_image_scale_u8", ptr(u8.dev), H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
                       int(cfg.get("color_space", "rgb") == "yuv"), s)
             done = torch.cuda.Event(); done.record()
-            u8.slot["consumed"] = done   # the ring slot may be overwritten once this launch has read the frame
+            u8.slot["consumed"] = done   # the frame's buffer may be overwritten once this launch has read it
+            if u8.recycle is not None:
+                u8.recycle(); u8.recycle = None
         else:
             _lib.call("frcnn_image_scale", ptr(img), Cn, H, W, ptr(cur), sh, sw, ptr(self._tmp("scale", Cn * H * sw)),
                       int(to_yuv), s)
@@ -374,8 +438,9 @@ class BatchIterator(object):
             vf = True
             rois = _transform_rois(rois, lambda r, w, h: Rect(r.minX, h - r.maxY, r.maxX, h - r.minY), cw, ch, cw, ch)
         if hf or vf or (cw, ch) != (sw, sh):   # crop and both flips are one gather
-            nxt = self.ring.get((Cn, ch, cw))
+            nxt = _PooledTensor(self.pool, (Cn, ch, cw))
             _lib.call("frcnn_image_crop_flip", ptr(cur), Cn, sh, sw, x0, y0, cw, ch, int(hf), int(vf), ptr(nxt), s)
+            cur.release()    # an intermediate: reusable behind this launch (same stream)
             cur = nxt
         nz = cfg["normalization"]
         if nz.get("centering") or nz.get("scaling"):   # :146-160
@@ -397,7 +462,7 @@ class BatchIterator(object):
 
         def checked_load(fn, what):
             try:
-                img = self.load_image(fn)
+                img = self.load_image(fn, what=what)
             except Exception as e:   # pcall: ImageNet contains invalid files (:176-181)
                 self.log("Invalid image '%s': %s" % (fn, e))
                 return None
@@ -409,7 +474,7 @@ class BatchIterator(object):
         def try_add_next():
             fn = self._next_entry(self.training)
             rois = _copy_rois(self.ground_truth[fn]["rois"])
-            img = checked_load(fn, "training")
+            img = checked_load(fn, "examples")
             if img is None:
                 return 0
             img, rois = self.processImage(img, rois)

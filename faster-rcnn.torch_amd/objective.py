@@ -196,7 +196,8 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 c4[0] += np_ + nn_; c4[1] += np_; c4[2] += np_; c4[3] += 1
             counts_cpu = torch.tensor(c4, dtype=torch.float64)
             counts_work = _dist().all_reduce(counts_cpu, group=host_group, async_op=True)
-        for x in batch:
+        for bi, x in enumerate(batch):
+            last = bi == len(batch) - 1   # (by position: an iterator may hand out the same pooled image twice)
             img = to_device(x["img"])  # :66
             outputs = pnet.forward(img, async_heads=True)  # :71 (the anchor nets stay in flight beside the cnet stage)
             p = cleanAnchors(x["positive"], outputs)  # :74-75
@@ -216,6 +217,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 if npos:
                     ex_roi[:npos] = [(e[1].rect.minX, e[1].rect.minY, e[1].rect.maxX, e[1].rect.maxY) for e in p]
                     ex_class[:npos] = [e[1].class_index for e in p]
+                    if ex_class[:npos].min() < 1 or ex_class[:npos].max() > cfg["class_count"]:
+                        # nn.ClassNLLCriterion raises on a target outside 1..n (objective.lua:174); the batched loss
+                        # kernel indexes with it, so a stale index in a training-data file must stop here
+                        raise _lib.FrcnnError("roi.class_index %d outside 1..%d (class_count)"
+                                              % (int(ex_class[:npos].min() if ex_class[:npos].min() < 1 else ex_class[:npos].max()),
+                                                 cfg["class_count"]))
                 # positives pool the GT rect (:117), negatives pool the anchor rect itself (:137)
                 wins = roi_windows(np.concatenate([ex_roi[:npos], ex_anchor[npos:]], 0), localizer, fmH, fmW)
                 # positions where delta_outputs[l] will be non-zero (hint for the sparse head backward)
@@ -267,7 +274,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             if E == 0:
                 for l in range(4):
                     _lib.call("frcnn_pnet_set_sparse_deltas", native.h, l + 1, None, 0)
-            if x is batch[-1] and _dist() is not None:
+            if last and _dist() is not None:
                 # the classification net's slice of the flat gradient (55 % of it) is final, and so is the anchor
                 # nets' slice once the side stream's part is joined: their all-reduces run beside the backbone's
                 # backward pass; only the backbone's 3.3 M elements remain for the end
@@ -282,7 +289,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     pnet.backward_heads_join()
                     lo, hi = pnet.heads_param_range()
                     pending.append(allreduce_begin(gradient, lo, hi))
-            if x is batch[-1] and defer and _dist() is None:
+            if last and defer and _dist() is None:
                 # the eight statistics are final before the backbone's backward pass: their read-back is queued
                 # here, so the caller's wait ends mid-step and the host queues the next step while this one
                 # is still running (the device never drains between steps)
@@ -290,7 +297,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 acc_event.record()
                 early_copy = True
             pnet.backward(img, delta_outputs)  # :189
-            if x is batch[-1] and _dist() is not None and early_blocks and getattr(gradient, "is_cuda", False):
+            if last and _dist() is not None and early_blocks and getattr(gradient, "is_cuda", False):
                 if aux_stream[0] is None:
                     aux_stream[0] = torch.cuda.Stream()
                 for b in early_blocks:   # deepest first: the order in which their gradients become final

@@ -25,6 +25,15 @@ TYPE_NIL, TYPE_NUMBER, TYPE_STRING, TYPE_TABLE, TYPE_TORCH, TYPE_BOOLEAN = 0, 1,
 
 _STORAGE = {"Float": np.float32, "Double": np.float64, "Long": np.int64, "Int": np.int32, "Short": np.int16,
             "Byte": np.uint8, "Char": np.int8}
+
+
+def _cuda_kind(k):
+    """'Cuda' -> 'Float', 'CudaLong' -> 'Long', ... (cutorch's device classes serialise like their host twins)."""
+    if k == "Cuda":
+        return "Float"
+    return k[4:] if k.startswith("Cuda") else k
+
+
 _BY_DTYPE = {np.dtype(v): k for k, v in _STORAGE.items()}
 _BIN = {np.dtype(np.float32): "f", np.dtype(np.float64): "d", np.dtype(np.int64): "q", np.dtype(np.int32): "i",
         np.dtype(np.int16): "h", np.dtype(np.uint8): "B", np.dtype(np.int8): "b"}
@@ -225,16 +234,18 @@ class Reader(object):
             version = self.string()
             cls = self.string() if version.startswith("V ") else version
             kind = cls.split(".")[-1]
-            if kind.endswith("Storage") and kind[:-7] in _STORAGE:
+            if kind.endswith("Storage") and _cuda_kind(kind[:-7]) in _STORAGE:
+                # (cutorch writes a CudaStorage as its size followed by the float data -- the reference's snapshots
+                # hold `weights` as a torch.CudaTensor over a torch.CudaStorage, main.lua:86-92 / utilities.lua:126-134)
                 n = self.long()
-                a = self._array(n, _STORAGE[kind[:-7]])
-            elif kind.endswith("Tensor") and kind[:-6].replace("Cuda", "Float") in _STORAGE:
+                a = self._array(n, _STORAGE[_cuda_kind(kind[:-7])])
+            elif kind.endswith("Tensor") and _cuda_kind(kind[:-6]) in _STORAGE:
                 nd = self.int()
                 size = self._array(nd, np.int64); stride = self._array(nd, np.int64)
                 off = self.long() - 1
                 st = self.object()
                 if st is None or nd == 0:
-                    a = np.zeros(tuple(size) if nd else (0,), _STORAGE[kind[:-6].replace("Cuda", "Float")])
+                    a = np.zeros(tuple(size) if nd else (0,), _STORAGE[_cuda_kind(kind[:-6])])
                 else:
                     a = np.lib.stride_tricks.as_strided(st[off:], shape=tuple(int(s) for s in size),
                                                         strides=tuple(int(s) * st.itemsize for s in stride)).copy()

@@ -34,7 +34,11 @@ def test_host_only_entry_points(F):
     assert (nat.total_params, nat.pnet_params) == (26784106, 12089683)
     assert [len(nat.localizer_layers(i)) for i in range(1, 6)] == [10, 13, 13, 13, 11]
     large = F.vgg_large(dict(F.imgnet_cfg))
-    assert large["native"].total_params > 38_000_000   # 38.6 M with 6x6 ROI pooling
+    # hand count (models/vgg_large.lua:5-22, imagenet.lua:2,9): backbone 7 635 274 + anchor nets 11 488 332 = 19 123 606,
+    # cnet 18432*1024+1024 + 2*1024 + 1 + 1024*512+512 + 1 + 512*4+4 + 512*201+201 = 19 507 407
+    assert (large["native"].total_params, large["native"].pnet_params) == (38631013, 19123606)
+    c7 = dict(F.imgnet_cfg); c7["roi_pooling"] = dict(kw=7, kh=7)      # README.md:19 experiment
+    assert F.vgg_large(c7)["native"].total_params == 38631013 + 512 * 13 * 1024
     # errors surface as exceptions carrying frcnn_last_error()
     import pytest
     with pytest.raises(F.FrcnnError):

@@ -20,6 +20,9 @@ CASES = [
     (10, 29, 50, 24, 5, 0),     # valid 5x5 head
     (6, 29, 50, 24, 7, 0),      # valid 7x7 head
     (130, 15, 17, 130, 3, 1),   # channel counts that are not multiples of the chunk / tile
+    (256, 38, 63, 512, 3, 1),   # vgg_large.lua:9 widths: 256 -> 512 ...
+    (512, 38, 63, 512, 3, 1),   # ... and 512 -> 512 (M = 512, K = 4608)
+    (512, 38, 63, 256, 7, 0),   # 7x7 anchor net on the 512-plane map (K = 25 088)
 ]
 
 

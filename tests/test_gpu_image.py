@@ -276,6 +276,41 @@ def test_batch_iterator_decodes_image_files(F, small_cfg, tmp_path):
     assert np.array_equal(a, b)
 
 
+def test_background_base_path_and_many_frame_sizes(F, small_cfg, tmp_path):
+    """Background files resolve against cfg.background_base_path (BatchIterator.lua:255), not the examples' base; and a
+    data set in which every frame has its own size does not grow the loader's device cache beyond its bound."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(21)
+    ex_dir, bg_dir = tmp_path / "examples", tmp_path / "backgrounds"
+    ex_dir.mkdir(); bg_dir.mkdir()
+    names = []
+    for i in range(12):
+        h, w = 200 + 7 * i, 300 + 11 * i
+        Image.fromarray(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(str(ex_dir / ("f%d.png" % i)))
+        names.append("f%d.png" % i)
+    Image.fromarray(rng.randint(0, 256, size=(240, 400, 3)).astype(np.uint8)).save(str(bg_dir / "bg.png"))
+    cfg = dict(small_cfg); cfg["examples_base_path"] = str(ex_dir); cfg["background_base_path"] = str(bg_dir)
+    model = F.vgg_small(cfg)
+    gt = dict((n, dict(rois=[F.Roi(F.Rect(40, 30, 200, 150), 1 + i % 16)])) for i, n in enumerate(names))
+    data = dict(ground_truth=gt, training_set=names, validation_set=names, background_files=["bg.png"])
+    for workers in (0, 2):
+        bound = 24 << 20
+        it = F.BatchIterator(model, data, workers=workers, cache_bytes=bound, seed=3)
+        logs = []
+        it.log = logs.append
+        for _ in range(6):
+            batch = it.nextTraining(40)
+            assert not batch[0]["positive"] and len(batch[0]["negative"]) == 2     # the background image: 5 % of 40
+            assert len(batch) >= 2
+            shapes = set(tuple(b["img"].shape) for b in batch)
+            ptrs = [b["img"].ptr for b in batch]
+            assert len(set(ptrs)) == len(ptrs), "two images of one batch share a buffer"
+            del batch
+            assert it.pool.cached <= bound
+        assert not [l for l in logs if "Invalid" in l], logs
+        assert it.pool.allocated <= bound + 8 * (3 * 470 * 830 * 4)      # cache + the frames a batch holds
+
+
 def test_golden_image_fixture_on_device(F):
     """The committed golden vectors (tests/golden/image_small.json) through the kernels."""
     import json, os

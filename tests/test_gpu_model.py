@@ -4,7 +4,7 @@ image size the oracle finishes in seconds (3x128x176, real vgg_small topology)."
 import numpy as np
 import pytest
 
-from util import VGG_SMALL_CLS, VGG_SMALL_HEADS, VGG_SMALL_LAYERS, assert_close, oracle_model
+from util import VGG_SMALL_CLS, VGG_SMALL_HEADS, VGG_SMALL_LAYERS, assert_close, oracle_model, oracle_tables
 
 pytestmark = pytest.mark.gpu
 H, W = 128, 176
@@ -120,17 +120,17 @@ class _OneBatch(object):
         return self.batch
 
 
-def test_loss_and_gradient(F, O, setup):
-    """objective.lua:45-218 on two images: losses within 1e-5 relative, gradient per SURVEY 8d."""
-    s = setup
+def check_loss_and_gradient(F, O, s, H, W, nimages=2, nrois=3, negatives=8, heads_lo=None):
+    """objective.lua:45-218 on `nimages` images: losses within 1e-5 relative, gradient per SURVEY 8d.  `s`: dict with
+    cfg, model, weights, gradient, om (oracle model), w (host copy of the weights)."""
     model, cfg = s["model"], s["cfg"]
     anchors = F.Anchors(model["pnet"], cfg["scales"])
     rng_m = np.random.RandomState(3)
     mt = F.MT19937(7)
     batch, oracle_in = [], []
-    for k in range(2):
-        rois = F.synthetic_rois(cfg, W, H, 3, 7, k)
-        pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, mt, negatives=8)
+    for k in range(nimages):
+        rois = F.synthetic_rois(cfg, W, H, nrois, 7, k)
+        pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, mt, negatives=negatives)
         sizes = F.output_map_sizes(model, H, W)
         pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)   # cleanAnchors, objective.lua:74-75
         img = F.synthetic_image(H, W, k)
@@ -140,33 +140,25 @@ def test_loss_and_gradient(F, O, setup):
     pm = _masks(rng_m, model)
     model["pnet"].drop_masks = pm
     nat = model["native"]
+    n1, n2 = [l["n"] for l in model["class_layers"]]
     bn0 = nat.bn_running.cpu().numpy().copy()
     # the oracle needs explicit cnet masks per image (R differs): draw them and hand the same to both
     g_want = np.zeros_like(s["w"]); acc = np.zeros(8); bn_o = bn0.copy()
     stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
     cm_per_image = []
     for (img, rois, pos, neg) in oracle_in:
-        fm_shapes = None
         R = len(pos) + len(neg)
-        cm = [(rng_m.rand(R, 1024) > 0.5).astype(np.float32), (rng_m.rand(R, 512) > 0.5).astype(np.float32)]
+        cm = [(rng_m.rand(R, n1) > 0.5).astype(np.float32), (rng_m.rand(R, n2) > 0.5).astype(np.float32)]
         cm_per_image.append(cm)
-        pos_idx = np.array([[a.layer, a.aspect, a.index[1], a.index[2], rois.index(r) + 1] for a, r in pos], dtype=np.int32).reshape(-1, 5)
-        pos_rect = np.array([[a.minX, a.minY, a.maxX, a.maxY] for a, r in pos], dtype=np.float64).reshape(-1, 4)
-        neg_idx = np.array([[e[0].layer, e[0].aspect, e[0].index[1], e[0].index[2]] for e in neg], dtype=np.int32).reshape(-1, 4)
-        neg_rect = np.array([[e[0].minX, e[0].minY, e[0].maxX, e[0].maxY] for e in neg], dtype=np.float64).reshape(-1, 4)
-        roi_rect = np.array([[r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY] for r in rois], dtype=np.float64)
-        roi_cls = np.array([r.class_index for r in rois], dtype=np.int32)
-        O.train_image(s["om"], s["w"], g_want, img, pos_idx, pos_rect, roi_rect, roi_cls, neg_idx, neg_rect, pm, cm, bn_o, acc)
+        O.train_image(s["om"], s["w"], g_want, img, *oracle_tables(pos, neg, rois), pm, cm, bn_o, acc)
     g_want /= acc[2]
     want = dict(pcls=acc[0] / acc[2], preg=acc[1] / acc[3], dcls=acc[6] / acc[7], dreg=acc[4] / acc[5])
 
-    class _Cnet(object):  # per-image explicit masks: wrap cnet.forward to install them in order
-        pass
     cnet = model["cnet"]
     orig_forward = cnet.forward
     it = iter(cm_per_image)
 
-    def fwd(x):
+    def fwd(x):   # per-image explicit masks: wrap cnet.forward to install them in order
         cnet.drop_masks = next(it)
         return orig_forward(x)
     cnet.forward = fwd
@@ -188,55 +180,94 @@ def test_loss_and_gradient(F, O, setup):
     # pnet test above, hold 1e-4 / 1e-3).  SURVEY 8d: "pooling argmax when no ties: exact".
     _compare_gradient(nat, grad.cpu().numpy(), g_want, 0, nat.total_params, tol_l2=1e-2, elementwise=False)
     # tensors ABOVE the first pooling decision on the backward path are unaffected: heads and cnet hold 1e-4
-    _compare_gradient(nat, grad.cpu().numpy(), g_want, 3321095, nat.total_params, tol_l2=1e-4, elementwise=False)
+    lo = model["pnet"].heads_param_range()[0]
+    if heads_lo is not None:
+        assert lo == heads_lo
+    _compare_gradient(nat, grad.cpu().numpy(), g_want, lo, nat.total_params, tol_l2=1e-4, elementwise=False)
     assert_close(nat.bn_running.cpu().numpy(), bn_o, 1e-5, "bn running")
     import torch
     nat.bn_running.copy_(torch.from_numpy(bn0))
+    return dict(loss=loss, examples=int(acc[2]))
 
 
-def test_detect(F, O, setup):
-    """Detector:detect vs the oracle.  Head logits are amplified so that the p > 0.95 test fires."""
-    s = setup
-    import torch
-    model = s["model"]
-    nat = model["native"]
-    w = s["w"].copy()
+def test_loss_and_gradient(F, O, setup):
+    """objective.lua:45-218 on two images: losses within 1e-5 relative, gradient per SURVEY 8d."""
+    check_loss_and_gradient(F, O, setup, H, W, heads_lo=3321095)
+
+
+def _amplified_weights(nat, w, ncls):
+    """Head logits amplified so that the p > 0.95 test fires, class head sharpened so that p > 0.2 does."""
+    w = w.copy()
     for off, cnt, kind, aux in nat.param_table:
         if kind == 0 and aux == 18:  # the 1x1 head convs (kW*kH*nOutputPlane = 18): amplify the 2 class logits
             v = w[off:off + cnt].reshape(18, -1)
             for a in range(3):
                 v[a * 6:a * 6 + 2] *= 60.0
-        if kind == 3 and cnt == 512 * 17:  # class head of cnet: make the arg-max confident (p > 0.2)
+        if kind == 3 and cnt == 512 * ncls:  # class head of cnet: make the arg-max confident (p > 0.2)
             w[off:off + cnt] *= 30.0
-    s["weights"].copy_(torch.from_numpy(w))
-    try:
-        img = F.synthetic_image(H, W, 5)
-        d = F.Detector(model)
+    return w
+
+
+def check_detect(F, O, model, om, w, img_seeds, H, W):
+    """Detector:detect against the oracle, every stage, on the first frame of `img_seeds` whose match list and NMS
+    pick list agree (an anchor within fp32 rounding of the 0.95 threshold, or a pair of boxes within rounding of the
+    NMS threshold, may legitimately differ between fp32-MFMA and fp64-accumulated activations; the border rule is
+    checked on every frame, and the test FAILS if no frame agrees -- nothing below is conditional)."""
+    nat = model["native"]
+    d = F.Detector(model)
+    bn = nat.bn_running.cpu().numpy()
+    chosen = None
+    for seed in img_seeds:
+        img = F.synthetic_image(H, W, seed)
         winners = d.detect(img)
-        bn = nat.bn_running.cpu().numpy()
-        ref = O.detect(s["om"], w, bn, img)
+        ref = O.detect(om, w, bn, img)
         m = d.last_scan
         gp, gidx, grect = m["p"].numpy(), m["idx"].numpy(), m["rect"].numpy()
-        # matches: identical anchor indices except those within 1e-4 of the 0.95 threshold
+
         def key(a):
             return set(map(tuple, a.tolist()))
+        # matches: identical anchor indices except those within 1e-4 of the 0.95 threshold
         border_ref = np.abs(np.exp(ref["match_p"].astype(np.float64)) - 0.95) < 1e-4
         border_got = np.abs(np.exp(gp.astype(np.float64)) - 0.95) < 1e-4
         assert key(gidx[~border_got]) - key(ref["match_idx"]) == set()
         assert key(ref["match_idx"][~border_ref]) - key(gidx) == set()
         assert len(gidx) > 10, "test image produced too few matches to be meaningful"
-        if len(gidx) == len(ref["match_idx"]) and np.array_equal(gidx, ref["match_idx"]):
-            assert_close(gp, ref["match_p"], 1e-4, "match log-prob")
-            assert_close(grect, ref["match_rect"], 1e-3, "decoded rects")
         # NMS ids: bit-exact when the oracle NMS is fed the boxes the GPU produced
         boxes = m["box"].numpy()
         assert d.last_pick.tolist() == O.nms(boxes, 0.25).tolist()
-        if len(gidx) == len(ref["match_idx"]) and d.last_pick.tolist() == ref["cand_ids"].tolist():
-            assert_close(d.last_cnet["bbox"], ref["cand_bbox"], 1e-3, "cnet bbox (eval)")
-            assert_close(d.last_cnet["cls"], ref["cand_cls"], 1e-3, "cnet log-probs (eval)")
-            got = [(x["class"], round(x["confidence"], 3)) for x in winners]
-            want = [(int(r[0]), round(float(r[1]), 3)) for r in ref["winners"]]
-            assert got == want
+        if (len(gidx) == len(ref["match_idx"]) and np.array_equal(gidx, ref["match_idx"])
+                and d.last_pick.tolist() == ref["cand_ids"].tolist()):
+            chosen = (seed, winners, ref, gp, grect)
+            break
+    assert chosen is not None, "no frame of %r gave identical match and candidate lists" % (list(img_seeds),)
+    seed, winners, ref, gp, grect = chosen
+    assert_close(gp, ref["match_p"], 1e-4, "match log-prob")
+    assert_close(grect, ref["match_rect"], 1e-3, "decoded rects")
+    assert len(ref["cand_ids"]) > 0
+    assert_close(d.last_cnet["bbox"], ref["cand_bbox"], 1e-3, "cnet bbox (eval)")
+    assert_close(d.last_cnet["cls"], ref["cand_cls"], 1e-3, "cnet log-probs (eval)")
+    # winners: {class, confidence, r2} per class in NMS pick order (classes ascending on both sides)
+    assert len(winners) == len(ref["winners"]), (len(winners), len(ref["winners"]))
+    assert [x["class"] for x in winners] == [int(r[0]) for r in ref["winners"]]
+    if len(winners):
+        assert_close([x["confidence"] for x in winners], ref["winners"][:, 1], 1e-3, "winner confidence")
+        assert_close([[x["r2"].minX, x["r2"].minY, x["r2"].maxX, x["r2"].maxY] for x in winners], ref["winners"][:, 2:6],
+                     1e-3, "winner rects (Detector.lua:107)")
+    return dict(seed=seed, matches=len(gp), candidates=len(ref["cand_ids"]), winners=len(winners), ref=ref, got=winners)
+
+
+def test_detect(F, O, setup):
+    """Detector:detect vs the oracle: matches, decoded rects, NMS picks, cnet outputs and the per-class winners."""
+    s = setup
+    import torch
+    model = s["model"]
+    nat = model["native"]
+    w = _amplified_weights(nat, s["w"], 17)
+    s["weights"].copy_(torch.from_numpy(w))
+    try:
+        r = check_detect(F, O, model, s["om"], w, range(5, 10), H, W)
+        assert r["winners"] > 0, "no winner: the back half of detect was not exercised"
+        print("detect: frame %(seed)d, %(matches)d matches, %(candidates)d candidates, %(winners)d winners" % r)
     finally:
         s["weights"].copy_(torch.from_numpy(s["w"]))
 

@@ -44,6 +44,24 @@ def test_binary_known_answers():
     assert _binary(t) == want
 
 
+def test_cuda_tensor_snapshot_reads_as_float():
+    """The reference's snapshots hold `weights` as a torch.CudaTensor over a torch.CudaStorage (the nets are :cuda()
+    before they are flattened, main.lua:86-92; utilities.lua:126-134): cutorch writes them like the Float classes."""
+    raw = (b"4\n1\n3\nV 1\n16\ntorch.CudaTensor\n1\n3\n1\n1\n"
+           b"4\n2\n3\nV 1\n17\ntorch.CudaStorage\n3\n1.5 2 -0.25\n")
+    t = t7.Reader(io.BytesIO(raw), True).object()
+    assert t.dtype == np.float32 and t.tolist() == [1.5, 2.0, -0.25]
+    rawb = (struct.pack("<ii", 4, 1) + struct.pack("<i", 3) + b"V 1" + struct.pack("<i", 16) + b"torch.CudaTensor" +
+            struct.pack("<iqqq", 1, 2, 1, 1) + struct.pack("<ii", 4, 2) + struct.pack("<i", 3) + b"V 1" +
+            struct.pack("<i", 17) + b"torch.CudaStorage" + struct.pack("<q", 2) + struct.pack("<ff", 1.5, 2.0))
+    t = t7.Reader(io.BytesIO(rawb), False).object()
+    assert t.dtype == np.float32 and t.tolist() == [1.5, 2.0]
+    # a whole {version, weights, options, stats} table with device-class weights restores into the flat vector
+    snap = (b"3\n1\n2\n2\n7\nversion\n1\n0\n2\n7\nweights\n" + raw.replace(b"4\n1\n3", b"4\n2\n3", 1).replace(b"4\n2\n3\nV 1\n17", b"4\n3\n3\nV 1\n17"))
+    obj = t7.Reader(io.BytesIO(snap), True).object()
+    assert obj["version"] == 0 and obj["weights"].tolist() == [1.5, 2.0, -0.25]
+
+
 @pytest.mark.parametrize("ascii_mode", [True, False])
 def test_round_trip(tmp_path, ascii_mode):
     rng = np.random.RandomState(0)

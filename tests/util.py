@@ -53,3 +53,15 @@ def random_boxes(rng, n, w=800, h=450, unique_y2=True):
             b[dup, 3] += rng.uniform(0.01, 1.0, int(dup.sum())).astype(np.float32)
         assert len(np.unique(b[:, 3])) == n
     return b
+
+
+def oracle_tables(pos, neg, rois):
+    """The example tables O.train_image takes, from the host mirror's lists: positives (anchor, roi) and
+    negatives (anchor,) as built by assemble_examples (BatchIterator.lua:198-225), already cleaned."""
+    pos_idx = np.array([[a.layer, a.aspect, a.index[1], a.index[2], rois.index(r) + 1] for a, r in pos], dtype=np.int32).reshape(-1, 5)
+    pos_rect = np.array([[a.minX, a.minY, a.maxX, a.maxY] for a, r in pos], dtype=np.float64).reshape(-1, 4)
+    neg_idx = np.array([[e[0].layer, e[0].aspect, e[0].index[1], e[0].index[2]] for e in neg], dtype=np.int32).reshape(-1, 4)
+    neg_rect = np.array([[e[0].minX, e[0].minY, e[0].maxX, e[0].maxY] for e in neg], dtype=np.float64).reshape(-1, 4)
+    roi_rect = np.array([[r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY] for r in rois], dtype=np.float64)
+    roi_cls = np.array([r.class_index for r in rois], dtype=np.int32)
+    return pos_idx, pos_rect, roi_rect, roi_cls, neg_idx, neg_rect
