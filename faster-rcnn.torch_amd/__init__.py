@@ -6,6 +6,8 @@ from . import _lib
 from ._lib import FrcnnError
 from .Anchors import Anchors, MT19937, manualSeed
 from .BatchIterator import BatchIterator, decode_image, find_target_size, gaussian1D
+from . import comm
+from .comm import Comm
 from .config import duplo_cfg, imgnet_cfg
 from .Detector import Detector
 from .Localizer import Localizer
@@ -21,6 +23,6 @@ from .utilities import combine_and_flatten_parameters, rmsprop
 from .vgg_large import vgg_large
 from .vgg_small import vgg_small
 
-__all__ = ["decode_image", "traindata", "t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
+__all__ = ["Comm", "comm", "decode_image", "traindata", "t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
            "create_model", "create_objective", "duplo_cfg", "extract_roi_pooling_input", "imgnet_cfg", "manualSeed", "nms",
            "rmsprop", "roi_window", "roi_windows", "vgg_large", "vgg_small"]

@@ -95,6 +95,15 @@ _SIGS = {
     "frcnn_anchors_destroy": ([vp], C.c_int),
     "frcnn_anchors_assemble": ([vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_int), vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "frcnn_comm_get_unique_id": ([vp], C.c_int),
+    "frcnn_comm_exchange_id_file": ([C.c_char_p, C.c_int, vp, C.c_int], C.c_int),
+    "frcnn_comm_init_rank": ([C.POINTER(vp), C.c_int, C.c_int, vp], C.c_int),
+    "frcnn_comm_init_rank_file": ([C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int),
+    "frcnn_comm_destroy": ([vp], C.c_int),
+    "frcnn_comm_info": ([vp, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "frcnn_allreduce_f32": ([vp, vp, C.c_longlong, vp], C.c_int),
+    "frcnn_allreduce_f64": ([vp, vp, C.c_longlong, vp], C.c_int),
+    "frcnn_broadcast_f32": ([vp, vp, C.c_longlong, C.c_int, vp], C.c_int),
     "frcnn_image_rgb2yuv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
     "frcnn_image_scale": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
     "frcnn_image_scale_u8": ([vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),

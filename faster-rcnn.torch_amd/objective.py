@@ -65,6 +65,12 @@ class _Scratch(object):
 
 
 def _dist():
+    """The exchange back end of the step: the library's own communicator when one is active (comm.activate: RCCL through
+    the C ABI, what a LuaJIT host uses), else an initialised torch.distributed process group, else None."""
+    from . import comm
+    c = comm.active()
+    if c is not None:
+        return c
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -335,6 +335,30 @@ int frcnn_anchors_assemble(frcnn_anchors *, const double *rois_host, int nroi, d
                            int negatives, unsigned int *mt_state_host, int *mt_index_host, int *ex_host,
                            double *ex_rect_host, int cap, int *npos_host, int *nneg_host);
 
+/* ---- data-parallel exchange step: communicator + all-reduce (SURVEY 8b last row, 8e) --------------
+ * Not in the reference (one process, one device: main.lua:52).  The training step shards over images; the ranks
+ * meet once per step, between the last pnet:backward (objective.lua:189) and gradient:div(cls_count)
+ * (objective.lua:197-200): sum of the flat gradient (frcnn_allreduce_f32) and of the 8 fp64 accumulators declared
+ * at objective.lua:52-58 (frcnn_allreduce_f64), then every rank applies the identical optim.rmsprop step.
+ * One process per GPU; the communicator runs RCCL (xGMI inside a node), bound at first use (dlopen "librccl.so.1").
+ * Rendezvous: rank 0 creates a 128-byte id (frcnn_comm_get_unique_id) and hands it to the other ranks by any
+ * host-side channel; frcnn_comm_init_rank_file does that through a file on a path every rank can see (rank 0 writes
+ * it atomically, the others poll up to timeout_ms; the path must not exist from a previous job).
+ * frcnn_comm_init_rank* is a collective call: every rank of the job makes it, after frcnn_set_device.
+ * The all-reduces are IN PLACE sums, asynchronous on `stream`, ordered like any other work of that stream. */
+#define FRCNN_COMM_ID_BYTES 128
+typedef struct frcnn_comm frcnn_comm;
+int frcnn_comm_get_unique_id(void *id_host);
+int frcnn_comm_exchange_id_file(const char *path, int rank, void *id_host, int timeout_ms);   /* host only, no RCCL */
+int frcnn_comm_init_rank(frcnn_comm **out_host, int nranks, int rank, const void *id_host);
+int frcnn_comm_init_rank_file(frcnn_comm **out_host, int nranks, int rank, const char *path, int timeout_ms);
+int frcnn_comm_destroy(frcnn_comm *);
+int frcnn_comm_info(const frcnn_comm *, int *nranks_host, int *rank_host);
+int frcnn_allreduce_f32(frcnn_comm *, float *buf, long long n, void *stream);
+int frcnn_allreduce_f64(frcnn_comm *, double *buf, long long n, void *stream);
+/* one-time weight broadcast after load_model / restore (main.lua:92-98) so that every replica starts identical */
+int frcnn_broadcast_f32(frcnn_comm *, float *buf, long long n, int root, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,127 @@
+"""The communicator entry points of the C ABI (include/frcnn_hip.h, SURVEY 8b last row / 8e).
+CPU: the file rendezvous between two processes (no RCCL involved).  GPU box (one MI355X): a one-rank communicator
+over the real librccl -- in-place all-reduces of both dtypes, the weight broadcast, and one whole training step whose
+exchange runs through it (every collective an identity) against the step without any exchange."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import pytest
+
+
+def _rank1(path, q):
+    import frcnn_amd as F
+    buf = C.create_string_buffer(128)
+    F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, buf, 20000)
+    q.put(buf.raw)
+
+
+def test_file_rendezvous_between_two_processes(F, tmp_path):
+    path = str(tmp_path / "id")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rank1, args=(path, q))
+    p.start()
+    time.sleep(0.5)                      # rank 1 is polling by now; the file appears atomically
+    ident = bytes(range(128))
+    F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 0, C.create_string_buffer(ident, 128), 1000)
+    got = q.get(timeout=60)
+    p.join(60)
+    assert got == ident and p.exitcode == 0
+    assert not os.path.exists(path + ".tmp")
+
+
+def test_file_rendezvous_times_out_with_a_message(F, tmp_path):
+    t0 = time.time()
+    with pytest.raises(F.FrcnnError, match="waited 200 ms"):
+        F._lib.call("frcnn_comm_exchange_id_file", str(tmp_path / "never").encode(), 3, C.create_string_buffer(128), 200)
+    assert time.time() - t0 < 5
+    with pytest.raises(F.FrcnnError):
+        F._lib.call("frcnn_comm_init_rank", C.byref(C.c_void_p()), 2, 5, C.create_string_buffer(128))   # rank >= nranks
+
+
+@pytest.mark.gpu
+def test_one_rank_communicator_on_the_gpu(F, tmp_path):
+    import torch
+    comm = F.Comm(0, 1, path=str(tmp_path / "rdv"))
+    try:
+        n, r = C.c_int(), C.c_int()
+        F._lib.call("frcnn_comm_info", comm.h, C.byref(n), C.byref(r))
+        assert (n.value, r.value) == (1, 0)
+        g = torch.randn(26784106, device="cuda")          # the flat gradient of vgg_small / duplo (107 MB)
+        want = g.clone()
+        w1 = comm.all_reduce(g[1000:5_000_000], async_op=True)    # buckets, as the objective issues them
+        w2 = comm.all_reduce(g[5_000_000:], async_op=True)
+        w3 = comm.all_reduce(g[:1000], async_op=True)
+        acc = torch.arange(8, dtype=torch.float64, device="cuda") * 0.1
+        w4 = comm.all_reduce(acc, async_op=True)
+        for w in (w1, w2, w3, w4):
+            w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        assert acc.cpu().tolist() == [k * 0.1 for k in range(8)]
+        comm.broadcast(g, 0)
+        assert torch.equal(g, want)
+        assert comm.gather_max(3.5) == 3.5
+        comm.barrier()
+        with pytest.raises(F.FrcnnError):
+            comm.all_reduce(torch.zeros(4, dtype=torch.int32, device="cuda"))
+        with pytest.raises(F.FrcnnError):
+            F._lib.call("frcnn_broadcast_f32", comm.h, F.ptr(g), 10, 1, F.stream_ptr())   # root outside the communicator
+    finally:
+        comm.destroy()
+
+
+@pytest.mark.gpu
+def test_training_step_through_the_native_communicator(F, small_cfg, tmp_path, monkeypatch):
+    """lossAndGradient + rmsprop with the exchange step on frcnn_allreduce_* (one rank: sums are identities) equals the
+    plain single-process step; the bucket schedule (cnet slice, anchor nets, deep blocks, rest) is the data-parallel one."""
+    import torch
+    cfg = dict(small_cfg)
+    model = F.vgg_small(cfg)
+    weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
+    w0 = weights.clone()
+    nat = model["native"]
+    bn0 = nat.bn_running.clone()
+    it = F.SyntheticBatchIterator(model, H=128, W=176, images_per_batch=1, pool=1)
+    R = len(F.clean_examples(it.pool[0]["positive"], F.output_map_sizes(model, 128, 176))) + \
+        len(F.clean_examples(it.pool[0]["negative"], F.output_map_sizes(model, 128, 176)))
+    rng = np.random.RandomState(1)
+    model["pnet"].drop_masks = [None if l["dropout"] <= 0 else (rng.rand(l["filters"]) > l["dropout"]).astype(np.float32) for l in model["layers"]]
+    model["cnet"].drop_masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+    res = {}
+    comm = F.Comm(0, 1, path=str(tmp_path / "rdv2"))
+    calls = []
+    orig = comm.all_reduce
+    comm.all_reduce = lambda t, async_op=False, group=None: (calls.append((t.dtype, t.numel())), orig(t, async_op, group))[1]
+    try:
+        for mode in ("native", "single"):
+            if mode == "native":
+                monkeypatch.setenv("FRCNN_COMM_FORCE", "1")
+                F.comm.activate(comm)
+            else:
+                monkeypatch.delenv("FRCNN_COMM_FORCE")
+                F.comm.activate(None)
+            stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+            f = F.create_objective(model, weights, gradient, it, stats)
+            state = dict(learningRate=1e-4, alpha=0.9)
+            _, fx = F.rmsprop(f, weights, state)
+            torch.cuda.synchronize()
+            res[mode] = (fx[0], gradient.cpu().numpy().copy(), weights.cpu().numpy().copy())
+            weights.copy_(w0); nat.bn_running.copy_(bn0)
+    finally:
+        F.comm.activate(None)
+        comm.destroy()
+        model["pnet"].drop_masks = None
+        model["cnet"].drop_masks = None
+    assert abs(res["native"][0] - res["single"][0]) <= 1e-6 * abs(res["single"][0])
+    a, b = res["native"][1], res["single"][1]
+    assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+    w0h = w0.cpu().numpy()
+    assert np.linalg.norm(res["native"][2] - res["single"][2]) <= 1e-3 * np.linalg.norm(res["single"][2] - w0h)
+    f32 = sorted(n for d, n in calls if d == torch.float32)
+    assert sum(f32) == nat.total_params, "every gradient element is exchanged exactly once"
+    assert nat.total_params - nat.pnet_params in f32          # the cnet slice goes first, as one bucket
+    assert any(d == torch.float64 and n == 8 for d, n in calls)   # the accumulators of objective.lua:52-58

@@ -66,7 +66,7 @@ def test_fullsize_loss_and_gradient(F, O):
     for off, cnt, kind, aux in nat.param_table:
         a, b = g[off:off + cnt].astype(np.float64), g_want[off:off + cnt].astype(np.float64)
         nb = np.linalg.norm(b)
-        if nb > 0:
+        if nb > 1e-6 * np.sqrt(cnt):    # (a Linear bias feeding BatchNorm has a true gradient of ~0: rounding noise only)
             worst = max(worst, np.linalg.norm(a - b) / nb)
     print("full-size step: %d examples, loss %.6f (oracle %.6f), gradient rel-L2 %.2e whole vector, %.2e worst tensor"
           % (R, loss, want["pcls"] + want["preg"], rel, worst))

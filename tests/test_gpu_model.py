@@ -195,7 +195,7 @@ def test_loss_and_gradient(F, O, setup):
     check_loss_and_gradient(F, O, setup, H, W, heads_lo=3321095)
 
 
-def _amplified_weights(nat, w, ncls):
+def _amplified_weights(nat, w, ncls, cls_gain=30.0):
     """Head logits amplified so that the p > 0.95 test fires, class head sharpened so that p > 0.2 does."""
     w = w.copy()
     for off, cnt, kind, aux in nat.param_table:
@@ -204,7 +204,7 @@ def _amplified_weights(nat, w, ncls):
             for a in range(3):
                 v[a * 6:a * 6 + 2] *= 60.0
         if kind == 3 and cnt == 512 * ncls:  # class head of cnet: make the arg-max confident (p > 0.2)
-            w[off:off + cnt] *= 30.0
+            w[off:off + cnt] *= cls_gain
     return w
 
 
