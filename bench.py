@@ -10,8 +10,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying
   "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_igemm 3x3: forward + input-gradient
                     of every 3x3 convolution) = algorithmic FLOPs of its launches / their HIP-event
                     durations, measured live over the timed steps, vs the fp32-MFMA peak;
-  "cpu_baseline" -- the CPU restatement of the reference (oracle/, "port") timed on this host on a
-                    bounded sample (one full training step on a 1/16-area frame), N=1 only.
+  "cpu_baseline" -- the CPU restatement of the reference (oracle/, "port") timed on this host, N=1 only:
+                    the training step on the benchmarked 3x450x800 frame with all cores (1 warm-up + median
+                    of 3) and with one thread on a 1/16-area frame (BASELINE.md section 4);
+  "parity"       -- the GPU step on the oracle's inputs against the oracle's loss and gradient (the run
+                    exits non-zero when they differ);
+  "other_legs"   -- BASELINE config 2 (Detector:detect, images/sec) and nms() alone at n = 300 ... 26 544,
+                    each with its CPU-restatement time and its id parity, measured after the timed region.
+  --comm native  -- the exchange step through the library's own communicator (frcnn_comm_*, the calls a LuaJIT
+                    host makes) instead of torch.distributed.
 """
 import argparse
 import ctypes as C
@@ -52,46 +59,209 @@ def conv_flops_per_image(model, H, W):
     return fwd, 3 * fwd - first
 
 
-def cpu_baseline(cfg):
-    """Oracle (CPU restatement, all host cores via OpenMP) on a bounded sample: ONE training step on a
-    3x113x200 frame (1/16 of the 450x800 pixels, same network, same example assembly); the rate is scaled
-    by the pixel ratio to the metric's unit (conv work is proportional to pixels)."""
+def _host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(cpu_model=model, logical_cpus=os.cpu_count())
+
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle as O
-    import frcnn_amd as F
-    from util import oracle_model
-    H, W = FULL_H, FULL_W   # one full-size frame: ~15 s of wall time on the box's host cores
-    model = F.vgg_small(cfg)
-    om = oracle_model(O, cfg)
-    w = model["native"].init_parameters(42)
+    from util import oracle_model, oracle_tables
+    return O, oracle_model, oracle_tables
+
+
+def parity_inputs(F, cfg, model, H, W):
+    """The inputs of SURVEY 8d for image 0 (what SyntheticBatchIterator holds as pool[0] on rank 0): 4 boxes seed 7,
+    examples from findPositive + 16 sampled negatives (MT19937 seed 7) + nearby aversion, N(0,1) frame seed 1000,
+    fixed dropout masks."""
     anchors = F.Anchors(model["pnet"], cfg["scales"])
     rois = F.synthetic_rois(cfg, W, H, 4, 7, 0)
     pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(7))
     sizes = F.output_map_sizes(model, H, W)
     pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
-    img = F.synthetic_image(H, W, 0)
-    pos_idx = np.array([[a.layer, a.aspect, a.index[1], a.index[2], rois.index(r) + 1] for a, r in pos], dtype=np.int32).reshape(-1, 5)
-    pos_rect = np.array([[a.minX, a.minY, a.maxX, a.maxY] for a, r in pos], dtype=np.float64).reshape(-1, 4)
-    neg_idx = np.array([[e[0].layer, e[0].aspect, e[0].index[1], e[0].index[2]] for e in neg], dtype=np.int32).reshape(-1, 4)
-    neg_rect = np.array([[e[0].minX, e[0].minY, e[0].maxX, e[0].maxY] for e in neg], dtype=np.float64).reshape(-1, 4)
-    roi_rect = np.array([[r.rect.minX, r.rect.minY, r.rect.maxX, r.rect.maxY] for r in rois], dtype=np.float64)
-    roi_cls = np.array([r.class_index for r in rois], dtype=np.int32)
     R = len(pos) + len(neg)
     rng = np.random.RandomState(0)
     pm = [None if l["dropout"] <= 0 else (rng.rand(l["filters"]) > l["dropout"]).astype(np.float32) for l in model["layers"]]
-    cm = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
-    bn = np.concatenate([np.zeros(1024, np.float32), np.ones(1024, np.float32)])
-    g = np.zeros_like(w); m = np.zeros_like(w); acc = np.zeros(8)
-    t0 = time.time()
-    O.train_image(om, w, g, img, pos_idx, pos_rect, roi_rect, roi_cls, neg_idx, neg_rect, pm, cm, bn, acc)
+    cm = [(rng.rand(R, l["n"]) > 0.5).astype(np.float32) for l in model["class_layers"]]
+    return dict(anchors=anchors, rois=rois, pos=pos, neg=neg, img=F.synthetic_image(H, W, 0), pm=pm, cm=cm, R=R)
+
+
+def cpu_train_step(O, om, tables, w0, inp, bn0):
+    """One training step of the CPU restatement: lossAndGradient (objective.lua:45-218) + optim.rmsprop (main.lua:133).
+    Returns (seconds, loss, gradient)."""
+    w = w0.copy(); g = np.zeros_like(w); m = np.zeros_like(w); acc = np.zeros(8); bn = bn0.copy()
+    t0 = time.perf_counter()
+    O.train_image(om, w, g, inp["img"], *tables, inp["pm"], inp["cm"], bn, acc)
     g /= max(acc[2], 1.0)
+    gk = g.copy()
     O.rmsprop(w, g, m, 1e-4, 0.9, 1e-8)
-    dt = time.time() - t0
-    ratio = (H * W) / float(FULL_H * FULL_W)
-    return dict(value=round(ratio / dt, 5), unit="images/sec", cores=O.get_threads(), kind="port",
-                sample="1 training step (pnet fwd/bwd, RPN loss, ROI pool, cnet fwd/bwd, rmsprop) of the CPU restatement "
-                       "(oracle/, fp64 accumulation, OpenMP) on one 3x%dx%d frame (%.2f of the 800x450 pixels), %d examples; "
-                       "%.2f s wall" % (H, W, ratio, R, dt))
+    dt = time.perf_counter() - t0
+    loss = acc[0] / acc[2] + (acc[1] / acc[3] if acc[3] else float("nan"))
+    return dt, loss, gk
+
+
+def cpu_baseline(F, cfg, model, w0, bn0):
+    """the CPU restatement of the reference semantics (oracle/, fp64 accumulation; NOT Torch7 --
+    the Lua reference cannot run here) timed on this host: the training step on the benchmarked 3x450x800 frame with all
+    cores (OpenMP), 1 warm-up + median of 3, and with ONE thread on a bounded sample (a 3x113x200 frame, 1/16 of the
+    pixels, rate scaled by the pixel ratio: conv work is proportional to pixels).  Also returns the oracle's loss and
+    gradient of the full frame for the parity check of the GPU step."""
+    O, oracle_model, oracle_tables = _oracle()
+    om = oracle_model(O, cfg)
+    inp = parity_inputs(F, cfg, model, FULL_H, FULL_W)
+    tables = oracle_tables(inp["pos"], inp["neg"], inp["rois"])
+    nthreads = O.get_threads()
+    times = []
+    loss = grad = None
+    for k in range(4):      # 1 warm-up + 3
+        dt, loss, grad = cpu_train_step(O, om, tables, w0, inp, bn0)
+        if k:
+            times.append(dt)
+    med = sorted(times)[1]
+    # one thread, bounded sample
+    h1, w1 = 113, 200
+    small = parity_inputs(F, cfg, model, h1, w1)
+    st = oracle_tables(small["pos"], small["neg"], small["rois"])
+    O.set_threads(1)
+    try:
+        dt1, _, _ = cpu_train_step(O, om, st, w0, small, bn0)
+    finally:
+        O.set_threads(nthreads)
+    ratio = (h1 * w1) / float(FULL_H * FULL_W)
+    out = dict(value=round(1.0 / med, 5), unit="images/sec", cores=nthreads, kind="port",
+               sample="CPU restatement of reference semantics (oracle/, plain C, fp64 accumulation, OpenMP; not Torch7): training step "
+                      "(pnet fwd, RPN loss, ROI pool, cnet fwd/bwd, ROI-pool bwd, pnet bwd, rmsprop) on the benchmarked 3x%dx%d frame, "
+                      "%d examples, %d threads, 1 warm-up + median of 3 (%s s)" % (FULL_H, FULL_W, inp["R"], nthreads,
+                                                                               "/".join("%.2f" % t for t in times)),
+               single_thread=dict(value=round(ratio / dt1, 6), unit="images/sec", cores=1,
+                                  sample="same step, 1 thread, one 3x%dx%d frame (%.4f of the pixels, rate scaled by that ratio), "
+                                         "%d examples, %.2f s" % (h1, w1, ratio, small["R"], dt1)),
+               host=_host_info())
+    return out, inp, loss, grad
+
+
+def gpu_parity_step(F, model, weights, gradient, w0, bn0, inp):
+    """The GPU step on the oracle's inputs (explicit dropout masks): returns (loss, gradient as numpy)."""
+    import torch
+    nat = model["native"]
+    weights.copy_(torch.from_numpy(w0)); nat.bn_running.copy_(torch.from_numpy(bn0))
+    model["pnet"].drop_masks = inp["pm"]; model["cnet"].drop_masks = inp["cm"]
+
+    class _One(object):
+        def nextTraining(self, count=None):
+            return [dict(img=inp["img"], positive=inp["pos"], negative=inp["neg"])]
+    try:
+        stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+        f = F.create_objective(model, weights, gradient, _One(), stats)
+        loss, grad = f(weights)
+        g = grad.cpu().numpy().copy()
+    finally:
+        model["pnet"].drop_masks = None; model["cnet"].drop_masks = None
+    return loss, g
+
+
+def amplified(nat, w, ncls, gain=30.0):
+    """Head logits x30 so that a realistic number of anchors passes Detector.lua:54's p > 0.95 on random weights, class
+    head x200 so that some candidates pass the 0.2 confidence gate (Detector.lua:115)."""
+    w = w.copy()
+    for off, cnt, kind, aux in nat.param_table:
+        if kind == 0 and aux == 18:
+            v = w[off:off + cnt].reshape(18, -1)
+            for a in range(3):
+                v[a * 6:a * 6 + 2] *= gain
+        if kind == 3 and cnt == 512 * ncls:
+            w[off:off + cnt] *= 200.0
+    return w
+
+
+def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
+    """BASELINE config 2: Detector:detect (Detector.lua:17-141) on synthetic 3x450x800 frames, images resident in HBM;
+    beside it the CPU restatement on the same frames (median of 3 after 1 warm-up) and the parity of its outputs."""
+    import torch
+    nat = model["native"]
+    wa = amplified(nat, w0, cfg["class_count"] + 1)
+    weights.copy_(torch.from_numpy(wa)); nat.bn_running.copy_(torch.from_numpy(bn0))
+    d = F.Detector(model)
+    host = [F.synthetic_image(FULL_H, FULL_W, i) for i in range(4)]
+    imgs = [F.to_device(x) for x in host]
+    for i in range(4):
+        r = d.detect(imgs[i])
+    torch.cuda.synchronize()
+    n = 40
+    t0 = time.perf_counter()
+    for i in range(n):
+        r = d.detect(imgs[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out = dict(metric="images/sec (vgg_small 800x450 inference: Detector:detect)", value=round(1.0 / dt, 2), ms_per_image=round(dt * 1e3, 3),
+               frames=n, matches=int(d.last_scan["n"]), candidates=int(len(d.last_pick)), winners=len(r),
+               note="head logits amplified x30 (random weights would pass no anchor at p > 0.95)")
+    if with_cpu:
+        O, oracle_model, _ = _oracle()
+        om = oracle_model(O, cfg)
+        times = []
+        same_matches = same_picks = same_winners = None
+        for k in range(4):
+            t0 = time.perf_counter()
+            ref = O.detect(om, wa, bn0, host[k % 4])
+            if k:
+                times.append(time.perf_counter() - t0)
+        # parity on the last frame the oracle saw (k = 3): anchor indices, NMS candidate ids, winner classes
+        win = d.detect(imgs[3])
+        gi = d.last_scan["idx"].numpy()
+        same_matches = bool(gi.shape == ref["match_idx"].shape and np.array_equal(gi, ref["match_idx"]))
+        same_picks = bool(list(d.last_pick) == ref["cand_ids"].tolist())
+        same_winners = bool([x["class"] for x in win] == [int(v[0]) for v in ref["winners"]])
+        # NMS ids on identical boxes are always required to be bit-exact (fp32 activations may move an anchor across 0.95)
+        picks_on_gpu_boxes = bool(list(d.last_pick) == O.nms(d.last_scan["box"].numpy(), 0.25).tolist())
+        out["cpu_baseline"] = dict(value=round(1.0 / sorted(times)[1], 4), unit="images/sec", cores=O.get_threads(), kind="port",
+                                   sample="orc_detect on the same frames, 1 warm-up + median of 3 (%s s)" % "/".join("%.2f" % t for t in times))
+        out["parity"] = dict(match_indices_identical=same_matches, nms_candidates_identical=same_picks,
+                             winner_classes_identical=same_winners, nms_ids_identical_on_gpu_boxes=picks_on_gpu_boxes,
+                             oracle_matches=int(len(ref["match_idx"])), oracle_candidates=int(len(ref["cand_ids"])),
+                             oracle_winners=int(len(ref["winners"])))
+    weights.copy_(torch.from_numpy(w0))
+    return out
+
+
+def nms_leg(F, with_cpu):
+    """BASELINE.md 4(c): nms() alone at n = 300 / 2000 / 6000 / 26544 boxes (unique y2 keys), thresholds 0.25 and 0.1;
+    boxes resident in HBM, ids read back; median of 10.  CPU restatement: 1 thread (nms.lua is a serial loop)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import random_boxes
+    O = _oracle()[0] if with_cpu else None
+    rows = []
+    for n in (300, 2000, 6000, 26544):
+        b = random_boxes(np.random.RandomState(n), n)
+        db = F.DeviceTensor.from_numpy(b)
+        for thr in (0.25, 0.1):
+            pick = F.nms(db, thr, None)
+            ts = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pick = F.nms(db, thr, None)
+                ts.append(time.perf_counter() - t0)
+            row = dict(n=n, overlap=thr, kept=int(len(pick)), gpu_ms=round(sorted(ts)[5] * 1e3, 4))
+            if O is not None:
+                cs = []
+                for _ in range(10 if n <= 6000 else 3):
+                    t0 = time.perf_counter()
+                    want = O.nms(b, thr)
+                    cs.append(time.perf_counter() - t0)
+                row["cpu_ms"] = round(sorted(cs)[len(cs) // 2] * 1e3, 3)
+                row["ids_identical"] = bool(list(pick) == want.tolist())
+            rows.append(row)
+    return rows
 
 
 def main():
@@ -105,6 +275,9 @@ def main():
     ap.add_argument("--model", default="vgg_small", choices=["vgg_small", "vgg_large"],
                     help="vgg_large = SURVEY 8d config 5 (config/imagenet.lua, use --height 600 --width 1000); not the bench line")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
+    ap.add_argument("--no-other-legs", action="store_true", help="skip the inference / nms legs")
+    ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "torch"), choices=["torch", "native"],
+                    help="exchange back end at N > 1: torch.distributed ('nccl' = RCCL) or the C ABI's frcnn_comm_* (RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -118,7 +291,13 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    native_comm = None
+    if world > 1 and args.comm == "native":
+        import frcnn_amd as F0
+        F0._lib.call("frcnn_set_device", local_rank)
+        native_comm = F0.Comm.from_env()       # RCCL through the C ABI; no torch.distributed process group at all
+        F0.comm.activate(native_comm)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             # one node: the host-side (gloo) subgroup of the objective binds to loopback instead of resolving the hostname
@@ -141,7 +320,9 @@ def main():
         F.rmsprop(f, weights, state)  # main.lua:133
 
     def barrier():
-        if world > 1:
+        if native_comm is not None:
+            native_comm.barrier()
+        elif world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,10 +378,12 @@ def main():
             a2 = (f2[0] / 1e12) / (m2[0] / 1e3)
             iso = dict(achieved=round(a2, 2), frac=round(a2 / FP32_MFMA_PEAK_TFLOPS, 4), avg_launch_ms=round(m2[0] / max(l2[0], 1), 4),
                        note="same kernel with frcnn_set_option('side_stream', 0): no concurrent weight-gradient launches")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if native_comm is not None:
+        dt = native_comm.gather_max(dt)
+    elif world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dt = float(tmax.item())
 
     if rank == 0:
         fwd_flops, train_flops = conv_flops_per_image(model, H, W)
@@ -239,10 +422,34 @@ def main():
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),
         )
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        out["config"]["exchange"] = ("frcnn_comm (RCCL through the C ABI)" if native_comm is not None else
+                                     "torch.distributed nccl (RCCL)" if world > 1 else "none (single process)")
+        ok = True
+        full = args.model == "vgg_small" and (H, W) == (FULL_H, FULL_W)
+        if world == 1 and not args.no_cpu_baseline and full:
+            nat = model["native"]
+            w0 = nat.init_parameters(42)
+            bn0 = np.concatenate([np.zeros(1024, np.float32), np.ones(1024, np.float32)])
+            base, inp, o_loss, o_grad = cpu_baseline(F, cfg, model, w0, bn0)
+            out["cpu_baseline"] = base
+            g_loss, g_grad = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
+            rel = float(np.linalg.norm(g_grad.astype(np.float64) - o_grad) / np.linalg.norm(o_grad.astype(np.float64)))
+            ok = abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3
+            out["parity"] = dict(what="lossAndGradient on the benchmarked frame, same inputs and dropout masks: GPU vs CPU restatement",
+                                 loss_gpu=g_loss, loss_oracle=float(o_loss), loss_tolerance=1e-5,
+                                 gradient_rel_l2=rel, gradient_tolerance=1e-3, examples=inp["R"], ok=bool(ok))
+            if not args.no_other_legs:
+                out["other_legs"] = dict(inference=inference_leg(F, cfg, model, weights, w0, bn0, True), nms=nms_leg(F, True))
+                ok = ok and all(r["ids_identical"] for r in out["other_legs"]["nms"]) \
+                    and out["other_legs"]["inference"]["parity"]["nms_ids_identical_on_gpu_boxes"]
         print(json.dumps(out))
-    if world > 1:
+        if not ok:
+            sys.stderr.write("bench.py: PARITY FAILURE (see the 'parity' / 'other_legs' objects of the JSON line)\n")
+            sys.stdout.flush()
+            os._exit(3)
+    if native_comm is not None:
+        native_comm.destroy()
+    elif world > 1:
         dist.destroy_process_group()
 
 
