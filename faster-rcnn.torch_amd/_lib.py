@@ -48,6 +48,7 @@ _SIGS = {
     "frcnn_stream_sync": ([vp], C.c_int),
     "frcnn_zero": ([vp, C.c_size_t, vp], C.c_int),
     "frcnn_scale": ([vp, C.c_longlong, C.c_float, vp], C.c_int),
+    "frcnn_add": ([vp, vp, C.c_longlong, vp], C.c_int),
     "frcnn_prof_enable": ([C.c_int], C.c_int),
     "frcnn_prof_collect": ([vp, vp, vp, vp], C.c_int),
     "frcnn_nms_workspace_bytes": ([C.c_int], C.c_size_t),

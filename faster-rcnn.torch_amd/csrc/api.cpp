@@ -99,6 +99,10 @@ int frcnn_stream_sync(void* stream) {
 }
 int frcnn_zero(void* ptr, size_t bytes, void* stream) { return fill_zero(ptr, bytes, S(stream)); }
 int frcnn_scale(float* x, long long n, float s, void* stream) { return scale_inplace(x, n, s, S(stream)); }
+int frcnn_add(float* y, const float* x, long long n, void* stream) {
+  FR_CHECK(y && x && n >= 0, "frcnn_add: bad arguments");
+  return n ? add_inplace(y, x, n, S(stream)) : FRCNN_OK;
+}
 
 int frcnn_prof_enable(int class_mask) {
   g_prof_mask = (unsigned)class_mask;

@@ -56,6 +56,7 @@ int frcnn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 int frcnn_stream_sync(void *stream);
 int frcnn_zero(void *ptr, size_t bytes, void *stream);            /* gradient:zero(), objective.lua:49 */
 int frcnn_scale(float *x, long long n, float s, void *stream);    /* gradient:div(n), objective.lua:200 */
+int frcnn_add(float *y, const float *x, long long n, void *stream);   /* y:add(x), objective.lua:106,114,184 */
 
 /* ---- per-kernel-class HIP-event profile (bench.py roofline leg) ---------------------- */
 #define FRCNN_KC_CONV_IGEMM_K3 0

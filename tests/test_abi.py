@@ -75,6 +75,70 @@ def test_lua_binding_in_sync_with_header():
     assert used <= declared, used - declared
 
 
+def _lua_code(txt):
+    """Lua source with comments and string literals blanked (enough for keyword counting)."""
+    import re
+    txt = re.sub(r"--\[\[.*?\]\]", " ", txt, flags=re.S)
+    txt = re.sub(r"\[\[.*?\]\]", " S ", txt, flags=re.S)
+    out = []
+    for line in txt.splitlines():
+        res, i, n = [], 0, len(line)
+        while i < n:
+            c = line[i]
+            if c == "-" and line[i:i + 2] == "--":
+                break
+            if c in "'\"":
+                j = i + 1
+                while j < n and line[j] != c:
+                    j += 2 if line[j] == "\\" else 1
+                res.append(" S ")
+                i = j + 1
+                continue
+            res.append(c)
+            i += 1
+        out.append("".join(res))
+    return "\n".join(out)
+
+
+def test_lua_drop_in_files_are_consistent_with_the_abi():
+    """bindings/objective_hip.lua / Detector_hip.lua / frcnn_hip.lua cannot be executed here (no Lua runtime in the
+    image).  What can be checked: every C.frcnn_* they call is declared by the generated cdef (= the header), blocks are
+    balanced (function / do / then / repeat vs end / until), the globals the reference's call sites need are defined, and
+    pnet.outnode.children[i] is built as the node chain Localizer.lua:8-36 walks (.data.module leaf, .children[1])."""
+    import re
+    lua = open(os.path.join(ROOT, "bindings", "frcnn_hip.lua")).read()
+    cdef = lua[lua.index("ffi.cdef[["):lua.index("]]")]
+    declared = set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", cdef))
+    used_all = set()
+    for fn in ("frcnn_hip.lua", "objective_hip.lua", "Detector_hip.lua"):
+        txt = open(os.path.join(ROOT, "bindings", fn)).read()
+        code = _lua_code(txt[txt.index("]]") + 2:] if fn == "frcnn_hip.lua" else txt)
+        used = set(re.findall(r"\bC\.(frcnn_[a-z0-9_]+)", code))
+        assert used <= declared, (fn, used - declared)
+        used_all |= used
+        words = re.findall(r"[A-Za-z_][A-Za-z0-9_]*", code)
+        opens = words.count("function") + words.count("do") + words.count("then") - words.count("elseif") + words.count("repeat")
+        closes = words.count("end") + words.count("until")
+        assert opens == closes, "%s: %d block openers vs %d closers" % (fn, opens, closes)
+        assert code.count("(") == code.count(")") and code.count("{") == code.count("}") and code.count("[") == code.count("]"), fn
+    # the batched entry points of the training step and of detect, and the exchange step, are all reached from Lua
+    for name in ("frcnn_pnet_forward_async_heads", "frcnn_pnet_anchor_loss_begin", "frcnn_pnet_anchor_loss_wait",
+                 "frcnn_pnet_set_sparse_deltas", "frcnn_roi_pool_forward", "frcnn_roi_pool_backward", "frcnn_cnet_losses",
+                 "frcnn_cnet_forward", "frcnn_cnet_backward", "frcnn_pnet_backward", "frcnn_rpn_scan", "frcnn_nms_device",
+                 "frcnn_cnet_decode", "frcnn_allreduce_f32", "frcnn_allreduce_f64", "frcnn_comm_init_rank_file",
+                 "frcnn_broadcast_f32", "frcnn_rmsprop", "frcnn_add"):
+        assert name in used_all, name
+    obj = open(os.path.join(ROOT, "bindings", "objective_hip.lua")).read()
+    det = open(os.path.join(ROOT, "bindings", "Detector_hip.lua")).read()
+    assert re.search(r"^function extract_roi_pooling_input\(input_rect, localizer, feature_layer_output\)", obj, re.M)
+    assert re.search(r"^function create_objective\(model, weights, gradient, batch_iterator, stats\)", obj, re.M)
+    assert "torch.class('Detector')" in det and "function Detector:detect(input)" in det and "function Detector:__init(model)" in det
+    shim = open(os.path.join(ROOT, "bindings", "frcnn_shims.lua.in")).read()
+    assert "node = { data = { module = leaf }, children = { node } }" in shim
+    for g in ("create_model =", "combine_and_flatten_parameters =", "nms =", "cutorch.setDevice =", "optim.rmsprop =", "save_model ="):
+        assert g in shim, g
+
+
 def test_kernel_class_table_matches_header():
     """frcnn_prof_collect fills FRCNN_KC_COUNT entries: the header's constants and the Python name table must agree."""
     import re
