@@ -316,7 +316,13 @@ def main():
     f = F.create_objective(model, weights, gradient, it, stats)
     state = dict(learningRate=1e-4, alpha=0.9)  # main.lua:122
 
+    user_stream = torch.cuda.Stream() if os.environ.get("FRCNN_BENCH_STREAM") else None   # (experiment: not the NULL stream)
+
     def step():
+        if user_stream is not None:
+            with torch.cuda.stream(user_stream):
+                F.rmsprop(f, weights, state)
+            return
         F.rmsprop(f, weights, state)  # main.lua:133
 
     def barrier():

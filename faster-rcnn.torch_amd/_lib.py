@@ -42,6 +42,8 @@ _SIGS = {
     "frcnn_device_name": ([C.c_char_p, C.c_int], C.c_int),
     "frcnn_malloc": ([C.POINTER(vp), C.c_size_t], C.c_int),
     "frcnn_free": ([vp], C.c_int),
+    "frcnn_host_alloc": ([C.POINTER(vp), C.c_size_t], C.c_int),
+    "frcnn_host_free": ([vp], C.c_int),
     "frcnn_memcpy_h2d": ([vp, vp, C.c_size_t, vp], C.c_int),
     "frcnn_memcpy_d2h": ([vp, vp, C.c_size_t, vp], C.c_int),
     "frcnn_memcpy_d2d": ([vp, vp, C.c_size_t, vp], C.c_int),

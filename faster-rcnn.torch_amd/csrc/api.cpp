@@ -19,7 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- profiler
-struct ProfRec { int klass; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { int klass; double flops, bytes; hipEvent_t a, b; hipStream_t s; };
+static hipEvent_t g_prof_base = nullptr;
 static unsigned g_prof_mask = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -39,7 +40,7 @@ void prof_before(int, hipStream_t s) {
 }
 void prof_after(int klass, double flops, double bytes, hipStream_t s) {
   ProfRec r;
-  r.klass = klass; r.flops = flops; r.bytes = bytes; r.a = g_pending; r.b = get_event();
+  r.klass = klass; r.flops = flops; r.bytes = bytes; r.a = g_pending; r.b = get_event(); r.s = s;
   (void)hipEventRecord(r.b, s);
   g_recs.push_back(r);
 }
@@ -81,6 +82,15 @@ int frcnn_free(void* ptr) {
   FR_HIP(hipFree(ptr));
   return FRCNN_OK;
 }
+int frcnn_host_alloc(void** ptr, size_t bytes) {
+  FR_CHECK(ptr, "frcnn_host_alloc: NULL result pointer");
+  FR_HIP(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault));
+  return FRCNN_OK;
+}
+int frcnn_host_free(void* ptr) {
+  FR_HIP(hipHostFree(ptr));
+  return FRCNN_OK;
+}
 int frcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
   FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
   return FRCNN_OK;
@@ -105,19 +115,31 @@ int frcnn_add(float* y, const float* x, long long n, void* stream) {
 }
 
 int frcnn_prof_enable(int class_mask) {
+  if (class_mask && !g_prof_mask && getenv("FRCNN_PROF_DUMP")) {   // debug: time base for the per-launch start offsets
+    if (!g_prof_base) FR_HIP(hipEventCreate(&g_prof_base));
+    FR_HIP(hipDeviceSynchronize());
+    FR_HIP(hipEventRecord(g_prof_base, nullptr));
+  }
   g_prof_mask = (unsigned)class_mask;
   return FRCNN_OK;
 }
 int frcnn_prof_collect(long long* launches, double* ms, double* flops, double* bytes) {
   FR_HIP(hipDeviceSynchronize());
   for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; }
+  FILE* dump = (getenv("FRCNN_PROF_DUMP") && g_prof_base) ? fopen(getenv("FRCNN_PROF_DUMP"), "a") : nullptr;
   for (auto& r : g_recs) {
     float t = 0.f;
     FR_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    if (dump) {   // debug timeline: class, stream, start offset (us) from frcnn_prof_enable, duration (us)
+      float t0 = 0.f;
+      if (hipEventElapsedTime(&t0, g_prof_base, r.a) == hipSuccess)
+        fprintf(dump, "%d %p %.1f %.1f\n", r.klass, (void*)r.s, t0 * 1e3, t * 1e3);
+    }
     launches[r.klass] += 1; ms[r.klass] += t; flops[r.klass] += r.flops; bytes[r.klass] += r.bytes;
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
+  if (dump) { fprintf(dump, "-1 0 0 0\n"); fclose(dump); }
   g_recs.clear();
   return FRCNN_OK;
 }

@@ -584,8 +584,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int nSplit,
 
 // library-owned split-K workspace (grown outside the steady state)
 // (one per stream that may run split-K convolutions concurrently: slot 0 = caller's stream, 1 = side stream)
-static void* g_ig_ws[2] = {nullptr, nullptr};
-static size_t g_ig_ws_bytes[2] = {0, 0};
+static void* g_ig_ws[8] = {};
+static size_t g_ig_ws_bytes[8] = {};
 static int ig_workspace(size_t need, float** out, int slot) {
   if (need > g_ig_ws_bytes[slot]) {
     if (g_ig_ws[slot]) FR_HIP(hipFree(g_ig_ws[slot]));
@@ -705,7 +705,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
     // (fp32 atomics on the shared result serialise in the memory-side atomic units: 2 splits cost 5-10%
     // more than the slab pass, 5-8 splits 50-70 us per launch)
     float* ws = nullptr;
-    FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 1));
+    FR_TRY(ig_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
   static const int ig_dma = getenv("FRCNN_IG_DMA") ? atoi(getenv("FRCNN_IG_DMA")) : 1;

@@ -319,8 +319,8 @@ __global__ void gemm_reduce_kernel(const float* __restrict__ slab, int nSplit, i
 }
 
 // library-owned split-K workspaces (one per stream that may run GEMMs concurrently; grown outside the steady state)
-static void* g_gemm_ws[2] = {nullptr, nullptr};
-static size_t g_gemm_ws_bytes[2] = {0, 0};
+static void* g_gemm_ws[8] = {};
+static size_t g_gemm_ws_bytes[8] = {};
 static int gemm_workspace(size_t need, float** out, int slot) {
   if (need > g_gemm_ws_bytes[slot]) {
     if (g_gemm_ws[slot]) FR_HIP(hipFree(g_gemm_ws[slot]));
@@ -355,7 +355,7 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
   float* user_C = C;
   if (splitK > 1) {   // partial products go to slabs with plain stores; one pass folds them (+ bias, + accumulate)
     float* ws = nullptr;
-    FR_TRY(gemm_workspace((size_t)splitK * M * N * 4, &ws, ws_slot & 1));
+    FR_TRY(gemm_workspace((size_t)splitK * M * N * 4, &ws, ws_slot & 7));
     p.C = ws; p.bias = nullptr; p.out_mode = 3;
   }
   dim3 grid(tn, tm, splitK);

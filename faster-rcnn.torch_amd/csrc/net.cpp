@@ -66,6 +66,9 @@ struct Head {
   DevBuf delta;               // delta_outputs[h]
   const int* sp_pos = nullptr; // optional one-shot hint: delta is zero outside these positions
   int sp_count = -1;
+  DevBuf spD, spHX, spHY, spGH, spCol, spDX;  // scratch of the sparse backward pass (per anchor net: they run concurrently)
+  hipStream_t stream = nullptr;  // this anchor net's own stream (forward and sparse backward beside the other anchor nets)
+  hipEvent_t done = nullptr;     // last work queued on `stream`
 };
 
 struct ClsLayer {
@@ -91,7 +94,6 @@ struct frcnn_model {
   int H = 0, W = 0;            // current image size
   int training = 0;
   DevBuf delta_last;           // delta_outputs[nheads+1]
-  DevBuf spD, spHX, spHY, spGH, spCol, spDX;  // sparse head backward scratch
   DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
@@ -104,6 +106,7 @@ struct frcnn_model {
   bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
   hipEvent_t loss_ev = nullptr;    // anchor losses of frcnn_pnet_anchor_loss_begin are final (side stream)
+  hipEvent_t chain_ev = nullptr;   // ... and the pooled-map gradient buffers are zeroed: the anchor nets' backward may start
   std::vector<hipEvent_t> block_ev;   // block b's parameter gradients are final (recorded by frcnn_pnet_backward)
   bool block_ev_valid = false;
   bool loss_pending = false;
@@ -328,14 +331,21 @@ int frcnn_model_destroy(frcnn_model* m) {
   auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.x.release(); c.gx.release(); };
   for (auto& c : m->convs) rel(c);
   for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); }
-  for (auto& h : m->heads) { rel(h.c3); rel(h.c1); h.delta.release(); }
+  for (auto& h : m->heads) {
+    rel(h.c3); rel(h.c1); h.delta.release();
+    h.spD.release(); h.spHX.release(); h.spHY.release(); h.spGH.release(); h.spCol.release(); h.spDX.release();
+  }
   for (auto& l : m->cls) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
-  m->spD.release(); m->spHX.release(); m->spHY.release(); m->spGH.release(); m->spCol.release(); m->spDX.release();
   m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
+  for (auto& h : m->heads) {
+    if (h.done) (void)hipEventDestroy(h.done);
+    if (h.stream) (void)hipStreamDestroy(h.stream);
+  }
+  if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
   if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
   for (auto e : m->block_ev) (void)hipEventDestroy(e);
@@ -407,16 +417,48 @@ static int ensure_side(frcnn_model* m) {
     FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&m->chain_ev, hipEventDisableTiming));
+    // FRCNN_HEAD_STREAMS=1: one stream per anchor net (the four nets are independent of each other: forward a k x k and
+    // a 1 x 1 convolution on a pooled map; backward on the sampled anchors ~17 small launches each), so that their chains
+    // run beside each other instead of one after the other.  Measured on the training step: the anchor nets' backward
+    // chains shrink from 670 to 310 us, but the classification net's chain on the caller's stream, which runs beside them,
+    // slows down by as much (both are bound by the launch rate of small kernels): 223.6 against 225.4 images/s.  Off by
+    // default: all anchor nets on the one side stream.
+    static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 0;
+    for (auto& h : m->heads) {
+      if (head_streams) FR_HIP(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+      FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+    }
   }
   return FRCNN_OK;
 }
 
+static hipStream_t head_stream(frcnn_model* m, size_t i) { return m->heads[i].stream ? m->heads[i].stream : m->side; }
+static int head_slot(frcnn_model* m, size_t i) { return m->heads[i].stream ? 2 + (int)(i % 6) : 1; }   // split-K workspace slot
+
 // the caller's stream waits for everything queued on the side stream so far
+static int join_heads(frcnn_model* m, hipStream_t s) {
+  for (auto& h : m->heads) {
+    if (!h.stream) continue;
+    FR_HIP(hipEventRecord(h.done, h.stream));
+    FR_HIP(hipStreamWaitEvent(s, h.done, 0));
+  }
+  return FRCNN_OK;
+}
 static int join_side(frcnn_model* m, hipStream_t s) {
   if (!m->side || !m->side_busy) return FRCNN_OK;
+  FR_TRY(join_heads(m, s));
   FR_HIP(hipEventRecord(m->join_ev, m->side));
   FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
   m->side_busy = false;
+  return FRCNN_OK;
+}
+
+// stream `to` waits for everything enqueued on `from` so far (event ev is re-recorded: its previous waiters are queued already)
+static int chain(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  if (from == to) return FRCNN_OK;
+  FR_HIP(hipEventRecord(ev, from));
+  FR_HIP(hipStreamWaitEvent(to, ev, 0));
   return FRCNN_OK;
 }
 
@@ -430,6 +472,20 @@ static int fork_side(frcnn_model* m, hipStream_t s, size_t idx) {
   }
   FR_HIP(hipEventRecord(m->fork_ev[idx], s));
   FR_HIP(hipStreamWaitEvent(m->side, m->fork_ev[idx], 0));
+  m->side_busy = true;
+  return FRCNN_OK;
+}
+
+// stream `to` (the side stream or an anchor net's own) waits for everything enqueued on `s` so far
+static int fork_to(frcnn_model* m, hipStream_t s, hipStream_t to, size_t idx) {
+  FR_TRY(ensure_side(m));
+  while (m->fork_ev.size() <= idx) {
+    hipEvent_t e;
+    FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->fork_ev.push_back(e);
+  }
+  FR_HIP(hipEventRecord(m->fork_ev[idx], s));
+  FR_HIP(hipStreamWaitEvent(to, m->fork_ev[idx], 0));
   m->side_busy = true;
   return FRCNN_OK;
 }
@@ -503,34 +559,29 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     cur = blk.pooled.f();
     cur_slope = nullptr;
     cur_scale = nullptr;
-    // anchor nets on an earlier block's map run beside the following blocks
+    // anchor nets on an earlier block's map run beside the following blocks, each on its own stream
     if (use_side && b + 1 < m->blocks.size()) {
-      bool forked = false;
-      for (auto& h : m->heads) {
+      FR_TRY(ensure_side(m));
+      for (size_t i = 0; i < m->heads.size(); ++i) {
+        Head& h = m->heads[i];
         if (h.input != (int)b) continue;
-        if (!forked) {
-          FR_TRY(fork_side(m, s, b));
-          forked = true;
-        }
-        FR_TRY(head_forward(m, h, w, m->side, 1));
+        FR_TRY(fork_to(m, s, head_stream(m, i), 16 + i));
+        FR_TRY(head_forward(m, h, w, head_stream(m, i), head_slot(m, i)));
       }
     }
   }
-  // heads on the LAST block's map: the heaviest stays on the caller's stream, the others share the side stream
+  // heads on the LAST block's map: the heaviest stays on the caller's stream, the others run beside it
   {
     const int last = (int)m->blocks.size() - 1;
     int heavy = -1;
     for (size_t i = 0; i < m->heads.size(); ++i)
       if ((!use_side || m->heads[i].input == last) && (heavy < 0 || m->heads[i].c3.k > m->heads[heavy].c3.k)) heavy = (int)i;
-    if (async_heads) heavy = -1;   // the caller's stream goes on with the last map; every anchor net stays on the side stream
-    bool forked = false;
+    if (async_heads) heavy = -1;   // the caller's stream goes on with the last map; every anchor net stays off it
+    if (use_side) FR_TRY(ensure_side(m));
     for (size_t i = 0; use_side && i < m->heads.size(); ++i) {
       if (m->heads[i].input != last || (int)i == heavy) continue;
-      if (!forked) {
-        FR_TRY(fork_side(m, s, m->blocks.size()));
-        forked = true;
-      }
-      FR_TRY(head_forward(m, m->heads[i], w, m->side, 1));
+      FR_TRY(fork_to(m, s, head_stream(m, i), 16 + i));
+      FR_TRY(head_forward(m, m->heads[i], w, head_stream(m, i), head_slot(m, i)));
     }
     for (size_t i = 0; i < m->heads.size(); ++i)
       if ((int)i == heavy || (!use_side)) FR_TRY(head_forward(m, m->heads[i], w, s, 0));
@@ -582,63 +633,90 @@ int frcnn_pnet_zero_deltas(frcnn_model* m, void* stream) {
   return FRCNN_OK;
 }
 
-// anchor-net part of pnet:backward: gradients of the head parameters, input gradients added into the pooled
-// maps' gradient buffers (nngraph fan-out).  Runs on stream s with split-K workspace slot ws_slot.
-static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream_t s, int ws_slot) {
-  for (auto& h : m->heads) {
-    Block& in = m->blocks[h.input];
-    Conv &a = h.c3, &c = h.c1;
-    const long hw1 = (long)c.Ho * c.Wo;
-    if (h.sp_count >= 0 && h.sp_count <= SPARSE_MAX_POS) {
-      // ---- sparse path: the same arithmetic restricted to the P positions where delta is non-zero
-      const int P = h.sp_count;
-      const int* pos = h.sp_pos;
-      h.sp_count = -1; h.sp_pos = nullptr;   // one-shot hint
-      if (P == 0) continue;                  // no example on this head: every gradient term is zero
-      const int n = a.Cout, ckk = a.Cin * a.k * a.k;
-      FR_TRY(m->spD.ensure((size_t)HEAD_OUT * SPARSE_MAX_POS * 4));
-      FR_TRY(m->spHX.ensure((size_t)n * SPARSE_MAX_POS * 4));
-      FR_TRY(m->spHY.ensure((size_t)n * SPARSE_MAX_POS * 4));
-      FR_TRY(m->spGH.ensure((size_t)n * SPARSE_MAX_POS * 4));
-      FR_TRY(m->spCol.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
-      FR_TRY(m->spDX.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
-      float *D = m->spD.f(), *HX = m->spHX.f(), *HY = m->spHY.f(), *GH = m->spGH.f(), *COL = m->spCol.f(), *DX = m->spDX.f();
-      FR_TRY(gather_positions(h.delta.f(), HEAD_OUT, hw1, pos, P, D, nullptr, nullptr, s));
-      FR_TRY(gather_positions(a.x.f(), n, hw1, pos, P, HX, w + a.a_off, HY, s));
-      // 1x1 conv: gW1[18][n] += D[18][P] * HY[n][P]^T ; gb1 += rowsum(D)
-      FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s, ws_slot));
-      FR_TRY(channel_sum(D, HEAD_OUT, P, grad + c.b_off, s));
-      // GH[n][P] = W1^T[n][18] * D[18][P], then PReLU backward (+ bias / slope gradients of the k x k conv)
-      FR_TRY(gemm_f32(w + c.w_off, 1, n, D, P, 1, GH, P, n, P, HEAD_OUT, OUT_STORE, nullptr, s, ws_slot));
-      FR_TRY(act_backward(GH, HX, n, P, w + a.a_off, nullptr, GH, grad + a.b_off, grad + a.a_off, s));
-      // k x k conv: gW[n][ckk] += GH[n][P] * COL[P][ckk]
-      FR_TRY(im2col_positions(in.pooled.f(), a.Cin, a.H, a.W, a.k, a.Wo, pos, P, COL, s));
-      FR_TRY(gemm_f32(GH, P, 1, COL, ckk, 1, grad + a.w_off, ckk, n, ckk, P, OUT_ADD, nullptr, s, ws_slot));
-      // DX[P][ckk] = GH^T[P][n] * W[n][ckk], scattered back into the pooled-map gradient
-      FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s, ws_slot));
-      FR_TRY(col2im_positions_add(DX, a.Cin, a.H, a.W, a.k, a.Wo, pos, P, in.gpooled.f(), s));
-      continue;
-    }
-    h.sp_count = -1; h.sp_pos = nullptr;
-    if (!m->head_packs_fresh) {   // dense fallback: bring the heads' input-gradient packs up to date
-      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all + m->n_pack_fwd, m->n_pack_heads,
-                                     m->pack_grid_heads, s));
-      m->head_packs_fresh = true;
-    }
-    // 1x1 conv: accGradParameters + updateGradInput
-    FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
-    FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));
-    double f1 = 2.0 * HEAD_OUT * c.Cin * (double)hw1;
-    FR_TRY(conv_igemm(h.delta.f(), HEAD_OUT, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, 1, 0, a.gx.f(),
-                      OUT_STORE, f1, s, ws_slot));
-    // PReLU backward of the head (+ bias gradient of the k x k conv)
-    FR_TRY(act_backward(a.gx.f(), a.x.f(), a.Cout, (long)a.Ho * a.Wo, w + a.a_off, nullptr, a.gx.f(),
-                        grad + a.b_off, grad + a.a_off, s));
-    FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
-    double f3 = 2.0 * a.Cout * a.Cin * a.k * a.k * (double)a.Ho * a.Wo;
-    FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
-                      in.gpooled.f(), OUT_ADD, f3, s, ws_slot));  // nngraph fan-out: gradients add up
+// One anchor net's part of pnet:backward: gradients of its parameters, input gradient added into the pooled map's gradient
+// buffer (nngraph fan-out; atomic adds -- several anchor nets feed the same map).  Runs on stream s with split-K workspace
+// slot ws_slot.  *dense is set when the dense fallback was taken (no usable sparse hint).
+static bool head_is_sparse(const Head& h) { return h.sp_count >= 0 && h.sp_count <= SPARSE_MAX_POS; }
+
+static int backward_head(frcnn_model* m, Head& h, const float* w, float* grad, hipStream_t s, int ws_slot) {
+  Block& in = m->blocks[h.input];
+  Conv &a = h.c3, &c = h.c1;
+  const long hw1 = (long)c.Ho * c.Wo;
+  if (head_is_sparse(h)) {
+    // ---- sparse path: the same arithmetic restricted to the P positions where delta is non-zero
+    const int P = h.sp_count;
+    const int* pos = h.sp_pos;
+    h.sp_count = -1; h.sp_pos = nullptr;   // one-shot hint
+    if (P == 0) return FRCNN_OK;           // no example on this head: every gradient term is zero
+    const int n = a.Cout, ckk = a.Cin * a.k * a.k;
+    FR_TRY(h.spD.ensure((size_t)HEAD_OUT * SPARSE_MAX_POS * 4));
+    FR_TRY(h.spHX.ensure((size_t)n * SPARSE_MAX_POS * 4));
+    FR_TRY(h.spHY.ensure((size_t)n * SPARSE_MAX_POS * 4));
+    FR_TRY(h.spGH.ensure((size_t)n * SPARSE_MAX_POS * 4));
+    FR_TRY(h.spCol.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
+    FR_TRY(h.spDX.ensure((size_t)ckk * SPARSE_MAX_POS * 4));
+    float *D = h.spD.f(), *HX = h.spHX.f(), *HY = h.spHY.f(), *GH = h.spGH.f(), *COL = h.spCol.f(), *DX = h.spDX.f();
+    FR_TRY(gather_positions(h.delta.f(), HEAD_OUT, hw1, pos, P, D, nullptr, nullptr, s));
+    FR_TRY(gather_positions(a.x.f(), n, hw1, pos, P, HX, w + a.a_off, HY, s));
+    // the input-gradient path first (the backbone's backward pass waits for it), the parameter gradients after it:
+    // GH[n][P] = W1^T[n][18] * D[18][P], then PReLU backward (+ bias / slope gradients of the k x k conv)
+    FR_TRY(gemm_f32(w + c.w_off, 1, n, D, P, 1, GH, P, n, P, HEAD_OUT, OUT_STORE, nullptr, s, ws_slot));
+    FR_TRY(act_backward(GH, HX, n, P, w + a.a_off, nullptr, GH, grad + a.b_off, grad + a.a_off, s));
+    // DX[P][ckk] = GH^T[P][n] * W[n][ckk], scattered back into the pooled-map gradient
+    FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s, ws_slot));
+    FR_TRY(col2im_positions_add(DX, a.Cin, a.H, a.W, a.k, a.Wo, pos, P, in.gpooled.f(), s));
+    // 1x1 conv: gW1[18][n] += D[18][P] * HY[n][P]^T ; gb1 += rowsum(D)
+    FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s, ws_slot));
+    FR_TRY(channel_sum(D, HEAD_OUT, P, grad + c.b_off, s));
+    // k x k conv: gW[n][ckk] += GH[n][P] * COL[P][ckk]
+    FR_TRY(im2col_positions(in.pooled.f(), a.Cin, a.H, a.W, a.k, a.Wo, pos, P, COL, s));
+    FR_TRY(gemm_f32(GH, P, 1, COL, ckk, 1, grad + a.w_off, ckk, n, ckk, P, OUT_ADD, nullptr, s, ws_slot));
+    return FRCNN_OK;
   }
+  h.sp_count = -1; h.sp_pos = nullptr;
+  if (!m->head_packs_fresh) {   // dense fallback: bring the heads' input-gradient packs up to date
+    FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all + m->n_pack_fwd, m->n_pack_heads,
+                                   m->pack_grid_heads, s));
+    m->head_packs_fresh = true;
+  }
+  // 1x1 conv: accGradParameters + updateGradInput
+  FR_TRY(conv_wgrad(a.x.f(), c.Cin, c.H, c.W, w + a.a_off, nullptr, h.delta.f(), HEAD_OUT, 1, 0, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
+  FR_TRY(channel_sum(h.delta.f(), HEAD_OUT, hw1, grad + c.b_off, s));
+  double f1 = 2.0 * HEAD_OUT * c.Cin * (double)hw1;
+  FR_TRY(conv_igemm(h.delta.f(), HEAD_OUT, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, 1, 0, a.gx.f(),
+                    OUT_STORE, f1, s, ws_slot));
+  // PReLU backward of the head (+ bias gradient of the k x k conv)
+  FR_TRY(act_backward(a.gx.f(), a.x.f(), a.Cout, (long)a.Ho * a.Wo, w + a.a_off, nullptr, a.gx.f(),
+                      grad + a.b_off, grad + a.a_off, s));
+  FR_TRY(conv_wgrad(in.pooled.f(), a.Cin, a.H, a.W, nullptr, nullptr, a.gx.f(), a.Cout, a.k, 0, grad + a.w_off, m->wg_ws.p, m->wg_ws.bytes, s));
+  double f3 = 2.0 * a.Cout * a.Cin * a.k * a.k * (double)a.Ho * a.Wo;
+  FR_TRY(conv_igemm(a.gx.f(), a.Cout, a.Ho, a.Wo, nullptr, nullptr, a.wd.f(), nullptr, a.Cin, a.k, a.k - 1,
+                    in.gpooled.f(), OUT_ADD, f3, s, ws_slot));  // nngraph fan-out: gradients add up
+  return FRCNN_OK;
+}
+
+// every anchor net on ONE stream, one after the other (serial mode, and the fallback of frcnn_pnet_backward)
+static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream_t s, int ws_slot) {
+  for (auto& h : m->heads) FR_TRY(backward_head(m, h, w, grad, s, ws_slot));
+  return FRCNN_OK;
+}
+
+// The anchor nets' backward pass off the caller's stream: the side stream holds whatever must precede it (its last
+// event = chain_ev); every anchor net with a sparse hint then runs on its own stream beside the others, the dense
+// fallback (shared weight-gradient workspace) stays on the side stream.
+static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
+  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
+  FR_HIP(hipEventRecord(m->chain_ev, m->side));
+  std::vector<char> own(m->heads.size(), 0);   // (the hint is consumed by backward_head: decide before calling it)
+  for (size_t i = 0; i < m->heads.size(); ++i) own[i] = m->heads[i].stream && head_is_sparse(m->heads[i]);
+  for (size_t i = 0; i < m->heads.size(); ++i) {
+    Head& h = m->heads[i];
+    if (!own[i]) continue;
+    FR_HIP(hipStreamWaitEvent(h.stream, m->chain_ev, 0));
+    FR_TRY(backward_head(m, h, w, grad, h.stream, head_slot(m, i)));
+  }
+  for (size_t i = 0; i < m->heads.size(); ++i)
+    if (!own[i]) FR_TRY(backward_head(m, m->heads[i], w, grad, m->side, 1));
   return FRCNN_OK;
 }
 
@@ -647,8 +725,8 @@ int frcnn_pnet_backward_heads_begin(frcnn_model* m, const float* w, float* grad,
   FR_CHECK(m->H > 0 && m->training, "pnet_backward_heads_begin: needs a preceding training-mode forward");
   if (!side_enabled() || m->heads_begun) return FRCNN_OK;   // frcnn_pnet_backward does everything
   FR_TRY(fork_side(m, s, m->blocks.size() + 1));             // delta_outputs[1..nheads] are final on s
-  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
-  FR_TRY(backward_heads(m, w, grad, m->side, 1));
+  FR_TRY(join_heads(m, m->side));                            // (anchor nets of an asynchronous forward still in flight)
+  FR_TRY(backward_heads_fanout(m, w, grad));
   m->heads_begun = true;
   return FRCNN_OK;
 }
@@ -675,12 +753,12 @@ int frcnn_pnet_anchor_loss_begin(frcnn_model* m, const float* w, float* grad, co
     return FRCNN_OK;
   }
   FR_TRY(fork_side(m, s, m->blocks.size() + 1));   // example tables and zeroed delta buffers are final on s
+  FR_TRY(join_heads(m, m->side));                  // the anchor nets' outputs (each on its own stream) are final
   FR_TRY(rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, m->side));
   FR_TRY(loss_accumulate(ex_loss, E, acc, m->side));
   FR_HIP(hipEventRecord(m->loss_ev, m->side));
   m->loss_pending = true;
-  FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
-  FR_TRY(backward_heads(m, w, grad, m->side, 1));
+  FR_TRY(backward_heads_fanout(m, w, grad));
   m->heads_begun = true;
   return FRCNN_OK;
 }
@@ -698,6 +776,7 @@ int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
   if (joined) *joined = 0;
   if (!m->heads_begun) return FRCNN_OK;   // nothing was started: frcnn_pnet_backward computes the anchor nets' part
   if (!m->heads_joined) {
+    FR_TRY(join_heads(m, s));
     FR_HIP(hipEventRecord(m->join_ev, m->side));
     FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
     m->heads_joined = true;   // frcnn_pnet_backward will not wait again
@@ -720,6 +799,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   const int nb = (int)m->blocks.size();
   if (m->heads_begun) {   // started by frcnn_pnet_backward_heads_begin: wait for the side stream
     if (!m->heads_joined) {
+      FR_TRY(join_heads(m, s));
       FR_HIP(hipEventRecord(m->join_ev, m->side));
       FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
     }

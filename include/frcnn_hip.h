@@ -50,6 +50,13 @@ int frcnn_get_option(const char *name, int *value_host);
 /* ---- device buffers (torch.CudaTensor storage; main.lua:86-89, objective.lua:66,147-149) */
 int frcnn_malloc(void **ptr_out_host, size_t bytes);
 int frcnn_free(void *ptr);
+/* Page-locked host memory: a frcnn_memcpy_h2d / _d2h whose host side lives in such a buffer is truly asynchronous (the call
+ * returns at once and the copy runs in stream order).  From ordinary (pageable) host memory the same call only returns when
+ * the stream has reached the copy -- the host loses whatever lead it had over the device (in the training step: the example
+ * tables of objective.lua:91-140 are uploaded mid-step, and a blocking upload made the device wait ~0.45 ms per step for
+ * the launches that follow it).  The caller keeps the buffer untouched until the copy has run (an event or a later sync). */
+int frcnn_host_alloc(void **ptr_out_host, size_t bytes);
+int frcnn_host_free(void *ptr_host);
 int frcnn_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
 int frcnn_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
 int frcnn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);

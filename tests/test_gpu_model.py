@@ -262,7 +262,7 @@ def test_detect(F, O, setup):
     import torch
     model = s["model"]
     nat = model["native"]
-    w = _amplified_weights(nat, s["w"], 17)
+    w = _amplified_weights(nat, s["w"], 17, cls_gain=200.0)
     s["weights"].copy_(torch.from_numpy(w))
     try:
         r = check_detect(F, O, model, s["om"], w, range(5, 10), H, W)
