@@ -122,7 +122,7 @@ function Detector:detect(input)                                         -- Detec
     check(C.frcnn_memcpy_d2h(h_conf, dconf, 4 * R, nil))
     check(C.frcnn_stream_sync(nil))
 
-    local yclass = {}
+    local kept = {}
     for i, x in ipairs(candidates) do                                   -- :106-122
       local t = torch.FloatTensor(4)
       for k = 1, 4 do t[k] = h_bbox[4 * (i - 1) + k - 1] end
@@ -130,24 +130,50 @@ function Detector:detect(input)                                         -- Detec
       x.class = h_cls[i - 1]
       x.confidence = h_conf[i - 1]
       if x.class ~= bgclass and math.exp(x.confidence) > 0.2 then       -- :115
-        if not yclass[x.class] then yclass[x.class] = {} end
-        table.insert(yclass[x.class], x)
+        table.insert(kept, x)
       end
     end
 
-    -- per-class NMS (:125-136); classes in ascending order (the reference iterates with pairs(): unspecified)
-    local classes = {}
-    for c in pairs(yclass) do classes[#classes + 1] = c end
-    table.sort(classes)
-    for _, ci in ipairs(classes) do
-      local c = yclass[ci]
-      local bb = torch.FloatTensor(#c, 5)
-      for j, r in ipairs(c) do
-        bb[{j, {1, 4}}] = r.r2:totensor()
-        bb[{j, 5}] = r.confidence
+    -- per-class NMS (:125-136), every class in ONE device pass (frcnn_nms_device_classes): rows only suppress rows of
+    -- their own class; a stable partition of the picks by class is, per class, exactly nms(bb, 0.1, bb[{{}, 5}]) -- the
+    -- score tensor is ignored by nms.lua:42, the key is max-y.  One launch sequence and one read-back instead of one per
+    -- class (up to 200 with config/imagenet.lua).
+    local K = #kept
+    if K > 0 then
+      local bb = ffi.new('float[?]', 5 * K)
+      local kc = ffi.new('int[?]', K)
+      for j, r in ipairs(kept) do
+        local tt = r.r2:totensor()
+        for k = 1, 4 do bb[5 * (j - 1) + k - 1] = tt[k] end
+        bb[5 * (j - 1) + 4] = r.confidence
+        kc[j - 1] = r.class
       end
-      local pick = nms(bb, 0.1, bb[{{}, 5}])                            -- tensor scores -> ignored, key = max-y
-      pick:apply(function(q) table.insert(winners, c[q]) end)
+      local dbb = ffi.cast('float*', scratch('bb5', 20 * K).ptr)
+      local dkc = ffi.cast('int*', scratch('bbcls', 4 * K).ptr)
+      check(C.frcnn_memcpy_h2d(dbb, bb, 20 * K, nil))
+      check(C.frcnn_memcpy_h2d(dkc, kc, 4 * K, nil))
+      local cwsb = tonumber(C.frcnn_nms_workspace_bytes(K))
+      local cws = scratch('nms_ws', cwsb)
+      local cpick = ffi.cast('long long*', scratch('pick', 8 * K).ptr)
+      check(C.frcnn_nms_device_classes(dbb, K, 5, 0.1, 0, 0, dkc, cpick, cnt, cws.ptr, cwsb, nil))
+      local h_cp = ffi.new('long long[?]', K)
+      check(C.frcnn_memcpy_d2h(count, cnt, 4, nil))
+      check(C.frcnn_memcpy_d2h(h_cp, cpick, 8 * K, nil))
+      check(C.frcnn_stream_sync(nil))
+      -- classes in ascending order (the reference iterates with pairs(): unspecified), pick order within a class
+      local byclass, classes = {}, {}
+      for q = 0, count[0] - 1 do
+        local x = kept[tonumber(h_cp[q])]
+        if not byclass[x.class] then
+          byclass[x.class] = {}
+          classes[#classes + 1] = x.class
+        end
+        table.insert(byclass[x.class], x)
+      end
+      table.sort(classes)
+      for _, ci in ipairs(classes) do
+        for _, x in ipairs(byclass[ci]) do table.insert(winners, x) end
+      end
     end
   end
 

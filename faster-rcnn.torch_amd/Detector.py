@@ -30,6 +30,7 @@ class Detector(object):
         self._ah = DeviceTensor.from_numpy(self.anchors.h)
         self._bufs = {}
         self.verbose = False
+        self.keep_cnet_outputs = True   # last_cnet["cls"]: the R x (classes+1) log-probabilities, read back for inspection
 
     def _buf(self, name, shape, dtype=np.float32):
         need = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
@@ -58,6 +59,23 @@ class Detector(object):
                     rect=DeviceTensor(mr.ptr, (n, 4), np.float64, owner=mr),
                     box=DeviceTensor(mb.ptr, (n, 4), np.float32, owner=mb))
 
+    def _nms_device(self, boxes, n, ncols, overlap, cls=None):
+        """nms(bb, overlap, scores) with the reference's key (max-y) on boxes resident in HBM, workspace and result buffers
+        owned by the detector (no allocation per frame).  cls: optional device int32[n] -- rows only suppress rows of the
+        same class (frcnn_nms_device_classes).  Returns the 1-based row ids in pick order (one read-back)."""
+        wsb = _lib.load().frcnn_nms_workspace_bytes(n)
+        ws = self._buf("nms_ws", (wsb,), np.uint8)
+        pick = self._buf("nms_pick", (n,), np.int64)
+        cnt = self._buf("nms_count", (1,), np.int32)
+        if cls is None:
+            _lib.call("frcnn_nms_device", ptr(boxes), n, ncols, C.c_float(overlap), 0, 0, ptr(pick), ptr(cnt), ptr(ws), wsb,
+                      stream_ptr())
+        else:
+            _lib.call("frcnn_nms_device_classes", ptr(boxes), n, ncols, C.c_float(overlap), 0, 0, ptr(cls), ptr(pick),
+                      ptr(cnt), ptr(ws), wsb, stream_ptr())
+        k = int(cnt.numpy()[0])
+        return pick.numpy()[:k].copy()
+
     def detect(self, input):  # Detector.lua:17-141
         model = self.model
         cfg = model["cfg"]
@@ -77,10 +95,10 @@ class Detector(object):
         winners = []
         if m["n"] == 0:  # :71
             return winners
-        # NON-MAXIMUM SUPPRESSION (:74-85); the score tensor is ignored by nms.lua -> key = max-y
-        pick = nms(m["box"], 0.25, m["p"])
+        # NON-MAXIMUM SUPPRESSION (:74-85) on the device; the score tensor is ignored by nms.lua -> key = max-y
+        pick = self._nms_device(m["box"], m["n"], 4, 0.25)
         rect_all = m["rect"].numpy(); p_all = m["p"].numpy(); idx_all = m["idx"].numpy()
-        cand = [int(i) - 1 for i in pick]
+        cand = pick - 1
         self.last_pick = pick
         if self.verbose:
             print("candidates: %d" % len(cand))
@@ -89,8 +107,7 @@ class Detector(object):
         fm = outputs[-1]
         fmC, fmH, fmW = fm.shape
         R = len(cand)
-        cand_a = np.asarray(cand, dtype=np.int64)
-        wins = roi_windows(rect_all[cand_a], self.localizer, fmH, fmW)   # all candidates at once (objective.lua:5-13)
+        wins = roi_windows(rect_all[cand], self.localizer, fmH, fmW)   # all candidates at once (objective.lua:5-13)
         dwins = self._buf("wins", wins.shape, np.int32)
         dwins.copy_from_numpy(wins)
         cinput = self._buf("cinput", (R, kh * kw * planes))
@@ -100,26 +117,44 @@ class Detector(object):
         dcls = self._buf("cls", (R,), np.int32); dconf = self._buf("conf", (R,))
         _lib.call("frcnn_cnet_decode", ptr(cls_out), R, ncls, ptr(dcls), ptr(dconf), s)  # :110-113
         bbox_h = bbox_out.numpy(); cls_h = dcls.numpy(); conf_h = dconf.numpy()
-        self.last_cnet = dict(bbox=bbox_h, cls=cls_out.numpy())
-        yclass = {}
+        self.last_cnet = dict(bbox=bbox_h, cls=cls_out.numpy() if self.keep_cnet_outputs else None)
         # the class test of :115 first (vectorised); the per-candidate tables are only built for survivors
         keep = np.nonzero((cls_h != bgclass) & (np.exp(conf_h.astype(np.float64)) > 0.2))[0]
-        for k in keep:  # :106-122
-            i = cand[k]
-            x = dict(p=float(p_all[i]), r=Rect(*rect_all[i]), l=int(idx_all[i][0]),
-                     a=self.anchors.get(*[int(v) for v in idx_all[i]]))
-            x["r2"] = Anchors.anchorToInput(x["r"], bbox_h[k])  # :107
-            x["class"] = int(cls_h[k]); x["confidence"] = float(conf_h[k])
-            if x["class"] != bgclass and math.exp(x["confidence"]) > 0.2:  # :115
-                yclass.setdefault(x["class"], []).append(x)
-        # per-class NMS (:125-136); classes in ascending order (pairs() order is unspecified in Lua)
-        for cidx in sorted(yclass.keys()):
-            c = yclass[cidx]
-            bb = np.zeros((len(c), 5), dtype=np.float32)
-            for j, r in enumerate(c):
-                bb[j, 0:4] = r["r2"].totensor()
-                bb[j, 4] = r["confidence"]
-            pk = nms(bb, 0.1, bb[:, 4])  # tensor scores -> ignored, key = max-y (nms.lua:42)
-            for v in pk:
-                winners.append(c[int(v) - 1])
+        if len(keep) == 0:
+            return winners
+        # :106-122 for every surviving candidate at once: r2 = Anchors.anchorToInput(r, bbox_out[i]) in double arithmetic
+        # (the products and sums as separately rounded operations, exp through libm like the Lua number path); the per-
+        # detection tables {p, a, r, l, r2, class, confidence} are only built for the winners of the per-class NMS
+        ci = cand[keep]
+        ra = rect_all[ci]
+        aw, ah = ra[:, 2] - ra[:, 0], ra[:, 3] - ra[:, 1]
+        t = bbox_h[keep].astype(np.float64)
+        x0 = t[:, 0] * aw + ra[:, 0]; y0 = t[:, 1] * ah + ra[:, 1]
+        ew = np.array([math.exp(v) for v in t[:, 2].tolist()], dtype=np.float64) * aw
+        eh = np.array([math.exp(v) for v in t[:, 3].tolist()], dtype=np.float64) * ah
+        r2 = np.stack([x0, y0, x0 + ew, y0 + eh], 1)      # Rect.fromXYWidthHeight
+        # Per-class NMS (:125-136), all classes in ONE device pass: rows only suppress rows of their own class, and a stable
+        # partition of the picks by class is, per class, exactly nms(bb_class, 0.1, scores) -- the score tensor is ignored by
+        # nms.lua:42, the key is max-y.  With class_count = 200 (config/imagenet.lua) that is one launch sequence and one
+        # read-back instead of up to 200.
+        K = len(keep)
+        bb = np.empty((K, 5), dtype=np.float32)
+        bb[:, 0:4] = r2          # r.r2:totensor() (FloatTensor)
+        bb[:, 4] = conf_h[keep]
+        kc = cls_h[keep].astype(np.int32)
+        blob = np.concatenate([bb.view(np.uint8).ravel(), kc.view(np.uint8).ravel()])
+        dblob = self._buf("bbblob", (blob.size,), np.uint8)
+        dblob.copy_from_numpy(blob)
+        dbb = DeviceTensor(dblob.ptr, (K, 5), np.float32, owner=dblob)
+        dkc = DeviceTensor(dblob.ptr + bb.nbytes, (K,), np.int32, owner=dblob)
+        pk = self._nms_device(dbb, K, 5, 0.1, cls=dkc)
+        # classes in ascending order (pairs() order is unspecified in Lua), pick order within a class
+        order = sorted(range(len(pk)), key=lambda q: kc[int(pk[q]) - 1])   # sorted() is stable
+        for q in order:
+            j = int(pk[q]) - 1
+            k = int(keep[j]); i = int(ci[j])
+            winners.append(dict(p=float(p_all[i]), r=Rect(*rect_all[i]), l=int(idx_all[i][0]),
+                                a=self.anchors.get(*[int(v) for v in idx_all[i]]), r2=Rect(*r2[j]),
+                                confidence=float(conf_h[k]), candidate=k + 1,   # (1-based row among the NMS candidates)
+                                **{"class": int(cls_h[k])}))
         return winners

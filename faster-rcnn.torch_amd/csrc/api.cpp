@@ -150,6 +150,10 @@ int frcnn_nms_device(const float* boxes, int n, int ncols, float overlap, int ke
                      long long* pick, int* count, void* ws, size_t ws_bytes, void* stream) {
   return nms_device(boxes, n, ncols, overlap, key_mode, key_col, pick, count, ws, ws_bytes, S(stream));
 }
+int frcnn_nms_device_classes(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col, const int* cls,
+                             long long* pick, int* count, void* ws, size_t ws_bytes, void* stream) {
+  return nms_device(boxes, n, ncols, overlap, key_mode, key_col, pick, count, ws, ws_bytes, S(stream), cls);
+}
 int frcnn_nms_host(const float* boxes_host, int n, int ncols, float overlap, int key_mode, int key_col,
                    long long* pick_host, int* count_host) {
   if (n <= 0) { *count_host = 0; return FRCNN_OK; }

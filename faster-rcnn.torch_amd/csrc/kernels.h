@@ -102,8 +102,9 @@ int loss_accumulate(const double* ex_loss, int E, double* acc, hipStream_t s);
 
 // ---------------------------------------------------------------- nms (nms.hip)
 size_t nms_workspace_bytes(int n);
+// cls (optional, int[n]): rows only suppress rows of the same class (Detector.lua:125-136 in one pass)
 int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
-               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s);
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls = nullptr);
 
 // ---------------------------------------------------------------- cnet small ops (cnet.hip)
 int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,

@@ -60,18 +60,21 @@ __global__ void nms_scatter_kernel(const int* __restrict__ rank, int n, int* __r
 }
 
 // mask[a][w] bit b: box at sorted position a suppresses box at sorted position w*64+b (b > a)
+// cls (optional): rows only suppress rows of the same class -- the per-class NMS problems of Detector.lua:125-136 in one pass
 __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, const float* __restrict__ area,
-                                const int* __restrict__ sorted, int n, int nw, float thr,
+                                const int* __restrict__ sorted, int n, int nw, float thr, const int* __restrict__ cls,
                                 unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;
   __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], car[64];
+  __shared__ int ccl[64];
   const int t = threadIdx.x;  // 64 threads = one wave
   const int cpos = cb * 64 + t;
   if (cpos < n) {
     int j = sorted[cpos];
     const float* b = boxes + (size_t)j * ncols;
     cx1[t] = b[0]; cy1[t] = b[1]; cx2[t] = b[2]; cy2[t] = b[3]; car[t] = area[j];
+    ccl[t] = cls ? cls[j] : 0;
   }
   __syncthreads();
   const int rpos = rb * 64 + t;
@@ -79,6 +82,7 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
   const int i = sorted[rpos];
   const float* bi = boxes + (size_t)i * ncols;
   const float ix1 = bi[0], iy1 = bi[1], ix2 = bi[2], iy2 = bi[3], iar = area[i];
+  const int icl = cls ? cls[i] : 0;
   unsigned long long bits = 0ull;
   const int lim = min(64, n - cb * 64);
   for (int c = 0; c < lim; ++c) {
@@ -97,7 +101,7 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
     float denom = car[c] + iar;
     denom = denom - inter;
     float iou = inter / denom;
-    if (!(iou <= thr)) bits |= 1ull << c;
+    if (!(iou <= thr) && ccl[c] == icl) bits |= 1ull << c;
   }
   mask[(size_t)rpos * nw + cb] = bits;
 }
@@ -175,7 +179,7 @@ size_t nms_workspace_bytes(int n) {
 }
 
 int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
-               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s) {
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls) {
   if (n <= 0) {  // nms.lua:26-28
     FR_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     return FRCNN_OK;
@@ -201,7 +205,7 @@ int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode
   FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256), cdiv(n, NMS_RANK_SLICE)), dim3(256), 0, key, n, rank);
   FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (const int*)rank, n, sorted);
   FR_LAUNCH(KC_NMS, 3.5 * n * (double)n, 8.0 * n * nw / 2, s, nms_mask_kernel, dim3(nw, nw), dim3(64), 0,
-            boxes, ncols, area, sorted, n, nw, overlap, mask);
+            boxes, ncols, area, sorted, n, nw, overlap, cls, mask);
   FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(NMS_RED_THREADS), (size_t)nw * 8, mask,
             sorted, n, nw, pick, count);
   FR_LAUNCH_CHECK();

@@ -95,6 +95,13 @@ size_t frcnn_nms_workspace_bytes(int n);
 int frcnn_nms_device(const float *boxes, int n, int ncols, float overlap, int key_mode,
                      int key_col, long long *pick, int *count, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* The per-class loop of Detector.lua:125-136 (`for i,c in pairs(yclass) do ... nms(bb, 0.1, ...)`) in ONE call: row i only
+ * suppresses rows of the same class cls[i] (device int[n]; any integers).  Picks come in global pick order (descending key),
+ * i.e. the per-class pick lists interleaved: a stable partition of the picks by class gives, per class, exactly the result
+ * of nms() on that class's rows (same relative order, same fp32 arithmetic).  cls == NULL: frcnn_nms_device. */
+int frcnn_nms_device_classes(const float *boxes, int n, int ncols, float overlap, int key_mode, int key_col,
+                             const int *cls, long long *pick, int *count, void *workspace,
+                             size_t workspace_bytes, void *stream);
 /* Host-pointer variant (the reference's nms runs on CPU FloatTensors): uploads, runs the same
  * kernels, downloads, synchronises. */
 int frcnn_nms_host(const float *boxes_host, int n, int ncols, float overlap, int key_mode,

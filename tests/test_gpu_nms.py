@@ -80,3 +80,29 @@ def test_nms_golden_fixture(F):
         key = c["key"]
         scores = None if key == "y2" else ("area" if key == "area" else int(key))
         assert F.nms(b, c["overlap"], scores).tolist() == c["pick"], c["name"]
+
+
+@pytest.mark.parametrize("n,nclass", [(7, 3), (500, 16), (3000, 200), (4000, 1)])
+def test_class_aware_nms_equals_one_nms_per_class(F, O, n, nclass):
+    """frcnn_nms_device_classes: the per-class loop of Detector.lua:125-136 in one pass.  A stable partition of its picks
+    by class must be, per class, exactly nms() on that class's rows (5 columns: box + confidence, key = max-y)."""
+    rng = np.random.RandomState(n + nclass)
+    b = np.concatenate([random_boxes(rng, n), rng.rand(n, 1).astype(np.float32)], 1)
+    cls = rng.randint(1, nclass + 1, n).astype(np.int32)
+    db, dc = F.DeviceTensor.from_numpy(b), F.DeviceTensor.from_numpy(cls)
+    wsb = F._lib.load().frcnn_nms_workspace_bytes(n)
+    ws = F.DeviceTensor.empty((wsb,), np.uint8); pick = F.DeviceTensor.empty((n,), np.int64); cnt = F.DeviceTensor.empty((1,), np.int32)
+    import ctypes as C
+    F._lib.call("frcnn_nms_device_classes", F.ptr(db), n, 5, C.c_float(0.1), 0, 0, F.ptr(dc), F.ptr(pick), F.ptr(cnt),
+                F.ptr(ws), wsb, F.stream_ptr())
+    got = pick.numpy()[:int(cnt.numpy()[0])]
+    total = 0
+    for c in range(1, nclass + 1):
+        rows = np.nonzero(cls == c)[0]
+        want = rows[O.nms(b[rows], 0.1) - 1] + 1 if len(rows) else np.zeros(0, np.int64)
+        mine = np.array([g for g in got if cls[g - 1] == c], dtype=np.int64)
+        assert mine.tolist() == want.tolist(), "class %d" % c
+        total += len(want)
+    assert total == len(got)
+    if nclass == 1:   # one class: the plain NMS
+        assert got.tolist() == O.nms(b, 0.1).tolist()
