@@ -10,6 +10,8 @@ from . import comm
 from .comm import Comm
 from .config import duplo_cfg, imgnet_cfg
 from .Detector import Detector
+from . import evaluation
+from .evaluation import evaluate_detections, mean_average_precision, validation_losses
 from .Localizer import Localizer
 from .model_utilities import create_model
 from .nms import nms
@@ -23,6 +25,6 @@ from .utilities import combine_and_flatten_parameters, rmsprop
 from .vgg_large import vgg_large
 from .vgg_small import vgg_small
 
-__all__ = ["Comm", "comm", "decode_image", "traindata", "t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
+__all__ = ["Comm", "comm", "evaluation", "evaluate_detections", "mean_average_precision", "validation_losses", "decode_image", "traindata", "t7", "load_obj", "restore_weights", "save_model", "save_obj", "BatchIterator", "find_target_size", "gaussian1D", "allreduce_begin", "allreduce_begin_rest", "Anchors", "Detector", "DeviceTensor", "FrcnnError", "Localizer", "MT19937", "Rect", "combine_and_flatten_parameters",
            "create_model", "create_objective", "duplo_cfg", "extract_roi_pooling_input", "imgnet_cfg", "manualSeed", "nms",
            "rmsprop", "roi_window", "roi_windows", "vgg_large", "vgg_small"]

@@ -138,3 +138,12 @@ for fn in data["validation_set"]:
 print("held-out frames %d: ground-truth boxes %d, detections %d, correct (class + IoU >= 0.5) %d -> recall %.2f precision %.2f, mean IoU of the hits %.2f" % (
     len(data["validation_set"]), ngt, tp + fp, tp, tp / max(ngt, 1), tp / max(tp + fp, 1), float(np.mean(ious)) if ious else 0.0))
 print("anchors passing p > 0.95: %d, candidates after NMS: %d, cnet class histogram of the candidates (1..3 objects, 4 background): %s" % (nscan, ncand, predhist[1:5].tolist()))
+
+# the evaluation loop proper (frcnn_amd/evaluation.py): validation losses and VOC-style mAP over nextValidation
+nval = len(data["validation_set"])
+vl = F.validation_losses(model, it, nval)
+print("validation losses over %d held-out frames (evaluate mode): pcls %.4f preg %.4f dcls %.4f dreg %.4f (%d examples, %d positive)" % (
+    vl["images"], vl["pcls"], vl["preg"], vl["dcls"], vl["dreg"], vl["examples"], vl["positives"]))
+ev = F.evaluate_detections(det, it, nval)
+print("mAP@0.5 over %d frames: %.3f (per class %s; %d detections, %d ground-truth boxes, tp %d fp %d)" % (
+    ev["images"], ev["mAP"], dict((k, round(v, 3)) for k, v in ev["ap"].items()), ev["detections"], ev["ground_truth"], ev["tp"], ev["fp"]))
