@@ -150,7 +150,7 @@ int prelu_dropout_forward_gen(const float* x, long n, const float* slope, float*
 
 __global__ void prelu_dropout_backward_kernel(const float* __restrict__ gy, const float* __restrict__ x, long n,
                                               const float* slope, const float* __restrict__ mask,
-                                              float inv_keep, float* __restrict__ gx, float* gslope) {
+                                              float inv_keep, float* __restrict__ gx, float* gslope, float* part) {
   __shared__ float sh[4];
   const float a = *slope;
   float sa = 0.f;
@@ -166,13 +166,25 @@ __global__ void prelu_dropout_backward_kernel(const float* __restrict__ gy, cons
   for (int o = 32; o > 0; o >>= 1) sa += __shfl_down(sa, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sa;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(gslope, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    const float t = sh[0] + sh[1] + sh[2] + sh[3];
+    if (part) part[blockIdx.x] = t;   // deterministic mode: folded in block order by slope_fold_kernel
+    else unsafeAtomicAdd(gslope, t);
+  }
+}
+__global__ void slope_fold_kernel(const float* __restrict__ part, int n, float* gslope) {
+  float v = 0.f;
+  for (int i = 0; i < n; ++i) v += part[i];
+  *gslope += v;
 }
 int prelu_dropout_backward(const float* gy, const float* x, long n, const float* slope,
                            const float* mask, float inv_keep, float* gx, float* gslope, hipStream_t s) {
   int grid = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 256);
+  float* part = nullptr;
+  if (deterministic()) FR_TRY(det_workspace(s, (size_t)grid, &part));
   FR_LAUNCH(KC_ELEMWISE, 0, n * 16.0, s, prelu_dropout_backward_kernel, dim3(grid), dim3(256), 0, gy, x, n,
-            slope, mask, inv_keep, gx, gslope);
+            slope, mask, inv_keep, gx, gslope, part);
+  if (part) FR_LAUNCH(KC_ELEMWISE, 0, grid * 4.0, s, slope_fold_kernel, dim3(1), dim3(1), 0, (const float*)part, grid, gslope);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -6,6 +6,9 @@
 // 16-byte accesses where the layout allows and one wave-level reduction + one atomic per block.
 #include <algorithm>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "kernels.h"
 
 namespace frcnn {
@@ -158,7 +161,7 @@ template <bool POOLED, bool VEC>
 __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
                                     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
                                     const float* slope, const float* scale, float* __restrict__ gx,
-                                    float* gbias, float* gslope, int chunks) {
+                                    float* gbias, float* gslope, int chunks, float* part_b, float* part_a) {
   __shared__ float sh[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long hw = (long)H * W;
@@ -241,11 +244,60 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
     }
   }
   float tb = block_sum(sb, sh);
+  if (part_b) {   // deterministic mode: partials to scratch, folded in index order by fold_partials_kernel
+    if (threadIdx.x == 0) part_b[blockIdx.x] = tb;
+    float ta = (slope && gslope) ? block_sum(sa, sh) : 0.f;
+    if (threadIdx.x == 0) part_a[blockIdx.x] = ta;
+    return;
+  }
   if (threadIdx.x == 0 && gbias) unsafeAtomicAdd(gbias + c, tb);
   if (slope && gslope) {
     float ta = block_sum(sa, sh);
     if (threadIdx.x == 0) unsafeAtomicAdd(gslope, ta);
   }
+}
+
+// gbias[c] += sum_chunk part_b[c*chunks + chunk] (index order); *gslope += sum_b part_a[b] (fixed strided order + fixed tree)
+__global__ void fold_partials_kernel(const float* __restrict__ part_b, const float* __restrict__ part_a, int C, int chunks,
+                                     float* gbias, float* gslope) {
+  __shared__ float sh[16];
+  if (gbias && part_b)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float v = 0.f;
+      for (int k = 0; k < chunks; ++k) v += part_b[(size_t)c * chunks + k];
+      gbias[c] += v;
+    }
+  if (gslope && part_a) {
+    float v = 0.f;
+    for (int b = threadIdx.x; b < C * chunks; b += blockDim.x) v += part_a[b];
+    const float t = block_sum(v, sh);
+    if (threadIdx.x == 0) *gslope += t;
+  }
+}
+static int fold_partials(const float* part_b, const float* part_a, int C, int chunks, float* gbias, float* gslope, hipStream_t s) {
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)C * chunks * 8.0, s, fold_partials_kernel, dim3(1), dim3(256), 0, part_b, part_a, C, chunks,
+            gbias, gslope);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+static bool g_deterministic = getenv("FRCNN_DETERMINISTIC") && atoi(getenv("FRCNN_DETERMINISTIC")) != 0;   // default of the option
+bool deterministic() { return g_deterministic; }
+void set_deterministic(bool on) { g_deterministic = on; }
+static std::mutex g_det_mu;
+static std::unordered_map<hipStream_t, std::pair<float*, size_t>> g_det_ws;
+int det_workspace(hipStream_t s, size_t floats, float** out) {
+  std::lock_guard<std::mutex> lk(g_det_mu);
+  auto& e = g_det_ws[s];
+  if (e.second < floats) {
+    if (e.first) FR_HIP(hipFree(e.first));
+    e.first = nullptr; e.second = 0;
+    size_t n = std::max<size_t>(floats, 1 << 16);
+    FR_HIP(hipMalloc((void**)&e.first, n * 4));
+    e.second = n;
+  }
+  *out = e.first;
+  return FRCNN_OK;
 }
 
 // Blocks of 1024 threads, ~512-768 of them: every block ends with ONE atomic on the single slope-gradient
@@ -262,35 +314,41 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                          float* gslope, hipStream_t s) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
   int chunks = act_bwd_chunks(C, (long)H * W);
+  float *pb = nullptr, *pa = nullptr;
+  if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (W % 4 == 0) && (Wo % 2 == 0) && (((uintptr_t)gpool | (uintptr_t)x | (uintptr_t)gx) % 16 == 0) &&
                    ((uintptr_t)idx % 2 == 0);
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, true>), dim3(C * chunks),
-              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, false>), dim3(C * chunks),
-              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa);
   FR_LAUNCH_CHECK();
+  if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
   return FRCNN_OK;
 }
 
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
                  const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s) {
   int chunks = act_bwd_chunks(C, hw);
+  float *pb = nullptr, *pa = nullptr;
+  if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (hw % 4 == 0) && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) % 16 == 0);
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, true>), dim3(C * chunks),
               dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
-              gbias, gslope, chunks);
+              gbias, gslope, chunks, pb, pa);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, false>), dim3(C * chunks),
               dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
-              gbias, gslope, chunks);
+              gbias, gslope, chunks, pb, pa);
   FR_LAUNCH_CHECK();
+  if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
   return FRCNN_OK;
 }
 
-__global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks) {
+__global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks, float* part_b) {
   __shared__ float sh[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long per = cdivl(hw, chunks);
@@ -298,13 +356,17 @@ __global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* 
   float sb = 0.f;
   for (long i = beg + threadIdx.x; i < end; i += blockDim.x) sb += g[(size_t)c * hw + i];
   float tb = block_sum(sb, sh);
+  if (part_b) { if (threadIdx.x == 0) part_b[blockIdx.x] = tb; return; }
   if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, tb);
 }
 int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s) {
   int chunks = act_bwd_chunks(C, hw);
+  float* pb = nullptr;
+  if (deterministic()) FR_TRY(det_workspace(s, (size_t)C * chunks, &pb));
   FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 4.0, s, channel_sum_kernel, dim3(C * chunks), dim3(256), 0, g,
-            hw, gbias, chunks);
+            hw, gbias, chunks, pb);
   FR_LAUNCH_CHECK();
+  if (pb) FR_TRY(fold_partials(pb, nullptr, C, chunks, gbias, nullptr, s));
   return FRCNN_OK;
 }
 
@@ -388,8 +450,32 @@ __global__ void col2im_positions_add_kernel(const float* __restrict__ col, int C
     unsafeAtomicAdd(gX + ((size_t)c * H + y + ky) * W + x + kx, col[t]);
   }
 }
+// deterministic variant: one thread per element of gX gathers, in position order, every patch entry that lands on it
+__global__ void col2im_positions_gather_kernel(const float* __restrict__ col, int C, int H, int W, int k, int Wo,
+                                               const int* __restrict__ pos, int P, float* __restrict__ gX) {
+  const int ckk = C * k * k;
+  const long total = (long)C * H * W;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(t % W), yy = (int)((t / W) % H), c = (int)(t / ((long)W * H));
+    float v = 0.f;
+    bool any = false;
+    for (int pi = 0; pi < P; ++pi) {
+      const int y = pos[pi] / Wo, x = pos[pi] - y * Wo;
+      const int ky = yy - y, kx = xx - x;
+      if (ky >= 0 && ky < k && kx >= 0 && kx < k) { v += col[(size_t)pi * ckk + (c * k + ky) * k + kx]; any = true; }
+    }
+    if (any) gX[t] += v;
+  }
+}
 int col2im_positions_add(const float* col, int C, int H, int W, int k, int Wo, const int* pos, int P, float* gX,
                          hipStream_t s) {
+  if (deterministic()) {
+    long n = (long)C * H * W;
+    int g = (int)std::min<long>(std::max<long>(1, cdivl(n, 256)), 8192);
+    FR_LAUNCH(KC_ELEMWISE, 0, n * 8.0, s, col2im_positions_gather_kernel, dim3(g), dim3(256), 0, col, C, H, W, k, Wo, pos, P, gX);
+    FR_LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   long total = (long)P * C * k * k;
   int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 4096);
   FR_LAUNCH(KC_ELEMWISE, 0, total * 8.0, s, col2im_positions_add_kernel, dim3(grid), dim3(256), 0, col, C, H, W, k, Wo, pos,

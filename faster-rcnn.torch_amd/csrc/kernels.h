@@ -40,6 +40,17 @@ size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s);
 
+// ---------------------------------------------------------------- deterministic mode (frcnn_set_option("deterministic", 1))
+// Default: per-block partial sums of the bias / slope gradients and the scatter-adds of the ROI-pooling and sparse anchor-net
+// backward passes meet in fp32 atomics, whose order -- hence the last bits of the result -- varies from run to run.
+// Deterministic: block partials go to a scratch array and are folded in index order, the anchor deltas are applied in example
+// order, the sparse col2im becomes a gather, and the ROI-pooling backward accumulates in 64-bit fixed point (exact, so the order
+// does not matter).  Two runs on the same inputs are then bit-identical.
+bool deterministic();
+void set_deterministic(bool on);
+// stream-ordered scratch of at least `floats` floats owned by the library (one buffer per stream, grown on demand)
+int det_workspace(hipStream_t s, size_t floats, float** out);
+
 // ---------------------------------------------------------------- elementwise (elem.hip)
 int fill_zero(void* p, size_t bytes, hipStream_t s);
 int scale_inplace(float* x, long n, float sc, hipStream_t s);

@@ -401,6 +401,7 @@ static bool side_enabled() {
 int frcnn_get_option(const char* name, int* value) {
   FR_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
+  if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
 }
@@ -408,6 +409,7 @@ int frcnn_get_option(const char* name, int* value) {
 int frcnn_set_option(const char* name, int value) {
   FR_CHECK(name != nullptr, "set_option: null name");
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
+  if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
   FR_CHECK(false, "set_option: unknown option '%s'", name);
   return FRCNN_OK;
 }

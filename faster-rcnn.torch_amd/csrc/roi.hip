@@ -77,6 +77,49 @@ __global__ void roi_pool_backward_lds_kernel(float* __restrict__ gmap, int C, in
   }
 }
 
+// Deterministic variants: the contributions are accumulated in 64-bit fixed point (value * 2^44, rounded to nearest): integer
+// addition is exact, so the sum does not depend on the order in which the atomics land.  |g| < 2^18, resolution 6e-14.
+#define ROI_FIX_SCALE 17592186044416.0   /* 2^44 */
+__device__ __forceinline__ long long roi_to_fix(float g) { return __double2ll_rn((double)g * ROI_FIX_SCALE); }
+__global__ void roi_pool_backward_lds_det_kernel(float* __restrict__ gmap, int C, int HW, const float* __restrict__ gout,
+                                                 const int* __restrict__ idx, int R, int cell) {
+  extern __shared__ unsigned long long fplane[];
+  const int c = blockIdx.x;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) fplane[i] = 0ull;
+  __syncthreads();
+  const long D = (long)C * cell;
+  const int total = R * cell;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e / cell, j = e - r * cell;
+    const long t = (long)r * D + (long)c * cell + j;
+    const int bi = idx[t];
+    const float g = gout[t];
+    if (bi >= 0 && g != 0.f) atomicAdd(&fplane[bi], (unsigned long long)roi_to_fix(g));
+  }
+  __syncthreads();
+  float* gp = gmap + (size_t)c * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const long long v = (long long)fplane[i];
+    if (v != 0) gp[i] += (float)((double)v / ROI_FIX_SCALE);
+  }
+}
+__global__ void roi_pool_backward_det_kernel(unsigned long long* __restrict__ fix, int C, long HW,
+                                             const float* __restrict__ gout, const int* __restrict__ idx,
+                                             long total, int cell) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int c = (int)((t / cell) % C);
+    int bi = idx[t];
+    float g = gout[t];
+    if (bi >= 0 && g != 0.f) atomicAdd(fix + (size_t)c * HW + bi, (unsigned long long)roi_to_fix(g));
+  }
+}
+__global__ void roi_fix_apply_kernel(const unsigned long long* __restrict__ fix, long n, float* __restrict__ gmap) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const long long v = (long long)fix[t];
+    if (v != 0) gmap[t] += (float)((double)v / ROI_FIX_SCALE);
+  }
+}
+
 // delta_outputs[5][idx]:add(amp:backward(...))  (objective.lua:182-185): windows of different
 // ROIs overlap, so this is a scatter-ADD; fp32 atomics in L2.
 __global__ void roi_pool_backward_kernel(float* __restrict__ gmap, int C, long HW,
@@ -94,6 +137,24 @@ int roi_pool_backward(float* gmap, int C, int H, int W, const float* gout, const
                       int kh, int kw, hipStream_t s) {
   if (R <= 0) return FRCNN_OK;
   long total = (long)R * C * kh * kw;
+  if (deterministic()) {
+    if ((size_t)H * W * 8 <= 64 * 1024) {
+      FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_lds_det_kernel, dim3(C), dim3(256), (size_t)H * W * 8, gmap, C,
+                H * W, gout, idx, R, kh * kw);
+    } else {
+      float* ws = nullptr;
+      const long n = (long)C * H * W;
+      FR_TRY(det_workspace(s, (size_t)n * 2, &ws));
+      FR_HIP(hipMemsetAsync(ws, 0, (size_t)n * 8, s));
+      int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+      FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_det_kernel, dim3(grid), dim3(256), 0, (unsigned long long*)ws, C,
+                (long)H * W, gout, idx, total, kh * kw);
+      FR_LAUNCH(KC_ROI, 0, n * 16.0, s, roi_fix_apply_kernel, dim3((int)std::min<long>(cdivl(n, 256), 4096)), dim3(256), 0,
+                (const unsigned long long*)ws, n, gmap);
+    }
+    FR_LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   if ((size_t)H * W * 4 <= 64 * 1024) {
     FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_lds_kernel, dim3(C), dim3(256), (size_t)H * W * 4, gmap, C,
               H * W, gout, idx, R, kh * kw);

@@ -156,10 +156,12 @@ struct LossArgs {
   int H[4], W[4];
 };
 
+// exg (deterministic mode): the six gradient values of example e go to exg[e][0..5] instead of being added to the delta maps;
+// rpn_apply_kernel then adds them in example order (two sampled examples may name the same anchor).
 __global__ void rpn_loss_kernel(LossArgs a, const int* __restrict__ ex_idx, const double* __restrict__ ex_anchor,
                                 const double* __restrict__ ex_roi, const int* __restrict__ ex_class,
                                 int npos, int nneg, int bgclass, double* __restrict__ ex_loss,
-                                float* __restrict__ crtarget, float* __restrict__ cctarget) {
+                                float* __restrict__ crtarget, float* __restrict__ cctarget, float* __restrict__ exg) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npos + nneg) return;
   const int* ix = ex_idx + 4 * e;
@@ -175,8 +177,14 @@ __global__ void rpn_loss_kernel(LossArgs a, const int* __restrict__ ex_idx, cons
   const double lse = mx + log(exp((double)v0 - mx) + exp((double)v1 - mx));
   const float l0 = (float)((double)v0 - lse), l1 = (float)((double)v1 - lse);
   const double cls = pos ? -(double)l0 : -(double)l1;
-  unsafeAtomicAdd(d, (float)(exp((double)l0) - (pos ? 1.0 : 0.0)));       // :106 / :134
-  unsafeAtomicAdd(d + hw, (float)(exp((double)l1) - (pos ? 0.0 : 1.0)));
+  const float g0 = (float)(exp((double)l0) - (pos ? 1.0 : 0.0)), g1 = (float)(exp((double)l1) - (pos ? 0.0 : 1.0));
+  if (exg) {
+    exg[6 * (size_t)e] = g0; exg[6 * (size_t)e + 1] = g1;
+    exg[6 * (size_t)e + 2] = exg[6 * (size_t)e + 3] = exg[6 * (size_t)e + 4] = exg[6 * (size_t)e + 5] = 0.f;
+  } else {
+    unsafeAtomicAdd(d, g0);       // :106 / :134
+    unsafeAtomicAdd(d + hw, g1);
+  }
   double reg = 0.0;
   float* crt = crtarget + 4 * (size_t)e;
   if (pos) {
@@ -198,7 +206,8 @@ __global__ void rpn_loss_kernel(LossArgs a, const int* __restrict__ ex_idx, cons
       const float az = fabsf(z);
       s += az < 1.0f ? 0.5 * (double)z * (double)z : (double)az - 0.5;  // SmoothL1, sizeAverage=false
       const float g = az < 1.0f ? z : (z > 0.f ? 1.0f : -1.0f);
-      unsafeAtomicAdd(d + (2 + c) * hw, g * 10.0f);                     // :113-114
+      if (exg) exg[6 * (size_t)e + 2 + c] = g * 10.0f;
+      else unsafeAtomicAdd(d + (2 + c) * hw, g * 10.0f);                // :113-114
     }
     reg = (double)(float)s * 10.0;                                      // :112
     // reg_proposal = Anchors.anchorToInput(anchor, reg_out) (objective.lua:111), then the cnet
@@ -220,6 +229,18 @@ __global__ void rpn_loss_kernel(LossArgs a, const int* __restrict__ ex_idx, cons
   ex_loss[2 * (size_t)e + 1] = reg;
 }
 
+__global__ void rpn_apply_kernel(LossArgs a, const int* __restrict__ ex_idx, const float* __restrict__ exg, int E) {
+  const int c = threadIdx.x;   // one wave; lanes 0..5 own the six planes of an anchor, examples in order
+  if (c >= 6) return;
+  for (int e = 0; e < E; ++e) {
+    const int* ix = ex_idx + 4 * e;
+    const int l = ix[0] - 1, asp = ix[1] - 1, y = ix[2] - 1, x = ix[3] - 1;
+    const long hw = (long)a.H[l] * a.W[l];
+    float* d = a.delta[l] + (size_t)(asp * 6 + c) * hw + (long)y * a.W[l] + x;
+    *d += exg[6 * (size_t)e + c];
+  }
+}
+
 int rpn_loss(const RpnLayers& L, float* const* delta, const int* ex_idx, const double* ex_anchor,
              const double* ex_roi, const int* ex_class, int npos, int nneg, int bgclass,
              double* ex_loss, float* crtarget, float* cctarget, hipStream_t s) {
@@ -229,8 +250,11 @@ int rpn_loss(const RpnLayers& L, float* const* delta, const int* ex_idx, const d
   for (int l = 0; l < 4; ++l) {
     a.map[l] = L.map[l]; a.delta[l] = delta[l]; a.H[l] = L.H[l]; a.W[l] = L.W[l];
   }
+  float* exg = nullptr;
+  if (deterministic()) FR_TRY(det_workspace(s, (size_t)E * 6, &exg));
   FR_LAUNCH(KC_RPN, 0, E * 200.0, s, rpn_loss_kernel, dim3(cdiv(E, 64)), dim3(64), 0, a, ex_idx, ex_anchor,
-            ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget);
+            ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, exg);
+  if (exg) FR_LAUNCH(KC_RPN, 0, E * 48.0, s, rpn_apply_kernel, dim3(1), dim3(64), 0, a, ex_idx, (const float*)exg, E);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

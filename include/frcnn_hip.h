@@ -41,9 +41,13 @@ const char *frcnn_last_error(void);
 int frcnn_device_count(int *n);
 int frcnn_set_device(int device);            /* cutorch.setDevice, main.lua:52 (0-based here) */
 int frcnn_device_name(char *buf_host, int len);
-/* Library tuning knobs.  "side_stream" (default 1; environment FRCNN_SIDE_STREAM): independent parts of a
+/* Library options.  "side_stream" (default 1; environment FRCNN_SIDE_STREAM): independent parts of a
  * pass (anchor nets, weight gradients) are issued on a library-owned second HIP stream and joined before the
- * entry point's results are used on the caller's stream.  0 = strictly serial on the caller's stream. */
+ * entry point's results are used on the caller's stream.  0 = strictly serial on the caller's stream.
+ * "deterministic" (default 0): the places where floating-point partial results meet in fp32 atomics (bias / slope
+ * gradient partials of the activation backward passes, the scatter-adds of the ROI-pooling and sparse anchor-net backward
+ * passes, the anchor deltas of two examples naming one anchor) switch to order-independent forms -- partials folded in
+ * index order, gathers, 64-bit fixed-point accumulation -- so that two runs on the same inputs are bit-identical. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 

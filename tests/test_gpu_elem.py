@@ -141,3 +141,42 @@ def test_scale_rmsprop_equals_the_two_calls(F):
     F._lib.call("frcnn_scale_rmsprop", F.ptr(b[0]), F.ptr(b[1]), 1.0 / 41.0, F.ptr(b[2]), n, 1e-4, 0.9, 1e-8, s)
     for u, v, what in zip(a, b, ("x", "g", "m")):
         assert torch.equal(u, v), what
+
+
+@pytest.mark.parametrize("H,W", [(29, 50), (100, 120)])    # the LDS path (plane <= 64 KB of 64-bit words) and the global one
+def test_deterministic_roi_pool_backward_and_partials(F, O, H, W):
+    """Deterministic mode op by op: ROI-pooling backward in 64-bit fixed point, bias / slope partials folded in order --
+    equal to the oracle like the default mode, and bit-identical from run to run."""
+    rng = np.random.RandomState(H)
+    C_, kh, kw, R = 12, 6, 6, 40
+    fmap = rng.randn(C_, H, W).astype(np.float32)
+    y0 = rng.randint(1, H - 8, R); x0 = rng.randint(1, W - 8, R)
+    wins = np.stack([y0, y0 + rng.randint(1, 8, R), x0, x0 + rng.randint(1, 8, R)], 1).astype(np.int32)
+    out = F.DeviceTensor.empty((R, C_ * kh * kw)); idx = F.DeviceTensor.empty((R, C_ * kh * kw), np.int32)
+    dfm, dwins = _dev(F, fmap), _dev(F, wins, np.int32)
+    F._lib.call("frcnn_roi_pool_forward", F.ptr(dfm), C_, H, W, F.ptr(dwins), R, kh, kw, F.ptr(out), F.ptr(idx), F.stream_ptr())
+    gout = (rng.randn(R, C_ * kh * kw) * 1e-3).astype(np.float32)
+    gidx = idx.numpy()
+    want = np.zeros((C_, H, W), dtype=np.float32)
+    for r in range(R):
+        O.adaptive_max_pool_bwd(want, gout[r].reshape(C_, kh, kw), gidx[r].reshape(C_, kh, kw))
+    dgout = _dev(F, gout)
+    x = rng.randn(C_, H * W).astype(np.float32); g = rng.randn(C_, H * W).astype(np.float32)
+    res = []
+    F._lib.call("frcnn_set_option", b"deterministic", 1)
+    try:
+        for _ in range(2):
+            gmap = F.DeviceTensor.zeros((C_, H, W))
+            F._lib.call("frcnn_roi_pool_backward", F.ptr(gmap), C_, H, W, F.ptr(dgout), F.ptr(idx), R, kh, kw, F.stream_ptr())
+            dg, dx, da = _dev(F, g), _dev(F, x), _dev(F, [0.25])
+            gb = F.DeviceTensor.zeros((C_,)); ga = F.DeviceTensor.zeros((1,))
+            F._lib.call("frcnn_act_backward", F.ptr(dg), F.ptr(dx), C_, H * W, F.ptr(da), None, F.ptr(dg), F.ptr(gb), F.ptr(ga), F.stream_ptr())
+            res.append((gmap.numpy(), gb.numpy(), ga.numpy()))
+    finally:
+        F._lib.call("frcnn_set_option", b"deterministic", 0)
+    assert_close(res[0][0], want, 1e-5, "deterministic roi pool bwd")
+    gx = np.where(x > 0, g, 0.25 * g)
+    assert_close(res[0][1], gx.astype(np.float64).sum(1), 1e-4)
+    assert_close(res[0][2][0], float(np.where(x > 0, 0, x.astype(np.float64) * g).sum()), 1e-4)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)

@@ -437,3 +437,54 @@ def test_bucketed_exchange_path_on_one_gpu(F, setup, monkeypatch):
     b3, b2 = model["pnet"].block_param_range(3), model["pnet"].block_param_range(2)
     assert b3 in first_ranges and b2 in first_ranges and b3[1] == lo and b2[1] == b3[0]
     assert b3[1] - b3[0] == 256 * 384 * 9 + 384 * 384 * 9 + 2 * (384 + 1)
+
+
+def test_deterministic_mode_is_bit_reproducible(F, setup):
+    """frcnn_set_option("deterministic", 1): no floating-point partial results meet in fp32 atomics any more (ordered folds,
+    gathers, 64-bit fixed point), so two runs of the same training step are BIT-identical -- and agree with the default mode
+    to rounding."""
+    import ctypes as C
+    import torch
+    s = setup
+    model, cfg = s["model"], s["cfg"]
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rois = F.synthetic_rois(cfg, W, H, 3, 7, 4)
+    pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(17), negatives=24)
+    sizes = F.output_map_sizes(model, H, W)
+    pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
+    neg = neg + neg[:5]          # the same anchor sampled twice (two deltas land on one address)
+    batch = [dict(img=F.synthetic_image(H, W, 4), positive=pos, negative=neg)]
+    R = len(pos) + len(neg)
+    rng = np.random.RandomState(2)
+    nat = model["native"]
+    bn0 = nat.bn_running.cpu().numpy().copy()
+    w0 = s["weights"].clone()
+    model["pnet"].drop_masks = _masks(rng, model)
+    model["cnet"].drop_masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+    runs = {}
+    try:
+        for tag, det in (("det_a", 1), ("det_b", 1), ("default", 0)):
+            F._lib.call("frcnn_set_option", b"deterministic", det)
+            v = C.c_int(-1)
+            F._lib.call("frcnn_get_option", b"deterministic", C.byref(v))
+            assert v.value == det
+            stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+            f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
+            F.rmsprop(f, s["weights"], dict(learningRate=1e-4, alpha=0.9))
+            torch.cuda.synchronize()
+            runs[tag] = (s["gradient"].cpu().numpy().copy(), s["weights"].cpu().numpy().copy(), [stats[k][-1] for k in ("pcls", "preg", "dcls", "dreg")])
+            s["weights"].copy_(w0)
+            nat.bn_running.copy_(torch.from_numpy(bn0))
+    finally:
+        F._lib.call("frcnn_set_option", b"deterministic", 0)
+        model["pnet"].drop_masks = None
+        model["cnet"].drop_masks = None
+        s["weights"].copy_(w0)
+        nat.bn_running.copy_(torch.from_numpy(bn0))
+    assert np.array_equal(runs["det_a"][0], runs["det_b"][0]), "gradient differs between two deterministic runs"
+    assert np.array_equal(runs["det_a"][1], runs["det_b"][1]), "updated weights differ between two deterministic runs"
+    assert runs["det_a"][2] == runs["det_b"][2]
+    g, gd = runs["default"][0].astype(np.float64), runs["det_a"][0].astype(np.float64)
+    assert np.isfinite(gd).all() and np.abs(gd).max() > 0
+    assert np.linalg.norm(g - gd) <= 1e-6 * np.linalg.norm(g)
+    assert np.allclose(runs["default"][2], runs["det_a"][2], rtol=1e-6, atol=0)
