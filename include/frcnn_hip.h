@@ -47,7 +47,10 @@ int frcnn_device_name(char *buf_host, int len);
  * "deterministic" (default 0): the places where floating-point partial results meet in fp32 atomics (bias / slope
  * gradient partials of the activation backward passes, the scatter-adds of the ROI-pooling and sparse anchor-net backward
  * passes, the anchor deltas of two examples naming one anchor) switch to order-independent forms -- partials folded in
- * index order, gathers, 64-bit fixed-point accumulation -- so that two runs on the same inputs are bit-identical. */
+ * index order, gathers, 64-bit fixed-point accumulation -- so that two runs on the same inputs are bit-identical.
+ * "winograd" (default 0; environment FRCNN_WINO): 3x3 / pad 1 convolutions with enough 16 x 16-pixel blocks run in the
+ * Winograd F(2x2, 3x3) form (2.25x fewer multiplications, same result to fp32 rounding); applies to the operator-level
+ * entry points at once and to a model from its next (re)shaping on. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 

@@ -24,7 +24,18 @@ def fullsize_inputs(F, cfg, model):
     return anchors, rois, pos, neg, F.synthetic_image(H, W, 0)
 
 
-def test_fullsize_loss_and_gradient(F, O):
+@pytest.mark.parametrize("winograd", [0, 1])
+def test_fullsize_loss_and_gradient(F, O, winograd):
+    """winograd = 1: the eligible 3x3 layers of the forward pass (b2c1, b2c2, b3c1, b3c2 at this size) in the Winograd
+    F(2x2, 3x3) form (option "winograd") -- same bars."""
+    F._lib.call("frcnn_set_option", b"winograd", winograd)
+    try:
+        _fullsize(F, O)
+    finally:
+        F._lib.call("frcnn_set_option", b"winograd", 0)
+
+
+def _fullsize(F, O):
     import torch
     cfg = dict(F.duplo_cfg)
     model = F.vgg_small(cfg)
