@@ -29,7 +29,7 @@ k3 = [k for k in out["kernels"] if k.startswith("conv_igemm_kernel<3, 8")]
 n = sum(out["kernels"][k]["launches"] for k in k3)
 if n:
     out["conv_igemm_k3_bytes_per_launch"] = round(sum(out["kernels"][k]["launches"] * (out["kernels"][k]["fetch_bytes_per_launch_corrected"] + out["kernels"][k]["write_bytes_per_launch"]) for k in k3) / n)
-rm = out["kernels"].get("rmsprop_kernel")
+rm = next((v for k, v in out["kernels"].items() if k.startswith("rmsprop_kernel")), None)
 if rm:
     out["calibration_rmsprop"] = dict(fetch_corrected=rm["fetch_bytes_per_launch_corrected"], write=rm["write_bytes_per_launch"])
 json.dump(out, open(sys.argv[3], "w"), indent=1)

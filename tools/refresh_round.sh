@@ -1,0 +1,54 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): every measurement that profiles/ holds for one round, from the current tree, into
+# gpurun_out/<tag>/ (copy what should be judged into profiles/).  usage: bash tools/refresh_round.sh r02
+TAG=${1:-r02}
+R=/root/repo; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# 1. PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- $B > $O/mfma.log 2>&1
+cd $R
+python tools/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json | tee $O/traffic.log
+python tools/pmc_summary.py $O/mfma $O/fetch $O/write $O/${TAG}_kernel_evidence.csv > $O/evidence.log 2>&1
+python - "$O" "$TAG" <<'PY'
+import collections, csv, glob, sys
+O, TAG = sys.argv[1], sys.argv[2]
+for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob("%s/%s/*/*counter_collection.csv" % (O, name))[0])):
+        if r["Counter_Name"] == ctr:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    rows = sorted(acc.items(), key=lambda kv: -sum(kv[1]))
+    with open("%s/%s_pmc_%s_size.csv" % (O, TAG, name), "w") as f:
+        w = csv.writer(f); w.writerow(["kernel", "dispatches", "mean_%s_KB" % ctr, "total_KB"])
+        for k, v in rows:
+            w.writerow([k, len(v), round(sum(v) / len(v), 1), round(sum(v), 1)])
+PY
+# 2. kernel stats of the bench command (rocprofv3 --kernel-trace --stats) and the step timeline of the same trace
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
+cd $R
+cp $O/stats/*/*kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
+python tools/timeline.py $O/stats 12 > $O/${TAG}_step_timeline.txt 2>&1
+# 3. the bench line itself (un-profiled), with the CPU baseline, the parity object and the other legs
+python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
+# 4. the other configurations and options
+{
+  echo "# MI355X, $TAG: configurations and options beside the bench line (commands as run on the GPU box)"
+  echo "# per-layer convolution kernels, vgg_small 800x450 shapes -- python tools/bench_conv.py fwd|dgrad|wgrad"
+  python tools/bench_conv.py fwd 2>/dev/null; python tools/bench_conv.py dgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null; python tools/bench_conv.py wgrad 2>/dev/null
+  echo "# the same with the Winograd F(2x2,3x3) form of the eligible 3x3 layers -- FRCNN_WINO=1 python tools/bench_conv.py fwd|dgrad"
+  FRCNN_WINO=1 python tools/bench_conv.py fwd b2c1 b2c2 b3c1 b3c2 2>/dev/null; FRCNN_WINO=1 python tools/bench_conv.py dgrad b2c1 b2c2 b3c2 2>/dev/null
+  echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
+  for e in "FRCNN_WINO=0" "FRCNN_WINO=1" "FRCNN_WINO=1 FRCNN_WINO_DGRAD=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
+    echo -n "$e: "; env $e python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
+  done
+  echo "# config 5 shapes on one GPU -- python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline"
+  for e in "FRCNN_WINO=0" "FRCNN_WINO=1"; do
+    echo -n "$e: "; env $e python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'images/s', d['ms_per_step'], 'ms/step; conv_igemm 3x3', r['achieved'], 'TFLOP/s live,', r['isolated']['achieved'], 'alone')"
+  done
+  echo "# config 2 -- python tools/bench_detect.py 30   (Detector:detect on 3x450x800 frames; CLASSES=200: config/imagenet.lua class count)"
+  python tools/bench_detect.py 30 2>/dev/null; CLASSES=200 CLS_GAIN=2000 python tools/bench_detect.py 30 2>/dev/null
+} > $O/${TAG}_other_configs.txt 2>&1
+ls -la $O | head -40
