@@ -1,0 +1,476 @@
+// convx.hip -- the 3x3 nn.SpatialConvolution forward / updateGradInput (models/model_utilities.lua:8 driven by
+// objective.lua:71,189 and Detector.lua:33) on the gfx950 bf16 matrix cores WITHOUT giving up fp32 results:
+// "split operands".  Every fp32 value x is written as the exact sum of three bf16 numbers
+//     x = h + m + l + eps,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m),   |eps| <= 2^-26 |x|
+// (round to nearest; x - h and x - h - m are exact in fp32), and a product x*y is formed from the six partial products
+//     l*h' + h*l' + m*m' + m*h' + h*m' + h*h'                      (the dropped m*l', l*m', l*l' are <= 2^-25 |x y|)
+// each of which is EXACT in fp32 (8 x 8 significand bits) and is accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+// The result carries the 24 significand bits of an fp32 product; against an fp64 reference its error is the same as that
+// of the fp32 matrix-core kernel in conv.hip (tests/test_gpu_convx.py measures both), but six bf16 instructions of 32
+// cycles replace eight fp32 instructions (v_mfma_f32_32x32x2_f32) of 64 cycles for the same 32 x 32 x 16 block of the
+// product: 2.67x less matrix-pipe time.
+//
+// Tensors stay fp32 CHW in HBM exactly as in conv.hip.  Weights are split once per optimiser step by the pack kernel
+// (three bf16 planes in MFMA fragment order, brought to LDS by DMA); the input patch is split while it is staged (global
+// -> registers -> PReLU / dropout scale of the producing layer -> split -> LDS), once per block and 16-channel chunk, and
+// re-used by the nine taps and the four waves.
+//
+// GEMM view: D[m = filter][n = pixel] = sum_{tap, c} W[m][c][tap] * X[c][pixel + tap];  block = 128 filters x (TH x TW <=
+// 128) pixels, 2 x 2 waves of 64 x 64 (four 32x32 accumulators), K step = 16 channels of one tap (lane half h takes
+// channels 8h..8h+7), stage = one tap of a 16-channel chunk: A ring of three 12 KB stages (DMA two stages ahead), B patch
+// double-buffered per chunk.  75-79 KB of LDS -> two blocks per CU.
+#include <cstdlib>
+
+#include "kernels.h"
+#include <type_traits>
+
+namespace frcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CX_BM 128                       // filters per block
+#define CX_CH 16                        // channels per chunk (one MFMA K step per tap)
+#define CX_PP 228                       // patch positions per (plane, half) in LDS (pitch); patch plane <= CX_PP
+#define CX_NTMAX 128                    // pixels per block
+#define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage: [plane 3][half 2][128 filters][8 bf16]
+#define CX_BBUF (6 * CX_PP * 16)        // bytes of one B buffer: [plane 3][half 2][CX_PP positions][8 bf16]
+#define CX_LDS (3 * CX_ASTAGE + 2 * CX_BBUF)
+
+static int g_splitbf16 = -1;   // -1: not decided yet (environment FRCNN_SPLIT_BF16, default on)
+void set_split_bf16(int on) { g_splitbf16 = on ? 1 : 0; }
+int get_split_bf16() {
+  if (g_splitbf16 < 0) g_splitbf16 = getenv("FRCNN_SPLIT_BF16") ? (atoi(getenv("FRCNN_SPLIT_BF16")) != 0) : 1;
+  return g_splitbf16;
+}
+
+bool conv_x3_eligible(int Cin, int M, int k) {
+  return get_split_bf16() && k == 3 && Cin % CX_CH == 0 && Cin >= CX_CH && M % CX_BM == 0;
+}
+
+size_t conv_x3_pack_bytes(int Kchan, int M) { return (size_t)(M / CX_BM) * (Kchan / CX_CH) * 9 * CX_ASTAGE; }
+
+// ---- three-way bf16 split of 8 values -> three 16-byte plane entries
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint4& L) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    h[j] = cvt2(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h[j] << 16), r1 = x1 - __builtin_bit_cast(float, h[j] & 0xFFFF0000u);
+    m[j] = cvt2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m[j] << 16), s1 = r1 - __builtin_bit_cast(float, m[j] & 0xFFFF0000u);
+    l[j] = cvt2(s0, s1);
+  }
+  H = make_uint4(h[0], h[1], h[2], h[3]);
+  Mi = make_uint4(m[0], m[1], m[2], m[3]);
+  L = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+// dst, per (m tile, chunk, tap): one A stage [plane][half][128][8] -- exactly the LDS image.
+//  mode 0 (fwd):   A[m][kc][tap] = W[m][kc][tap]            (W is [O][C][3][3]: M = O, K channels = C)
+//  mode 1 (dgrad): A[m][kc][tap] = W[kc][m][8 - tap]        (M = C, K channels = O; the flipped filter)
+__device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk) {
+  const float* __restrict__ w = weights + j.w_off;
+  const int M = j.mode == 0 ? j.O : j.C, KC = j.mode == 0 ? j.C : j.O;
+  const int nCh = KC / CX_CH;
+  const long items = (long)(M / CX_BM) * nCh * 9 * 2 * CX_BM;
+  for (long it = (long)blk * 256 + threadIdx.x; it < items; it += (long)nblk * 256) {
+    const int r = (int)(it % CX_BM);
+    long q = it / CX_BM;
+    const int h = (int)(q & 1); q >>= 1;
+    const int tap = (int)(q % 9); q /= 9;
+    const int chunk = (int)(q % nCh);
+    const int mt = (int)(q / nCh);
+    const int m = mt * CX_BM + r;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kc = chunk * CX_CH + 8 * h + i;
+      v[i] = j.mode == 0 ? w[((long)m * j.C + kc) * 9 + tap] : w[((long)kc * j.C + m) * 9 + (8 - tap)];
+    }
+    uint4 H, Mi, L;
+    split8(v, H, Mi, L);
+    char* stage = reinterpret_cast<char*>(j.dst) + ((size_t)(mt * nCh + chunk) * 9 + tap) * CX_ASTAGE;
+    *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * CX_BM + r) * 16) = H;
+    *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * CX_BM + r) * 16) = Mi;
+    *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * CX_BM + r) * 16) = L;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_x3_multi_kernel(const float* __restrict__ weights, const PackXJob* __restrict__ jobs, int njobs) {
+  int jb = 0;
+  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_begin) ++jb;
+  const PackXJob j = jobs[jb];
+  pack_x3_job(weights, j, blockIdx.x - j.blk_begin, j.nblk);
+}
+
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ weights, PackXJob j) {
+  pack_x3_job(weights, j, blockIdx.x, gridDim.x);
+}
+
+PackXJob conv_x3_pack_job(long w_off, int O, int C, int mode, void* dst) {
+  PackXJob j;
+  j.w_off = w_off; j.O = O; j.C = C; j.mode = mode; j.dst = dst;
+  j.total = (long)O * C * 9;
+  j.blk_begin = 0; j.nblk = 1;
+  return j;
+}
+
+int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs) {
+  int b = 0;
+  for (int i = 0; i < njobs; ++i) {
+    jobs[i].blk_begin = b;
+    jobs[i].nblk = (int)std::max<long>(1, std::min<long>(512, jobs[i].total / 8 / 256 / 2));
+    b += jobs[i].nblk;
+  }
+  return b;
+}
+
+int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s) {
+  if (njobs <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_multi_kernel, dim3(grid), dim3(256), 0, weights, jobs_dev, njobs);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// one pack by itself (op-level entry points and tests)
+int conv_x3_pack(const float* w, int O, int C, int mode, void* dst, hipStream_t s) {
+  PackXJob j = conv_x3_pack_job(0, O, C, mode, dst);
+  int grid = conv_x3_pack_assign_blocks(&j, 1);
+  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_kernel, dim3(grid), dim3(256), 0, w, j);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ the convolution
+struct CxArgs {
+  const float* in;
+  const float* in_slope;  // device scalar or null
+  const float* in_scale;  // device [Cin] or null
+  const void* wp;         // packed stages [mTile][chunk][tap][CX_ASTAGE]
+  const float* bias;      // [M] or null
+  float* out;             // [M][Ho][Wo]
+  int Cin, H, W, M, Ho, Wo, pad;
+  int TH, TW, tilesX, tilesY, mTiles;
+  int nChunks, splitK, chunksPerSplit;
+  int out_mode;           // 0 store, 1 add, 3 split-K slab
+};
+
+template <bool SLOPE, bool SCALE>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, li = lane & 31;
+
+  // XCD-aware order (see conv.hip): consecutive virtual indices of one XCD are the M tiles of one pixel tile
+  const int nT = p.tilesX * p.tilesY;
+  int v;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    v = xcd * q + min(xcd, r) + idx;
+  }
+  const int mt_id = v % p.mTiles;
+  v /= p.mTiles;
+  const int nt_id = v % nT;
+  const int split = v / nT;
+  const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
+  const int m0 = mt_id * CX_BM;
+  const int PW = p.TW + 2, plane = (p.TH + 2) * PW;
+  const int NT = p.TH * p.TW;
+  const int HW = p.H * p.W;
+  const size_t hw_bytes = (size_t)HW * 4;
+
+  // ---- this thread's two staging items: (half g, patch position): 8 channels each
+  unsigned gofs[2];      // byte offset inside the chunk's first channel plane (includes the 8 g channels)
+  bool gok[2];
+  unsigned sdst[2];      // LDS byte offset of the item's 16-byte entry inside plane 0 of a B buffer
+  int gsel[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + 256 * it;
+    const int g = e >= plane ? 1 : 0;
+    const int pos = e - g * plane;
+    const int r = pos / PW, col = pos - r * PW;
+    const int gy = ty0 - p.pad + r, gx = tx0 - p.pad + col;
+    const bool valid = e < 2 * plane;
+    gok[it] = valid && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    gofs[it] = (gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u) + (unsigned)g * 8u * (unsigned)hw_bytes;
+    sdst[it] = valid ? (unsigned)((g * CX_PP + pos) * 16) : 0xFFFFFFFFu;
+    gsel[it] = g;
+  }
+  const float slope = SLOPE ? *p.in_slope : 1.f;
+
+  // ---- lane offsets of the MFMA operand reads
+  const unsigned aoff = (unsigned)((h * CX_BM + wm * 64 + li) * 16);
+  unsigned boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    int q = wn * 64 + nt * 32 + li;
+    q = q < NT ? q : NT - 1;
+    const int ty = q / p.TW, tx = q - ty * p.TW;
+    boff[nt] = (unsigned)((h * CX_PP + ty * PW + tx) * 16);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int cbeg = split * p.chunksPerSplit;
+  const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
+  const int nStages = (cend - cbeg) * 9;
+
+  char* const As = smem;
+  char* const Bs = smem + 3 * CX_ASTAGE;
+
+  // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
+  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * 9 * CX_ASTAGE +
+                           (size_t)wave * 3072 + lane * 16;
+  auto dma_stage = [&](int stage, int buf) {
+    const char* src = wsrc + (size_t)stage * CX_ASTAGE;
+    char* dst = As + buf * CX_ASTAGE + wave * 3072;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+
+  float vb[2][8];
+  float sc[2][8];
+  auto load_patch = [&](int chunk) {
+    const char* srcB = reinterpret_cast<const char*>(p.in) + (size_t)chunk * CX_CH * hw_bytes;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[it][j] = *reinterpret_cast<const float*>(srcB + j * hw_bytes + gofs[it]);
+    if (SCALE) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + chunk * CX_CH + 8 * gsel[it]);
+        const float4 s0 = sp[0], s1 = sp[1];
+        sc[it][0] = s0.x; sc[it][1] = s0.y; sc[it][2] = s0.z; sc[it][3] = s0.w;
+        sc[it][4] = s1.x; sc[it][5] = s1.y; sc[it][6] = s1.z; sc[it][7] = s1.w;
+      }
+    }
+  };
+  auto store_patch = [&](char* Bb) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = vb[it][j];
+        if (SLOPE) t = t > 0.f ? t : slope * t;
+        if (SCALE) t *= sc[it][j];
+        x[j] = gok[it] ? t : 0.f;
+      }
+      uint4 H, Mi, L;
+      split8(x, H, Mi, L);
+      if (sdst[it] != 0xFFFFFFFFu) {
+        char* d = Bb + sdst[it];
+        *reinterpret_cast<uint4*>(d) = H;
+        *reinterpret_cast<uint4*>(d + 2 * CX_PP * 16) = Mi;
+        *reinterpret_cast<uint4*>(d + 4 * CX_PP * 16) = L;
+      }
+    }
+  };
+
+  // one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + 2 B)), 24 MFMAs
+  auto compute = [&](const char* Ab, const char* Bb, int tapoff) {
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * CX_BM + mt * 32) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
+    }
+    // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
+  };
+
+  // ---- prologue: patch of the first chunk, A stages 0 and 1
+  load_patch(cbeg);
+  dma_stage(0, 0);
+  dma_stage(1, 1);
+  store_patch(Bs);
+  bool more = false;
+
+  int stage = 0;
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const char* Bcur = Bs + ((chunk - cbeg) & 1) * CX_BBUF;
+    char* Bnext = Bs + (((chunk - cbeg) & 1) ^ 1) * CX_BBUF;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++stage) {
+      // stage's A image has landed in every wave's part (DMA retires in order: at most the next stage's three
+      // instructions -- and, right after a chunk's first tap, the patch loads issued behind them -- may be in flight)
+      if (stage + 1 >= nStages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __syncthreads();
+      if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2) % 3);
+      if (tap == 0) {   // the next chunk's patch: requested now, split and written to the other buffer at tap 4
+        more = chunk + 1 < cend;
+        if (more) load_patch(chunk + 1);
+      }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      compute(As + (tap % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
+      if (tap == 4 && more) store_patch(Bnext);
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
+  const long HoWo = (long)p.Ho * p.Wo;
+  const bool add_bias = p.bias != nullptr && split == 0;
+  const int mrow0 = m0 + wm * 64 + 4 * h;
+  auto store_tile = [&](auto mode_c) {
+    constexpr int OM = decltype(mode_c)::value;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int q = wn * 64 + nt * 32 + li;
+      const int ty = q / p.TW, tx = q - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      if (q < NT && oy < p.Ho && ox < p.Wo) {
+        float* col = p.out + (OM == 3 ? (size_t)split * p.M * HoWo : (size_t)0) + (size_t)oy * p.Wo + ox;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) {
+              float val = acc[mt][nt][r];
+              if (add_bias) val += p.bias[m];
+              float* dst = col + (size_t)m * HoWo;
+              if (OM == 1) *dst += val; else *dst = val;
+            }
+          }
+        }
+      }
+    }
+  };
+  if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
+  else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
+  else store_tile(std::integral_constant<int, 3>{});
+}
+
+// out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
+__global__ void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw, const float* __restrict__ bias,
+                                        float* __restrict__ out, int accumulate) {
+  const long total = (long)M * hw;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    float v = bias ? bias[t / hw] : 0.f;
+    for (int s = 0; s < nSplit; ++s) v += slab[(size_t)s * total + t];
+    if (accumulate) out[t] += v; else out[t] = v;
+  }
+}
+
+static void* g_x3_ws[8] = {};
+static size_t g_x3_ws_bytes[8] = {};
+static int x3_workspace(size_t need, float** out, int slot) {
+  if (need > g_x3_ws_bytes[slot]) {
+    if (g_x3_ws[slot]) FR_HIP(hipFree(g_x3_ws[slot]));
+    g_x3_ws[slot] = nullptr; g_x3_ws_bytes[slot] = 0;
+    FR_HIP(hipMalloc(&g_x3_ws[slot], need));
+    g_x3_ws_bytes[slot] = need;
+  }
+  *out = (float*)g_x3_ws[slot];
+  return FRCNN_OK;
+}
+
+// output tile TH x TW <= 128 pixels with a patch plane <= CX_PP that wastes the least work
+static void x3_choose_tile(int Ho, int Wo, int* TH, int* TW) {
+  long best = -1;
+  int bth = 1, btw = 1;
+  for (int tw = 1; tw <= std::min(Wo, CX_NTMAX); ++tw) {
+    if (tw < 8 && Wo >= 8) continue;
+    int th = std::min(CX_NTMAX / tw, Ho);
+    while (th > 1 && (th + 2) * (tw + 2) > CX_PP) --th;
+    if (th < 1 || (th + 2) * (tw + 2) > CX_PP) continue;
+    long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
+    long cost = tiles * CX_NTMAX * 64 + tiles * (th + 2) * (tw + 2);  // MFMA slots + halo traffic
+    if (best < 0 || cost < best || (cost == best && tw > btw)) { best = cost; bth = th; btw = tw; }
+  }
+  *TH = bth; *TW = btw;
+}
+
+template <bool SLOPE, bool SCALE>
+static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<SLOPE, SCALE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
+  double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
+  FR_LAUNCH(KC_CONV_IGEMM_K3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
+            const float* bias, int M, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot) {
+  FR_CHECK(Cin % CX_CH == 0 && M % CX_BM == 0, "conv_x3: %d channels -> %d filters is not a split-bf16 shape", Cin, M);
+  FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
+  CxArgs a;
+  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
+  a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.pad = pad;
+  a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
+  FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, pad=%d)", H, W, pad);
+  x3_choose_tile(a.Ho, a.Wo, &a.TH, &a.TW);
+  a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
+  a.mTiles = M / CX_BM;
+  a.nChunks = Cin / CX_CH;
+  const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
+  // split K until one round of blocks fills the 2 x 256 resident slots, keeping >= 4 chunks (36 stages) per split
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, 512 / blocks), 16), std::max(1, a.nChunks / 4));
+  if (const char* e = getenv("FRCNN_X3_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
+  a.chunksPerSplit = cdiv(a.nChunks, splitK);
+  a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
+  a.out_mode = out_mode;
+  bool slab = false;
+  if (a.splitK > 1) {
+    float* ws = nullptr;
+    FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
+    a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
+  }
+  if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * 9 * (double)a.Ho * a.Wo;
+  int rc;
+  if (in_slope) rc = in_scale ? launch_x3<true, true>(a, algo_flops, s) : launch_x3<true, false>(a, algo_flops, s);
+  else rc = in_scale ? launch_x3<false, true>(a, algo_flops, s) : launch_x3<false, false>(a, algo_flops, s);
+  FR_TRY(rc);
+  if (slab) {
+    long total = (long)M * a.Ho * a.Wo;
+    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel, dim3(grid), dim3(256), 0,
+              (const float*)a.out, a.splitK, M, (long)a.Ho * a.Wo, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    FR_LAUNCH_CHECK();
+  }
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn

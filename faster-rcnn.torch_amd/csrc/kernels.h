@@ -48,6 +48,21 @@ int conv_wino_filter_multi(const float* weights, const WinoFilterJob* jobs_dev, 
 int conv_wino(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* U,
               const float* bias, int M, float* out, int out_mode, double algo_flops, hipStream_t s);
 
+// ---- split-bf16 operand form of the 3x3 convolution (convx.hip): fp32 tensors in and out, every product formed from six
+// exact bf16 x bf16 partial products (three-way split of both operands) accumulated in fp32 on the bf16 matrix cores -- the
+// accuracy of the fp32 matrix-core kernel at 6/16 of its matrix-pipe time.  wp = stages packed by conv_x3_pack*.
+void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 launches take this form, 0 = fp32 MFMA only
+int get_split_bf16();
+bool conv_x3_eligible(int Cin, int M, int k);   // k == 3, Cin % 16 == 0, M % 128 == 0 (and the option is on)
+size_t conv_x3_pack_bytes(int Kchan, int M);
+struct PackXJob { long w_off; long total; void* dst; int O, C, mode, blk_begin, nblk; };   // mode 0 forward, 1 input gradient
+PackXJob conv_x3_pack_job(long w_off, int O, int C, int mode, void* dst);
+int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
+int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
+int conv_x3_pack(const float* w, int O, int C, int mode, void* dst, hipStream_t s);
+int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
+            const float* bias, int M, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0);
+
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (split-K slabs in `ws`, folded in a fixed order)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);

@@ -48,6 +48,8 @@ struct Conv {
   DevBuf wf, wd;              // packed weights (forward / input-gradient)
   DevBuf wu, wud;             // Winograd-transformed filters (wino.hip) for the launches that take that form
   bool wino_f = false, wino_d = false;
+  DevBuf wx, wxd;             // split-bf16 operand stages (convx.hip) for the launches that take that form
+  bool x_f = false, x_d = false;
   DevBuf x, gx;               // pre-activation output and its gradient
 };
 
@@ -101,6 +103,8 @@ struct frcnn_model {
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
   DevBuf wino_jobs;            // device table of WinoFilterJob: [training jobs (fwd + dgrad filters)] [forward-only jobs]
   int n_wino_all = 0, n_wino_fwd = 0, wino_grid_all = 0, wino_grid_fwd = 0;
+  DevBuf x3_jobs;              // device table of PackXJob, same arrangement
+  int n_x3_all = 0, n_x3_fwd = 0, x3_grid_all = 0, x3_grid_fwd = 0;
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
@@ -230,6 +234,11 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
   // of the matrix pipe while it shares the CUs (roofline.frac, live) drops from 0.59 to 0.53.  FRCNN_WINO_DGRAD=1 turns it on.
   static const int wino_dgrad = getenv("FRCNN_WINO_DGRAD") ? atoi(getenv("FRCNN_WINO_DGRAD")) : 0;
   c.wino_d = wino_dgrad && c.block >= 0 && need_dgrad && conv_wino_eligible(c.Cout, c.Ho, c.Wo, c.Cin, c.k, c.k - 1 - c.pad);
+  // 3x3 launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time
+  c.x_f = !c.wino_f && conv_x3_eligible(c.Cin, c.Cout, c.k);
+  c.x_d = !c.wino_d && c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
+  if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout)));
+  if (c.x_d) FR_TRY(c.wxd.ensure(conv_x3_pack_bytes(c.Cout, c.Cin)));
   if (c.wino_f) FR_TRY(c.wu.ensure(conv_wino_filter_floats(c.Cin, c.Cout) * 4));
   if (c.wino_d) FR_TRY(c.wud.ensure(conv_wino_filter_floats(c.Cout, c.Cin) * 4));
   return FRCNN_OK;
@@ -284,14 +293,15 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
   FR_TRY(m->wg_ws.ensure(wsb));
   {  // pack-job table (buffers may have been re-allocated above)
     std::vector<PackJob> jobs;
-    for (auto& c : m->convs) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wf.f()));
+    for (auto& c : m->convs)
+      if (!c.x_f) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wf.f()));
     for (auto& hd : m->heads) {
-      jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 0, hd.c3.wf.f()));
+      if (!hd.c3.x_f) jobs.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 0, hd.c3.wf.f()));
       jobs.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 0, hd.c1.wf.f()));
     }
     m->n_pack_fwd = (int)jobs.size();
     for (auto& c : m->convs)
-      if (!(c.block == 0 && c.step == 0)) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
+      if (!(c.block == 0 && c.step == 0) && !c.x_d) jobs.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
     m->n_pack_all = (int)jobs.size();
     // the heads' input-gradient packs are only needed by the dense head backward (more than SPARSE_MAX_POS
     // examples on a head); they are refreshed lazily by frcnn_pnet_backward
@@ -327,6 +337,23 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       FR_HIP(hipMemcpy(m->wino_jobs.p, all.data(), all.size() * sizeof(WinoFilterJob), hipMemcpyHostToDevice));
     }
   }
+  {  // split-bf16 pack jobs
+    std::vector<PackXJob> all, fwd;
+    auto add = [&](Conv& c) {
+      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, 0, c.wx.p)); fwd.push_back(all.back()); }
+      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, 1, c.wxd.p));
+    };
+    for (auto& c : m->convs) add(c);
+    for (auto& hd : m->heads) add(hd.c3);
+    m->n_x3_all = (int)all.size(); m->n_x3_fwd = (int)fwd.size();
+    m->x3_grid_all = conv_x3_pack_assign_blocks(all.data(), m->n_x3_all);
+    m->x3_grid_fwd = conv_x3_pack_assign_blocks(fwd.data(), m->n_x3_fwd);
+    all.insert(all.end(), fwd.begin(), fwd.end());
+    if (!all.empty()) {
+      FR_TRY(m->x3_jobs.ensure(all.size() * sizeof(PackXJob)));
+      FR_HIP(hipMemcpy(m->x3_jobs.p, all.data(), all.size() * sizeof(PackXJob), hipMemcpyHostToDevice));
+    }
+  }
   m->H = H; m->W = W;
   return FRCNN_OK;
 }
@@ -357,7 +384,7 @@ int frcnn_model_create(const frcnn_model_desc* desc, frcnn_model** out) {
 
 int frcnn_model_destroy(frcnn_model* m) {
   if (!m) return FRCNN_OK;
-  auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.wu.release(); c.wud.release(); c.x.release(); c.gx.release(); };
+  auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.wu.release(); c.wud.release(); c.wx.release(); c.wxd.release(); c.x.release(); c.gx.release(); };
   for (auto& c : m->convs) rel(c);
   for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); }
   for (auto& h : m->heads) {
@@ -368,7 +395,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
-  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->wino_jobs.release(); m->zero_arena.release();
+  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->wino_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
@@ -432,6 +459,7 @@ int frcnn_get_option(const char* name, int* value) {
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "winograd") == 0) { *value = get_winograd(); return FRCNN_OK; }
+  if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
 }
@@ -440,6 +468,7 @@ int frcnn_set_option(const char* name, int value) {
   FR_CHECK(name != nullptr, "set_option: null name");
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
+  if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   if (strcmp(name, "winograd") == 0) { set_winograd(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   FR_CHECK(false, "set_option: unknown option '%s'", name);
   return FRCNN_OK;
@@ -526,8 +555,12 @@ static int fork_to(frcnn_model* m, hipStream_t s, hipStream_t to, size_t idx) {
 // one anchor net: k x k conv -> PReLU (fused into the 1x1 loader) -> 1x1 conv (models/model_utilities.lua:31-34)
 static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, int ws_slot) {
   const Block& in = m->blocks[h.input];
-  FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
-                    h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
+  if (h.c3.x_f)
+    FR_TRY(conv_x3(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wx.p, w + h.c3.b_off, h.c3.Cout, 0,
+                   h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
+  else
+    FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
+                      h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
   FR_TRY(conv_igemm(h.c3.x.f(), h.c1.Cin, h.c1.H, h.c1.W, w + h.c3.a_off, nullptr, h.c1.wf.f(), w + h.c1.b_off,
                     HEAD_OUT, 1, 0, h.c1.x.f(), OUT_STORE, 0, s, ws_slot));
   return FRCNN_OK;
@@ -570,6 +603,10 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     FR_TRY(conv_wino_filter_multi(w, (const WinoFilterJob*)m->wino_jobs.p, m->n_wino_all, m->wino_grid_all, s));
   else
     FR_TRY(conv_wino_filter_multi(w, (const WinoFilterJob*)m->wino_jobs.p + m->n_wino_all, m->n_wino_fwd, m->wino_grid_fwd, s));
+  if (training)
+    FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p, m->n_x3_all, m->x3_grid_all, s));
+  else
+    FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
   FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
   FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
   const float* cur = m->img.f();
@@ -584,7 +621,9 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
       // the block's max pool rides in the epilogue of its last convolution when that launch is a single K split
       IgemmPool pl = {blk.pooled.f(), (unsigned char*)blk.pidx.p, w + c.a_off,
                       (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
-      if (c.wino_f)
+      if (c.x_f)
+        FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.pad, c.x.f(), OUT_STORE, 0, s));
+      else if (c.wino_f)
         FR_TRY(conv_wino(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wu.f(), w + c.b_off, c.Cout, c.x.f(), OUT_STORE, 0, s));
       else
         FR_TRY(conv_igemm(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wf.f(), w + c.b_off, c.Cout, c.k, c.pad,
@@ -898,7 +937,9 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
-      if (c.wino_d)
+      if (c.x_d)
+        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k - 1 - c.pad, gin, gmode, fl, s));
+      else if (c.wino_d)
         FR_TRY(conv_wino(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wud.f(), nullptr, c.Cin, gin, gmode, fl, s));
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,

@@ -1,0 +1,173 @@
+"""Split-bf16 operand form of the 3x3 convolution (csrc/convx.hip, option "split_bf16"): fp32 tensors in and out, every
+product formed from six exact bf16 x bf16 partial products on the bf16 matrix cores.  The claim under test: it is an fp32
+convolution -- against the CPU oracle (fp64 accumulation) its error is within the tolerance of the fp32 matrix-core kernel
+(|a-b| <= 1e-4 max(1,|b|)) AND no larger than that kernel's own error on the same inputs (factor 2 on the
+root-mean-square error, measured here for both forms)."""
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(F, a):
+    return F.DeviceTensor.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _option(F, name, value=None):
+    import ctypes as C
+    if value is None:
+        v = C.c_int(0)
+        F._lib.call("frcnn_get_option", name.encode(), C.byref(v))
+        return v.value
+    F._lib.call("frcnn_set_option", name.encode(), int(value))
+
+
+@pytest.fixture
+def both_forms(F):
+    """-> run(fn): (result with the split form, result with the fp32 matrix-core kernel)."""
+    before = _option(F, "split_bf16")
+
+    def run(fn):
+        _option(F, "split_bf16", 1)
+        a = fn()
+        _option(F, "split_bf16", 0)
+        b = fn()
+        _option(F, "split_bf16", 1)
+        return a, b
+    yield run
+    _option(F, "split_bf16", before)
+
+
+def _rms(a, want):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - want) ** 2)))
+
+
+SHAPES = [
+    # C, H, W, O, pad      (C % 16 == 0 and O % 128 == 0: the shapes the split form takes)
+    (64, 57, 100, 128, 1),      # b2 widths on a 57x100 map: ragged 5 x 25 tiles
+    (128, 29, 50, 256, 1),      # split-K slabs
+    (256, 38, 63, 512, 1),      # vgg_large widths
+    (16, 9, 11, 128, 1),        # one chunk, a map smaller than a tile
+    (48, 31, 45, 128, 0),       # valid convolution (anchor-net geometry)
+    (384, 29, 50, 256, 0),      # the 3x3 anchor net on the last map
+]
+
+
+@pytest.mark.parametrize("C_,H,W,O_,pad", SHAPES)
+def test_forward_is_an_fp32_convolution(F, O, both_forms, C_, H, W, O_, pad):
+    rng = np.random.RandomState(C_ + H)
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, 3, 3) * np.sqrt(2.0 / (9 * O_))).astype(np.float32)
+    b = rng.randn(O_).astype(np.float32)
+    want = O.conv2d_fwd(x, w, b, pad)
+    dx, dw, db = _dev(F, x), _dev(F, w), _dev(F, b)
+
+    def fn():
+        out = F.DeviceTensor.empty(want.shape)
+        F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), F.ptr(db), O_, 3, pad, F.ptr(out),
+                    F.stream_ptr())
+        return out.numpy()
+    split, direct = both_forms(fn)
+    assert not np.array_equal(split, direct), "the option did not switch the kernel"
+    assert_close(split, want, 1e-4, "split-bf16 conv fwd")
+    es, ed = _rms(split, want), _rms(direct, want)
+    assert es <= 2.0 * ed + 1e-9, (es, ed)
+
+
+def test_wide_dynamic_range(F, O, both_forms):
+    """Magnitudes spread over ~12 decades (log-normal): the three-way split keeps 24 significand bits of every operand
+    whatever its exponent, so the error stays that of an fp32 product."""
+    rng = np.random.RandomState(3)
+    C_, H, W, O_, pad = 64, 23, 37, 128, 1
+    x = (rng.randn(C_, H, W) * np.exp(3 * rng.randn(C_, H, W))).astype(np.float32)
+    w = (rng.randn(O_, C_, 3, 3) * np.exp(2 * rng.randn(O_, C_, 3, 3)) * 0.01).astype(np.float32)
+    want = O.conv2d_fwd(x, w, np.zeros(O_, np.float32), pad)
+    dx, dw = _dev(F, x), _dev(F, w)
+
+    def fn():
+        out = F.DeviceTensor.empty(want.shape)
+        F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), None, O_, 3, pad, F.ptr(out), F.stream_ptr())
+        return out.numpy()
+    split, direct = both_forms(fn)
+    # error relative to the sum of magnitudes (the natural scale of a dot product's rounding error)
+    mag = O.conv2d_fwd(np.abs(x), np.abs(w), np.zeros(O_, np.float32), pad)
+    rs = np.abs(split - want) / mag
+    rd = np.abs(direct - want) / mag
+    print("max error / sum of magnitudes: split %.3e  fp32 MFMA %.3e" % (rs.max(), rd.max()))
+    assert rs.max() <= 4e-6, rs.max()
+    assert rs.max() <= 2.0 * rd.max() + 1e-9, (rs.max(), rd.max())
+
+
+def test_fused_activation_of_the_producing_layer(F, O, both_forms):
+    rng = np.random.RandomState(1)
+    C_, H, W, O_, pad = 32, 21, 34, 128, 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, 3, 3) * 0.1).astype(np.float32)
+    b = rng.randn(O_).astype(np.float32)
+    a = np.float32(0.25)
+    scale = (rng.rand(C_) > 0.4).astype(np.float32)
+    for slope, sc in ((a, scale), (a, None), (None, scale)):
+        act = x if slope is None else np.where(x > 0, x, slope * x)
+        if sc is not None:
+            act = act * sc[:, None, None]
+        want = O.conv2d_fwd(act.astype(np.float32), w, b, pad)
+        out = F.DeviceTensor.empty(want.shape)
+        dx, dw, db = _dev(F, x), _dev(F, w), _dev(F, b)
+        da = _dev(F, [slope]) if slope is not None else None
+        ds = _dev(F, sc) if sc is not None else None
+        F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, F.ptr(da) if da else None, F.ptr(ds) if ds else None,
+                    F.ptr(dw), F.ptr(db), O_, 3, pad, F.ptr(out), F.stream_ptr())
+        assert_close(out.numpy(), want, 1e-4, "split-bf16 conv fwd + act")
+
+
+@pytest.mark.parametrize("C_,H,W,O_,pad", [(128, 57, 100, 64, 1), (256, 38, 63, 512, 1), (128, 31, 45, 48, 0)])
+def test_input_gradient(F, O, both_forms, C_, H, W, O_, pad):
+    """updateGradInput: M = C input channels (a multiple of 128), K = O filters (a multiple of 16)."""
+    rng = np.random.RandomState(C_ * 7 + O_)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    g = rng.randn(O_, Ho, Wo).astype(np.float32)
+    w = (rng.randn(O_, C_, 3, 3) * np.sqrt(2.0 / (9 * O_))).astype(np.float32)
+    want = O.conv2d_bwd_input(g, w, pad, H, W)
+    dg, dw = _dev(F, g), _dev(F, w)
+
+    def fn():
+        gin = F.DeviceTensor.empty((C_, H, W))
+        F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, 3, pad, F.ptr(gin), 0, F.stream_ptr())
+        first = gin.numpy()
+        F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, 3, pad, F.ptr(gin), 1, F.stream_ptr())
+        return first, gin.numpy()
+    (split, split2), (direct, _) = both_forms(fn)
+    assert not np.array_equal(split, direct)
+    assert_close(split, want, 1e-4, "split-bf16 conv dgrad")
+    assert_close(split2, 2 * want, 2e-4, "split-bf16 conv dgrad accumulate")
+    assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
+
+
+def test_exactness_properties_at_full_size(F):
+    """b2c2 at the benchmarked size (128 -> 128 @ 225x400), properties that need no oracle: the split of a value is exact
+    (h + m + l == x), so a delta image returns the filter taps BIT FOR BIT and conv(2x) == 2 conv(x) exactly."""
+    rng = np.random.RandomState(0)
+    C_, H, W, O_ = 128, 225, 400, 128
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, 3, 3) * 0.05).astype(np.float32)
+    dw = _dev(F, w)
+    o1 = F.DeviceTensor.empty((O_, H, W)); o2 = F.DeviceTensor.empty((O_, H, W))
+    dx1, dx2 = _dev(F, x), _dev(F, 2 * x)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx1), C_, H, W, None, None, F.ptr(dw), None, O_, 3, 1, F.ptr(o1), F.stream_ptr())
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dx2), C_, H, W, None, None, F.ptr(dw), None, O_, 3, 1, F.ptr(o2), F.stream_ptr())
+    assert np.array_equal(o2.numpy(), 2 * o1.numpy())
+    d = np.zeros((C_, H, W), np.float32); d[5, 100, 200] = 1.0; d[77, 224, 399] = 1.0; d[100, 0, 0] = -2.0
+    dd = _dev(F, d)
+    F._lib.call("frcnn_conv2d_forward", F.ptr(dd), C_, H, W, None, None, F.ptr(dw), None, O_, 3, 1, F.ptr(o1), F.stream_ptr())
+    r = o1.numpy()
+    for ky in range(3):
+        for kx in range(3):
+            assert np.array_equal(r[:, 100 + 1 - ky, 200 + 1 - kx], w[:, 5, ky, kx])
+            if ky >= 1 and kx >= 1:
+                assert np.array_equal(r[:, 224 + 1 - ky, 399 + 1 - kx], w[:, 77, ky, kx])
+            if ky <= 1 and kx <= 1:
+                assert np.array_equal(r[:, 0 + 1 - ky, 0 + 1 - kx], -2 * w[:, 100, ky, kx])
+    r[:, 99:102, 199:202] = 0; r[:, 223:225, 398:400] = 0; r[:, 0:2, 0:2] = 0
+    assert not r.any()
