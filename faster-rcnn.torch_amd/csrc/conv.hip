@@ -1112,7 +1112,20 @@ static void wgrad_plan(WgradArgs& a, int k) {
   if (const char* e = getenv("FRCNN_WG_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }
 
+int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s) {
+  const long total = (long)taps * OC;
+  const int rgrid = (int)std::min<long>(cdivl(total, 64), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slab, nSplit, taps, OC, gw);
+  return FRCNN_OK;
+}
+
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad) {
+  if (k == 3 && Cin % 64 == 0 && O % 64 == 0) {   // either form may run (option split_bf16): room for both
+    WgradArgs b;
+    b.Cin = Cin; b.H = H; b.W = W; b.O = O; b.pad = pad; b.Ho = H + 2 * pad - k + 1; b.Wo = W + 2 * pad - k + 1;
+    wgrad_plan(b, k);
+    return std::max((size_t)b.nSplit * k * k * O * Cin * 4 + 256, conv_wgradx_workspace_bytes(Cin, H, W, O, pad));
+  }
   WgradArgs a;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
@@ -1157,6 +1170,7 @@ int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
+  if (conv_wgradx_eligible(Cin, O, k)) return conv_wgradx(in, Cin, H, W, in_slope, in_scale, g, O, pad, gw, ws, ws_bytes, s);
   FR_CHECK((long)Cin * H * W < (1L << 31) && (long)O * a.Ho * a.Wo < (1L << 31), "conv_wgrad: tensor too large for 32-bit offsets");
   g_wgrad_first_ok = (in_slope == nullptr && in_scale == nullptr);
   wgrad_plan(a, k);

@@ -63,6 +63,14 @@ int conv_x3_pack(const float* w, int O, int C, int mode, void* dst, hipStream_t 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0);
 
+// weight gradient in the same split-bf16 form (wgradx.hip): k == 3, Cin % 64 == 0, O % 64 == 0; conv_wgrad routes to it
+bool conv_wgradx_eligible(int Cin, int O, int k);
+size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad);
+int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s);
+// gw[o][c][tap] += sum_s slab[s][tap][o][c]   (the fold shared by the weight-gradient kernels)
+int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s);
+
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (split-K slabs in `ws`, folded in a fixed order)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);

@@ -171,3 +171,45 @@ def test_exactness_properties_at_full_size(F):
                 assert np.array_equal(r[:, 0 + 1 - ky, 0 + 1 - kx], -2 * w[:, 100, ky, kx])
     r[:, 99:102, 199:202] = 0; r[:, 223:225, 398:400] = 0; r[:, 0:2, 0:2] = 0
     assert not r.any()
+
+
+@pytest.mark.parametrize("C_,H,W,O_,pad", [(64, 57, 100, 128, 1), (128, 29, 50, 64, 1), (256, 38, 63, 512, 1), (64, 9, 11, 64, 1),
+                                            (64, 31, 45, 64, 0)])
+def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
+    """accGradParameters (csrc/wgradx.hip): both operands split while they are staged, fragments by transpose reads."""
+    rng = np.random.RandomState(C_ * 13 + O_)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = rng.randn(C_, H, W).astype(np.float32)
+    g = (rng.randn(O_, Ho, Wo) / np.sqrt(Ho * Wo)).astype(np.float32)
+    gw_want, gb_want = O.conv2d_bwd_weight(x, g, 3, 3, pad)
+    dx, dg = _dev(F, x), _dev(F, g)
+
+    def fn():
+        gw = F.DeviceTensor.zeros((O_, C_, 3, 3)); gb = F.DeviceTensor.zeros((O_,))
+        F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, None, None, F.ptr(dg), O_, 3, pad, F.ptr(gw), F.ptr(gb),
+                    F.stream_ptr())
+        first = gw.numpy()
+        F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, None, None, F.ptr(dg), O_, 3, pad, F.ptr(gw), F.ptr(gb),
+                    F.stream_ptr())
+        return first, gw.numpy()
+    (split, split2), (direct, _) = both_forms(fn)
+    assert not np.array_equal(split, direct), "the option did not switch the kernel"
+    assert_close(split, gw_want, 1e-4, "split-bf16 conv wgrad")
+    assert_close(split2, 2 * gw_want, 2e-4, "split-bf16 conv wgrad accumulates")
+    assert _rms(split, gw_want) <= 2.0 * _rms(direct, gw_want) + 1e-9
+
+
+def test_weight_gradient_with_fused_activation(F, O):
+    rng = np.random.RandomState(2)
+    C_, H, W, O_, pad = 64, 21, 34, 64, 1
+    x = rng.randn(C_, H, W).astype(np.float32)
+    g = (rng.randn(O_, H, W) * 0.05).astype(np.float32)
+    a = np.float32(0.25)
+    scale = (rng.rand(C_) > 0.4).astype(np.float32)
+    act = (np.where(x > 0, x, a * x) * scale[:, None, None]).astype(np.float32)
+    gw_want, _ = O.conv2d_bwd_weight(act, g, 3, 3, pad)
+    gw = F.DeviceTensor.zeros((O_, C_, 3, 3)); gb = F.DeviceTensor.zeros((O_,))
+    dx, dg, da, ds = _dev(F, x), _dev(F, g), _dev(F, [a]), _dev(F, scale)
+    F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds), F.ptr(dg), O_, 3, pad, F.ptr(gw),
+                F.ptr(gb), F.stream_ptr())
+    assert_close(gw.numpy(), gw_want, 1e-4, "split-bf16 conv wgrad + act")
