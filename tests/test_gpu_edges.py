@@ -50,7 +50,10 @@ def test_odd_image_sizes(F, O, setup, H, W):
         class _NoScalars(object):   # the PReLU slope gradients are single numbers summed with cancellation:
             param_table = [t for t in nat.param_table if t[1] > 1]   # one re-routed element moves them by percents
         _compare_gradient(_NoScalars, g, g_want, lo=0, hi=nat.pnet_params, tol_l2=1e-2, elementwise=False)
-        _compare_gradient(nat, g, g_want, lo=3321095, hi=nat.pnet_params)   # anchor nets: above every pooling decision
+        # anchor nets: above every pooling decision; a PReLU sign decision of one hidden unit (256 per anchor net) within
+        # rounding of zero may still differ -- seen for 97x211: unit 158 of the 5x5 net, which carries the whole excess
+        # (3.2e-3 of the squared error against 2e-11 in every other row)
+        _compare_gradient(nat, g, g_want, lo=3321095, hi=nat.pnet_params, flip_rows=(256, 2))
     finally:
         pnet.drop_masks = None
 
