@@ -176,20 +176,12 @@ struct CxArgs {
   const void* wp;         // packed stages [mTile][chunk][tap][CX_ASTAGE]
   const float* bias;      // [M] or null
   float* out;             // [M][Ho][Wo]
-  float* ws;              // partial tiles [worker][2][64 x 256] (stream-K fix-up)
-  int* cnt;               // arrival counters [tile], all zero between launches
   int Cin, H, W, M, Ho, Wo, pad;
   int TH, TW, tilesX, tilesY, mTiles;
-  int nChunks;
-  int out_mode;           // 0 store, 1 add
+  int nChunks, splitK, chunksPerSplit;
+  int out_mode;           // 0 store, 1 add, 3 split-K slab
 };
 
-// Work decomposition ("stream-K"): the launch is a fixed set of workers (two per CU), the work is the list of
-// (tile, chunk) units in tile-major order, and worker v takes the contiguous units [v U / W, (v+1) U / W) -- every worker
-// the same amount whatever the number of tiles, instead of rounds of whole tiles whose last one leaves CUs idle.  A tile
-// whose chunks are shared by several workers is completed by the LAST of them to arrive (an arrival counter per tile, no
-// waiting): the others leave their accumulators in the workspace, the last one adds them up in worker order (the result
-// does not depend on who arrives last) and runs the epilogue.
 template <bool SLOPE, bool SCALE>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,288 +189,232 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, li = lane & 31;
-  char* const As = smem;
-  char* const Bs = smem + 3 * CX_ASTAGE;
-  int* const sflag = reinterpret_cast<int*>(smem + CX_LDS);
 
-  // XCD-aware worker order (see conv.hip): consecutive workers -- consecutive tiles, the M tiles of one pixel tile first --
-  // run on one XCD and share its L2
-  const int Wk = gridDim.x;
+  // XCD-aware order (see conv.hip): consecutive virtual indices of one XCD are the M tiles of one pixel tile
+  const int nT = p.tilesX * p.tilesY;
   int v;
   {
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int q = Wk >> 3, r = Wk & 7;
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
     v = xcd * q + min(xcd, r) + idx;
   }
-  const int nT = p.tilesX * p.tilesY, nC = p.nChunks;
-  const long U = (long)nT * p.mTiles * nC;
-  auto bnd = [&](int w) { return (int)(((long)w * U) / Wk); };
-  auto worker_of = [&](int x) {
-    int w = (int)(((long)x * Wk) / U);
-    while (bnd(w + 1) <= x) ++w;
-    while (bnd(w) > x) --w;
-    return w;
-  };
+  const int mt_id = v % p.mTiles;
+  v /= p.mTiles;
+  const int nt_id = v % nT;
+  const int split = v / nT;
+  const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
+  const int m0 = mt_id * CX_BM;
   const int PW = p.TW + 2, plane = (p.TH + 2) * PW;
   const int NT = p.TH * p.TW;
   const int HW = p.H * p.W;
   const size_t hw_bytes = (size_t)HW * 4;
-  const long HoWo = (long)p.Ho * p.Wo;
-  const float slope = SLOPE ? *p.in_slope : 1.f;
-  const unsigned aoff = (unsigned)((h * CX_BM + wm * 64 + li) * 16);
-  unsigned boff[2];
-  int q_ty[2], q_tx[2];
-  bool q_in[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    int q = wn * 64 + nt * 32 + li;
-    q_in[nt] = q < NT;
-    q = q < NT ? q : NT - 1;
-    q_ty[nt] = q / p.TW; q_tx[nt] = q - q_ty[nt] * p.TW;
-    boff[nt] = (unsigned)((h * CX_PP + q_ty[nt] * PW + q_tx[nt]) * 16);
-  }
-  // this thread's two staging items (half g, patch position): tile-independent part
-  int it_r[2], it_c[2], gsel[2];
-  bool it_valid[2];
-  unsigned sdst[2];
+
+  // ---- this thread's two staging items: (half g, patch position): 8 channels each
+  unsigned gofs[2];      // byte offset inside the chunk's first channel plane (includes the 8 g channels)
+  bool gok[2];
+  unsigned sdst[2];      // LDS byte offset of the item's 16-byte entry inside plane 0 of a B buffer
+  int gsel[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int e = tid + 256 * it;
     const int g = e >= plane ? 1 : 0;
     const int pos = e - g * plane;
-    it_r[it] = pos / PW; it_c[it] = pos - it_r[it] * PW;
-    it_valid[it] = e < 2 * plane;
-    sdst[it] = it_valid[it] ? (unsigned)((g * CX_PP + pos) * 16) : 0xFFFFFFFFu;
+    const int r = pos / PW, col = pos - r * PW;
+    const int gy = ty0 - p.pad + r, gx = tx0 - p.pad + col;
+    const bool valid = e < 2 * plane;
+    gok[it] = valid && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    gofs[it] = (gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u) + (unsigned)g * 8u * (unsigned)hw_bytes;
+    sdst[it] = valid ? (unsigned)((g * CX_PP + pos) * 16) : 0xFFFFFFFFu;
     gsel[it] = g;
   }
+  const float slope = SLOPE ? *p.in_slope : 1.f;
 
-  int u = bnd(v);
-  const int u_end = bnd(v + 1);
-  bool first_seg = true;
-  while (u < u_end) {
-    const int tile = u / nC;
-    const int cbeg = u - tile * nC;
-    const int cend = min(nC, cbeg + (u_end - u));
-    const int mt_id = tile % p.mTiles, nt_id = tile / p.mTiles;
-    const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
-    const int m0 = mt_id * CX_BM;
-    const int nStages = (cend - cbeg) * 9;
+  // ---- lane offsets of the MFMA operand reads
+  const unsigned aoff = (unsigned)((h * CX_BM + wm * 64 + li) * 16);
+  unsigned boff[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    int q = wn * 64 + nt * 32 + li;
+    q = q < NT ? q : NT - 1;
+    const int ty = q / p.TW, tx = q - ty * p.TW;
+    boff[nt] = (unsigned)((h * CX_PP + ty * PW + tx) * 16);
+  }
 
-    unsigned gofs[2];      // byte offset inside the chunk's first channel plane (includes the 8 g channels)
-    bool gok[2];
+  f32x16 acc[2][2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int gy = ty0 - p.pad + it_r[it], gx = tx0 - p.pad + it_c[it];
-      gok[it] = it_valid[it] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      gofs[it] = (gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u) + (unsigned)gsel[it] * 8u * (unsigned)hw_bytes;
-    }
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int cbeg = split * p.chunksPerSplit;
+  const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
+  const int nStages = (cend - cbeg) * 9;
 
-    // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
-    const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * nC + cbeg) * 9 * CX_ASTAGE +
-                             (size_t)wave * 3072 + lane * 16;
-    auto dma_stage = [&](int stage, int buf) {
-      const char* src = wsrc + (size_t)stage * CX_ASTAGE;
-      char* dst = As + buf * CX_ASTAGE + wave * 3072;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-    };
+  char* const As = smem;
+  char* const Bs = smem + 3 * CX_ASTAGE;
 
-    float vb[2][8];
-    int patch_chunk = 0;
-    auto load_patch = [&](int chunk) {
-      const char* srcB = reinterpret_cast<const char*>(p.in) + (size_t)chunk * CX_CH * hw_bytes;
-      patch_chunk = chunk;
+  // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
+  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * 9 * CX_ASTAGE +
+                           (size_t)wave * 3072 + lane * 16;
+  auto dma_stage = [&](int stage, int buf) {
+    const char* src = wsrc + (size_t)stage * CX_ASTAGE;
+    char* dst = As + buf * CX_ASTAGE + wave * 3072;
 #pragma unroll
-      for (int it = 0; it < 2; ++it)
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+
+  float vb[2][8];
+  float sc[2][8];
+  auto load_patch = [&](int chunk) {
+    const char* srcB = reinterpret_cast<const char*>(p.in) + (size_t)chunk * CX_CH * hw_bytes;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vb[it][j] = *reinterpret_cast<const float*>(srcB + j * hw_bytes + gofs[it]);
-    };
-    auto store_patch = [&](char* Bb) {
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[it][j] = *reinterpret_cast<const float*>(srcB + j * hw_bytes + gofs[it]);
+    if (SCALE) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        float sc[8];
-        if (SCALE) {   // (L1 / L2 hits; fetched here rather than held in registers since the patch was requested)
-          const float4* sp = reinterpret_cast<const float4*>(p.in_scale + patch_chunk * CX_CH + 8 * gsel[it]);
-          const float4 s0 = sp[0], s1 = sp[1];
-          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-        }
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float t = vb[it][j];
-          if (SLOPE) t = t > 0.f ? t : slope * t;
-          if (SCALE) t *= sc[j];
-          x[j] = gok[it] ? t : 0.f;
-        }
-        uint4 H, Mi, L;
-        split8(x, H, Mi, L);
-        if (sdst[it] != 0xFFFFFFFFu) {
-          char* d = Bb + sdst[it];
-          *reinterpret_cast<uint4*>(d) = H;
-          *reinterpret_cast<uint4*>(d + 2 * CX_PP * 16) = Mi;
-          *reinterpret_cast<uint4*>(d + 4 * CX_PP * 16) = L;
-        }
-      }
-    };
-
-    // one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + 2 B)), 24 MFMAs
-    auto compute = [&](const char* Ab, const char* Bb, int tapoff) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * CX_BM + mt * 32) * 16);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
-      }
-      // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
-    };
-
-    // ---- prologue: every wave is done with the previous segment's LDS; patch of the first chunk, A stages 0 and 1
-    __syncthreads();
-    load_patch(cbeg);
-    dma_stage(0, 0);
-    if (nStages > 1) dma_stage(1, 1);
-    store_patch(Bs);
-    bool more = false;
-
-    int stage = 0;
-    for (int chunk = cbeg; chunk < cend; ++chunk) {
-      const char* Bcur = Bs + ((chunk - cbeg) & 1) * CX_BBUF;
-      char* Bnext = Bs + (((chunk - cbeg) & 1) ^ 1) * CX_BBUF;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap, ++stage) {
-        // stage's A image has landed in every wave's part (DMA retires in order: at most the next stage's three
-        // instructions -- and, right after a chunk's first tap, the patch loads issued behind them -- may be in flight)
-        if (stage + 1 >= nStages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        __syncthreads();
-        if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2) % 3);
-        if (tap == 0) {   // the next chunk's patch: requested now, split and written to the other buffer at tap 4
-          more = chunk + 1 < cend;
-          if (more) load_patch(chunk + 1);
-        }
-        const int ky = tap / 3, kx = tap - ky * 3;
-        compute(As + (tap % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
-        if (tap == 4 && more) store_patch(Bnext);
+        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + chunk * CX_CH + 8 * gsel[it]);
+        const float4 s0 = sp[0], s1 = sp[1];
+        sc[it][0] = s0.x; sc[it][1] = s0.y; sc[it][2] = s0.z; sc[it][3] = s0.w;
+        sc[it][4] = s1.x; sc[it][5] = s1.y; sc[it][6] = s1.z; sc[it][7] = s1.w;
       }
     }
+  };
+  auto store_patch = [&](char* Bb) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = vb[it][j];
+        if (SLOPE) t = t > 0.f ? t : slope * t;
+        if (SCALE) t *= sc[it][j];
+        x[j] = gok[it] ? t : 0.f;
+      }
+      uint4 H, Mi, L;
+      split8(x, H, Mi, L);
+      if (sdst[it] != 0xFFFFFFFFu) {
+        char* d = Bb + sdst[it];
+        *reinterpret_cast<uint4*>(d) = H;
+        *reinterpret_cast<uint4*>(d + 2 * CX_PP * 16) = Mi;
+        *reinterpret_cast<uint4*>(d + 4 * CX_PP * 16) = L;
+      }
+    }
+  };
 
-    // ---- a tile shared with other workers: leave the partial sums, the last to arrive adds them up
-    bool finish = true;
-    if (cbeg != 0 || cend != nC) {
-      float* mine = p.ws + ((size_t)v * 2 + (first_seg ? 0 : 1)) * (64 * 256);
+  // one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + 2 B)), 24 MFMAs
+  auto compute = [&](const char* Ab, const char* Bb, int tapoff) {
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * CX_BM + mt * 32) * 16);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
+    }
+    // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)   // device-coherent (write-through) stores: no cache-wide release is needed below
-            __hip_atomic_store(mine + ((mt * 2 + nt) * 16 + r) * 256 + tid, acc[mt][nt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... acknowledged before this block counts as arrived
-      __syncthreads();
-      if (tid == 0) {
-        const int wf = worker_of(tile * nC), wl = worker_of(tile * nC + nC - 1);
-        const int old = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old + 1 == wl - wf + 1;
-        if (last) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sflag[0] = last; sflag[1] = wf; sflag[2] = wl;
-      }
-      __syncthreads();
-      finish = sflag[0] != 0;
-      if (finish) {
-        const int wf = sflag[1], wl = sflag[2];
-        // (its own partial is read back with the others: one accumulation order whoever finishes)
-        for (int w = wf; w <= wl; ++w) {
-          const int slot = w == v ? (first_seg ? 0 : 1) : (bnd(w) / nC == tile ? 0 : 1);   // a worker's first segment, or its last
-          const float* src = p.ws + ((size_t)w * 2 + slot) * (64 * 256);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              float x[16];   // sixteen device-coherent loads in flight, then the adds
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                x[r] = __hip_atomic_load(src + ((mt * 2 + nt) * 16 + r) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[mt][nt][r] = w == wf ? x[r] : acc[mt][nt][r] + x[r];
-            }
-        }
-      }
-    }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
+  };
 
-    // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
-    if (finish) {
-      const int mrow0 = m0 + wm * 64 + 4 * h;
+  // ---- prologue: patch of the first chunk, A stages 0 and 1
+  load_patch(cbeg);
+  dma_stage(0, 0);
+  dma_stage(1, 1);
+  store_patch(Bs);
+  bool more = false;
+
+  int stage = 0;
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const char* Bcur = Bs + ((chunk - cbeg) & 1) * CX_BBUF;
+    char* Bnext = Bs + (((chunk - cbeg) & 1) ^ 1) * CX_BBUF;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int oy = ty0 + q_ty[nt], ox = tx0 + q_tx[nt];
-        if (q_in[nt] && oy < p.Ho && ox < p.Wo) {
-          float* col = p.out + (size_t)oy * p.Wo + ox;
+    for (int tap = 0; tap < 9; ++tap, ++stage) {
+      // stage's A image has landed in every wave's part (DMA retires in order: at most the next stage's three
+      // instructions -- and, right after a chunk's first tap, the patch loads issued behind them -- may be in flight)
+      if (stage + 1 >= nStages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __syncthreads();
+      if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2) % 3);
+      if (tap == 0) {   // the next chunk's patch: requested now, split and written to the other buffer at tap 4
+        more = chunk + 1 < cend;
+        if (more) load_patch(chunk + 1);
+      }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      compute(As + (tap % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
+      if (tap == 4 && more) store_patch(Bnext);
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
+  const long HoWo = (long)p.Ho * p.Wo;
+  const bool add_bias = p.bias != nullptr && split == 0;
+  const int mrow0 = m0 + wm * 64 + 4 * h;
+  auto store_tile = [&](auto mode_c) {
+    constexpr int OM = decltype(mode_c)::value;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
+    for (int nt = 0; nt < 2; ++nt) {
+      const int q = wn * 64 + nt * 32 + li;
+      const int ty = q / p.TW, tx = q - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      if (q < NT && oy < p.Ho && ox < p.Wo) {
+        float* col = p.out + (OM == 3 ? (size_t)split * p.M * HoWo : (size_t)0) + (size_t)oy * p.Wo + ox;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-              if (m < p.M) {
-                float val = acc[mt][nt][r];
-                if (p.bias) val += p.bias[m];
-                float* dst = col + (size_t)m * HoWo;
-                if (p.out_mode == 1) *dst += val; else *dst = val;
-              }
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) {
+              float val = acc[mt][nt][r];
+              if (add_bias) val += p.bias[m];
+              float* dst = col + (size_t)m * HoWo;
+              if (OM == 1) *dst += val; else *dst = val;
             }
           }
         }
       }
     }
-    u += cend - cbeg;
-    first_seg = false;
+  };
+  if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
+  else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
+  else store_tile(std::integral_constant<int, 3>{});
+}
+
+// out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
+__global__ void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw, const float* __restrict__ bias,
+                                        float* __restrict__ out, int accumulate) {
+  const long total = (long)M * hw;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    float v = bias ? bias[t / hw] : 0.f;
+    for (int s = 0; s < nSplit; ++s) v += slab[(size_t)s * total + t];
+    if (accumulate) out[t] += v; else out[t] = v;
   }
 }
 
-// library-owned stream-K workspace (grown outside the steady state), one per stream that may run these launches
-// concurrently (slot 0 = caller's stream, 1 = side stream, 2.. = anchor-net streams)
-struct X3Ws { float* ws = nullptr; size_t ws_bytes = 0; int* cnt = nullptr; size_t cnt_n = 0; };
-static X3Ws g_x3_ws[8];
-static int x3_workspace(int slot, int workers, size_t tiles, float** ws, int** cnt) {
-  X3Ws& w = g_x3_ws[slot];
-  const size_t need = (size_t)workers * 2 * 64 * 256 * 4;
-  if (need > w.ws_bytes) {
-    if (w.ws) FR_HIP(hipFree(w.ws));
-    w.ws = nullptr; w.ws_bytes = 0;
-    FR_HIP(hipMalloc((void**)&w.ws, need));
-    w.ws_bytes = need;
+static void* g_x3_ws[8] = {};
+static size_t g_x3_ws_bytes[8] = {};
+static int x3_workspace(size_t need, float** out, int slot) {
+  if (need > g_x3_ws_bytes[slot]) {
+    if (g_x3_ws[slot]) FR_HIP(hipFree(g_x3_ws[slot]));
+    g_x3_ws[slot] = nullptr; g_x3_ws_bytes[slot] = 0;
+    FR_HIP(hipMalloc(&g_x3_ws[slot], need));
+    g_x3_ws_bytes[slot] = need;
   }
-  if (tiles > w.cnt_n) {
-    if (w.cnt) FR_HIP(hipFree(w.cnt));
-    w.cnt = nullptr; w.cnt_n = 0;
-    const size_t n = std::max<size_t>(tiles, 4096);
-    FR_HIP(hipMalloc((void**)&w.cnt, n * 4));
-    FR_HIP(hipMemset(w.cnt, 0, n * 4));   // (every launch leaves its counters at zero again)
-    w.cnt_n = n;
-  }
-  *ws = w.ws; *cnt = w.cnt;
+  *out = (float*)g_x3_ws[slot];
   return FRCNN_OK;
 }
 
@@ -499,15 +435,16 @@ static void x3_choose_tile(int Ho, int Wo, int* TH, int* TW) {
 }
 
 template <bool SLOPE, bool SCALE>
-static int launch_x3(CxArgs& a, int workers, double flops, hipStream_t s) {
+static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<SLOPE, SCALE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(KC_CONV_IGEMM_K3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(workers), dim3(256), CX_LDS + 64, a);
+  FR_LAUNCH(KC_CONV_IGEMM_K3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -525,18 +462,32 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
   a.mTiles = M / CX_BM;
   a.nChunks = Cin / CX_CH;
+  const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
+  // split K until one round of blocks fills the 2 x 256 resident slots, keeping >= 4 chunks (36 stages) per split
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, 512 / blocks), 16), std::max(1, a.nChunks / 4));
+  if (const char* e = getenv("FRCNN_X3_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
+  a.chunksPerSplit = cdiv(a.nChunks, splitK);
+  a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
-  const long tiles = (long)a.tilesX * a.tilesY * a.mTiles, units = tiles * a.nChunks;
-  FR_CHECK(units < (1L << 30), "conv_x3: too many work units");
-  // two workers per CU, each with at least two chunks of work
-  static const int x3_workers = getenv("FRCNN_X3_WORKERS") ? atoi(getenv("FRCNN_X3_WORKERS")) : 512;
-  // ... and no tile shared by more than ~four of them (every sharer writes or reads a 64 KB partial tile)
-  const long min_units = std::max(2, cdiv(a.nChunks, 4));
-  const int workers = (int)std::max<long>(1, std::min<long>(x3_workers, units / min_units));
-  FR_TRY(x3_workspace(ws_slot & 7, workers, (size_t)tiles, &a.ws, &a.cnt));
+  bool slab = false;
+  if (a.splitK > 1) {
+    float* ws = nullptr;
+    FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
+    a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
+  }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * 9 * (double)a.Ho * a.Wo;
-  if (in_slope) return in_scale ? launch_x3<true, true>(a, workers, algo_flops, s) : launch_x3<true, false>(a, workers, algo_flops, s);
-  return in_scale ? launch_x3<false, true>(a, workers, algo_flops, s) : launch_x3<false, false>(a, workers, algo_flops, s);
+  int rc;
+  if (in_slope) rc = in_scale ? launch_x3<true, true>(a, algo_flops, s) : launch_x3<true, false>(a, algo_flops, s);
+  else rc = in_scale ? launch_x3<false, true>(a, algo_flops, s) : launch_x3<false, false>(a, algo_flops, s);
+  FR_TRY(rc);
+  if (slab) {
+    long total = (long)M * a.Ho * a.Wo;
+    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
+    FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel, dim3(grid), dim3(256), 0,
+              (const float*)a.out, a.splitK, M, (long)a.Ho * a.Wo, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    FR_LAUNCH_CHECK();
+  }
+  return FRCNN_OK;
 }
 
 }  // namespace frcnn

@@ -14,7 +14,7 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, pad)
     "b1c1": (3, 450, 800, 64, 3, 1), "b2c1": (64, 225, 400, 128, 3, 1), "b2c2": (128, 225, 400, 128, 3, 1),
     "b3c1": (128, 113, 200, 256, 3, 1), "b3c2": (256, 113, 200, 256, 3, 1), "b4c1": (256, 57, 100, 384, 3, 1),
     "b4c2": (384, 57, 100, 384, 3, 1), "a1": (256, 57, 100, 256, 3, 0), "a2": (384, 29, 50, 256, 3, 0),
-    "a3": (384, 29, 50, 256, 5, 0), "a4": (384, 29, 50, 256, 7, 0), "a1x": (256, 55, 98, 18, 1, 0),
+    "bigk": (2048, 57, 100, 384, 3, 1), "a3": (384, 29, 50, 256, 5, 0), "a4": (384, 29, 50, 256, 7, 0), "a1x": (256, 55, 98, 18, 1, 0),
 }
 
 
