@@ -7,9 +7,11 @@ step, data-parallel over N GPUs of one node (gradient all-reduce on RCCL).
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying
-  "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_igemm 3x3: forward + input-gradient
-                    of every 3x3 convolution) = algorithmic FLOPs of its launches / their HIP-event
-                    durations, measured live over the timed steps, vs the fp32-MFMA peak;
+  "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_x3: forward + input-gradient of the 3x3
+                    convolutions in the split-bf16 operand form; conv_igemm 3x3, fp32 MFMA, with the option off)
+                    = algorithmic FLOPs of its launches / their HIP-event durations, measured live over the timed
+                    steps, vs the matrix-core peak FOR THAT FORMULATION: the bf16 dense peak / 6 (six bf16 MFMA
+                    partial products per fp32 product); the fp32-MFMA peak for conv_igemm;
   "cpu_baseline" -- the CPU restatement of the reference (oracle/, "port") timed on this host, N=1 only:
                     the training step on the benchmarked 3x450x800 frame with all cores (1 warm-up + median
                     of 3) and with one thread on a 1/16-area frame (BASELINE.md section 4);
@@ -33,6 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # ... v_mfma_f32_32x32x16_bf16: 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (dense)
+SPLIT_PRODUCTS = 6              # bf16 x bf16 partial products per fp32 product in the split-operand kernels (convx.hip)
+CONV_CLASSES = ("conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "conv_x3", "conv_wgradx")
 FULL_H, FULL_W = 450, 800
 
 
@@ -339,7 +344,8 @@ def main():
     # Live HIP-event bracketing puts two event packets around every bracketed launch of the dependent chain (~3 % of
     # the step when every step is bracketed): the conv classes are bracketed on every 4th step of the timed region
     # (a sample of the same launches), --profile-all brackets every class on every step.
-    mask = 0x3FF if args.profile_all else 0xF
+    conv_mask = sum(1 << F._lib.KC_NAMES.index(n) for n in CONV_CLASSES)
+    mask = (1 << len(F._lib.KC_NAMES)) - 1 if args.profile_all else conv_mask
     every = 1 if args.profile_all else 4
     sampled = 0
     barrier()
@@ -367,7 +373,7 @@ def main():
         step()
         barrier_local = torch.cuda.synchronize
         barrier_local()
-        F._lib.call("frcnn_prof_enable", 0xF)
+        F._lib.call("frcnn_prof_enable", conv_mask)
         for _ in range(3):
             step()
         barrier_local()
@@ -380,9 +386,12 @@ def main():
             if l2[i]:
                 iso_classes[name] = dict(launches_per_step=l2[i] / 3.0, ms_per_step=round(m2[i] / 3.0, 4),
                                          tflops=round((f2[i] / 1e12) / (m2[i] / 1e3), 2) if f2[i] > 0 and m2[i] > 0 else None)
-        if m2[0] > 0:
-            a2 = (f2[0] / 1e12) / (m2[0] / 1e3)
-            iso = dict(achieved=round(a2, 2), frac=round(a2 / FP32_MFMA_PEAK_TFLOPS, 4), avg_launch_ms=round(m2[0] / max(l2[0], 1), 4),
+        split_on = l2[F._lib.KC_NAMES.index("conv_x3")] > 0
+        kdom = F._lib.KC_NAMES.index("conv_x3" if split_on else "conv_igemm_k3")
+        peak_dom = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS
+        if m2[kdom] > 0:
+            a2 = (f2[kdom] / 1e12) / (m2[kdom] / 1e3)
+            iso = dict(achieved=round(a2, 2), frac=round(a2 / peak_dom, 4), avg_launch_ms=round(m2[kdom] / max(l2[kdom], 1), 4),
                        note="same kernel with frcnn_set_option('side_stream', 0): no concurrent weight-gradient launches")
     if native_comm is not None:
         dt = native_comm.gather_max(dt)
@@ -393,13 +402,15 @@ def main():
 
     if rank == 0:
         fwd_flops, train_flops = conv_flops_per_image(model, H, W)
-        k = 0  # conv_igemm_k3
+        split_on = launches[F._lib.KC_NAMES.index("conv_x3")] > 0
+        k = F._lib.KC_NAMES.index("conv_x3" if split_on else "conv_igemm_k3")
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS
         ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_igemm_k3_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("%s_bytes_per_launch" % F._lib.KC_NAMES[k])
             except Exception:
                 traffic = None
         classes = {}
@@ -407,11 +418,15 @@ def main():
             if launches[i]:
                 classes[name] = dict(launches_per_step=launches[i] / sampled, ms_per_step=round(ms[i] / sampled, 4),
                                      tflops=round((fl[i] / 1e12) / (ms[i] / 1e3), 2) if fl[i] > 0 and ms[i] > 0 else None)
-        conv_ms = sum(ms[i] for i in range(4)) / sampled
+        conv_ms = sum(ms[F._lib.KC_NAMES.index(n)] for n in CONV_CLASSES) / sampled
         out = dict(
             metric="images/sec (%s %dx%d fwd+bwd)" % (args.model, W, H), value=round(world * args.steps / dt, 3), unit="images/sec",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            arithmetic=("fp32 tensors, fp32 accumulation; the 3x3 convolutions (forward, input gradient, weight gradient) form every fp32 "
+                        "product from six exact bf16 x bf16 partial products of three-way split operands (24 significand bits, "
+                        "v_mfma_f32_32x32x16_bf16); every other product is a plain fp32 product (v_mfma_f32_32x32x2_f32 / VALU)"
+                        if split_on else "fp32 tensors, fp32 products (v_mfma_f32_32x32x2_f32 / VALU), fp32 accumulation"),
             config=dict(workload=args.model + " %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
                                  "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/%s.lua values" % (W, H, "duplo" if args.model == "vgg_small" else "imagenet"),
                         images_per_gpu_per_step=1,
@@ -421,9 +436,15 @@ def main():
                         conv_kernel_ms_per_step=round(conv_ms, 3), kernel_classes=classes,
                         kernel_classes_serial_pass=iso_classes,
                         last_loss=stats["pcls"][-1] + stats["preg"][-1] if stats["pcls"] else None),
-            roofline=dict(bound="mfma", kernel="conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)",
-                          achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                          frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+            roofline=dict(bound="mfma",
+                          kernel=("conv_x3_kernel (3x3 conv forward + input-gradient, split-bf16 operands: 6 bf16 MFMA partial products "
+                                  "per fp32 product)" if split_on else
+                                  "conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)"),
+                          achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                          frac=round(ach / peak, 4), traffic=traffic,
+                          peak_note=("algorithmic (fp32-product) TFLOP/s against the dense bf16 matrix-core peak 2516.6 / 6 partial "
+                                     "products; executed bf16 MFMA rate = 6 x achieved = %.0f TFLOP/s; the fp32 matrix-core peak is "
+                                     "157.3 TFLOP/s" % (SPLIT_PRODUCTS * ach) if split_on else "fp32 matrix-core peak"),
                           sampled_steps=sampled, launches_per_step=launches[k] / sampled, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libfrcnn_hip.so")
 
 KC_NAMES = ["conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "gemm", "elemwise",
-            "roi", "rpn", "nms", "optim", "image"]
+            "roi", "rpn", "nms", "optim", "image", "conv_x3", "conv_wgradx"]
 
 
 class FrcnnError(RuntimeError):

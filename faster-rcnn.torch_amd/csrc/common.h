@@ -59,6 +59,8 @@ enum KClass {
   KC_NMS,
   KC_OPTIM,
   KC_IMAGE,               // BatchIterator:processImage kernels (image.hip)
+  KC_CONV_X3,             // conv_x3_kernel: 3x3 fwd + dgrad in the split-bf16 operand form (convx.hip) -- the dominant kernel
+  KC_CONV_WGRADX,         // conv_wgradx_kernel (+ its slab fold): 3x3 weight gradient in the same form (wgradx.hip)
   KC_COUNT
 };
 

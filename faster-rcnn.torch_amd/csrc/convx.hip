@@ -444,7 +444,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(KC_CONV_IGEMM_K3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
+  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -39,6 +39,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define WX_GBYTES (3 * 8 * WX_GP * 16)
 #define WX_XBYTES (3 * 8 * WX_XP * 16)
 #define WX_LDS (WX_GBYTES + WX_XBYTES)
+#ifndef WX_TG
+#define WX_TG 3                  // taps whose MFMAs are interleaved
+#endif
 
 bool conv_wgradx_eligible(int Cin, int O, int k) {
   return get_split_bf16() && k == 3 && Cin % 64 == 0 && O % 64 == 0;
@@ -128,17 +131,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
   const int nPix = p.tilesX * p.tilesY;
   for (int t = split; t < nPix; t += p.nSplit) {
     const int oy0 = (t / p.tilesX) * WX_TH, ox0 = (t % p.tilesX) * WX_TW;
-    // ---- gradient tile: 2 items per thread
+    // ---- every global load of the tile first (one memory round trip, 48 values in flight per thread), then the splits:
+    // gradient tile: 2 items per thread; input patch: 4 items (2 channel groups x 2 position slots)
+    float vg[2][8], vp[2][2][8];
+    bool pok[2];
+    const int goy = oy0 + g_ty, gox = ox0 + g_tx;
+    const bool gok = goy < p.Ho && gox < p.Wo;
     {
-      const int goy = oy0 + g_ty, gox = ox0 + g_tx;
-      const bool gok = goy < p.Ho && gox < p.Wo;
       const unsigned gofs = gok ? (unsigned)(goy * p.Wo + gox) * 4u : 0u;
-      float vg[2][8];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const char* gb = reinterpret_cast<const char*>(p.g) + (size_t)(o0 + 8 * (wave + 4 * it)) * g_bytes;
 #pragma unroll
         for (int j = 0; j < 8; ++j) vg[it][j] = *reinterpret_cast<const float*>(gb + j * g_bytes + gofs);
+      }
+      unsigned pofs[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int iy = oy0 - p.pad + p_r[m], ix = ox0 - p.pad + p_c[m];
+        pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        pofs[m] = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+      }
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        const char* ib = reinterpret_cast<const char*>(p.in) + (size_t)(c0 + 8 * (2 * wave + gi)) * in_bytes;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vp[gi][m][j] = *reinterpret_cast<const float*>(ib + j * in_bytes + pofs[m]);
       }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -152,45 +172,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
         *reinterpret_cast<uint4*>(d + 8 * WX_GP * 16) = Mi;
         *reinterpret_cast<uint4*>(d + 16 * WX_GP * 16) = L;
       }
-    }
-    // ---- input patch: 4 items per thread (2 channel groups x 2 position slots), two at a time
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      const int cg = 2 * wave + gi;
-      const char* ib = reinterpret_cast<const char*>(p.in) + (size_t)(c0 + 8 * cg) * in_bytes;
-      float vp[2][8];
-      bool pok[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int iy = oy0 - p.pad + p_r[m], ix = ox0 - p.pad + p_c[m];
-        pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const unsigned pofs = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vp[m][j] = *reinterpret_cast<const float*>(ib + j * in_bytes + pofs);
-      }
-      float sc[8];
-      if (SCALE) {
-        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + c0 + 8 * cg);
-        const float4 s0 = sp[0], s1 = sp[1];
-        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = vp[m][j];
-          if (SLOPE) v = v > 0.f ? v : slope * v;
-          if (SCALE) v *= sc[j];
-          x[j] = pok[m] ? v : 0.f;
+      for (int gi = 0; gi < 2; ++gi) {
+        const int cg = 2 * wave + gi;
+        float sc[8];
+        if (SCALE) {
+          const float4* sp = reinterpret_cast<const float4*>(p.in_scale + c0 + 8 * cg);
+          const float4 s0 = sp[0], s1 = sp[1];
+          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
         }
-        uint4 Hh, Mi, L;
-        wx_split8(x, Hh, Mi, L);
-        if (p_in[m]) {
-          char* d = Xs + (cg * WX_XP + lane + 64 * m) * 16;
-          *reinterpret_cast<uint4*>(d) = Hh;
-          *reinterpret_cast<uint4*>(d + 8 * WX_XP * 16) = Mi;
-          *reinterpret_cast<uint4*>(d + 16 * WX_XP * 16) = L;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = vp[gi][m][j];
+            if (SLOPE) v = v > 0.f ? v : slope * v;
+            if (SCALE) v *= sc[j];
+            x[j] = pok[m] ? v : 0.f;
+          }
+          uint4 Hh, Mi, L;
+          wx_split8(x, Hh, Mi, L);
+          if (p_in[m]) {
+            char* d = Xs + (cg * WX_XP + lane + 64 * m) * 16;
+            *reinterpret_cast<uint4*>(d) = Hh;
+            *reinterpret_cast<uint4*>(d + 8 * WX_XP * 16) = Mi;
+            *reinterpret_cast<uint4*>(d + 16 * WX_XP * 16) = L;
+          }
         }
       }
     }
@@ -202,21 +210,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
         a[pl] = wx_frag(laneA + (pl * 8 * WX_GP + 16 * ks) * 16, laneA + (pl * 8 * WX_GP + 16 * ks + 4) * 16);
+      // taps in groups of up to three, the six partial products of a group interleaved: consecutive MFMAs write
+      // different accumulators (a chain on ONE accumulator issues at its dependent latency, not at the pipe rate)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        bf16x8 b[3];
+      for (int t0 = 0; t0 < 9; t0 += WX_TG) {
+        bf16x8 b[WX_TG][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[pl] = wx_frag(laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx) * 16,
-                          laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx + 4) * 16);
+        for (int i = 0; i < WX_TG; ++i) {
+          const int tap = t0 + i < 9 ? t0 + i : 8;
+          const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[i][pl] = wx_frag(laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx) * 16,
+                               laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx + 4) * 16);
+        }
         // smallest partial products first; plane 0 = h, 1 = m, 2 = l
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[tap], 0, 0, 0);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < WX_TG; ++i)
+            if (t0 + i < 9) acc[t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[i][PB[q]], acc[t0 + i], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -261,10 +275,10 @@ static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) 
   }
   const int grid = a.oTiles * a.cTiles * a.nSplit;
   const double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
-  if (prof_enabled(KC_CONV_WGRAD_K3)) prof_before(KC_CONV_WGRAD_K3, s);
+  if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
   hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), WX_LDS, s, a);
   FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
-  if (prof_enabled(KC_CONV_WGRAD_K3)) prof_after(KC_CONV_WGRAD_K3, flops, bytes, s);
+  if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -50,7 +50,13 @@ int frcnn_device_name(char *buf_host, int len);
  * index order, gathers, 64-bit fixed-point accumulation -- so that two runs on the same inputs are bit-identical.
  * "winograd" (default 0; environment FRCNN_WINO): 3x3 / pad 1 convolutions with enough 16 x 16-pixel blocks run in the
  * Winograd F(2x2, 3x3) form (2.25x fewer multiplications, same result to fp32 rounding); applies to the operator-level
- * entry points at once and to a model from its next (re)shaping on. */
+ * entry points at once and to a model from its next (re)shaping on.
+ * "split_bf16" (default 1; environment FRCNN_SPLIT_BF16): the 3x3 convolutions whose shapes fit (forward and input gradient:
+ * input channels a multiple of 16, filters a multiple of 128; weight gradient: both multiples of 64) run in the split-operand
+ * form: fp32 tensors in and out, fp32 accumulation, every fp32 product formed from six exact bf16 x bf16 partial products of
+ * three-way split operands on the bf16 matrix cores (24 significand bits per operand; against an fp64 reference the error
+ * equals that of the fp32 matrix-core kernels, tests/test_gpu_convx.py).  0 = fp32 matrix-core kernels only.  Applies to the
+ * operator-level entry points at once and to a model from its next (re)shaping on. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 
@@ -84,7 +90,9 @@ int frcnn_add(float *y, const float *x, long long n, void *stream);   /* y:add(x
 #define FRCNN_KC_NMS 8
 #define FRCNN_KC_OPTIM 9
 #define FRCNN_KC_IMAGE 10
-#define FRCNN_KC_COUNT 11
+#define FRCNN_KC_CONV_X3 11      /* 3x3 forward + input gradient, split-bf16 operand form */
+#define FRCNN_KC_CONV_WGRADX 12  /* 3x3 weight gradient, split-bf16 operand form */
+#define FRCNN_KC_COUNT 13
 /* class_mask: bit k set -> every launch of kernel class k is bracketed by two hipEvents on its
  * launch stream (0 = profiling off). */
 int frcnn_prof_enable(int class_mask);

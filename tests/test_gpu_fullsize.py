@@ -24,15 +24,18 @@ def fullsize_inputs(F, cfg, model):
     return anchors, rois, pos, neg, F.synthetic_image(H, W, 0)
 
 
-@pytest.mark.parametrize("winograd", [0, 1])
-def test_fullsize_loss_and_gradient(F, O, winograd):
+@pytest.mark.parametrize("winograd,split", [(0, 1), (1, 1), (0, 0)])
+def test_fullsize_loss_and_gradient(F, O, winograd, split):
     """winograd = 1: the eligible 3x3 layers of the forward pass (b2c1, b2c2, b3c1, b3c2 at this size) in the Winograd
-    F(2x2, 3x3) form (option "winograd") -- same bars."""
+    F(2x2, 3x3) form (option "winograd"); split = 1 (the default): the 3x3 layers whose shapes fit in the split-bf16 operand
+    form (option "split_bf16"), split = 0: fp32 matrix-core kernels only -- same bars for all three."""
     F._lib.call("frcnn_set_option", b"winograd", winograd)
+    F._lib.call("frcnn_set_option", b"split_bf16", split)
     try:
         _fullsize(F, O)
     finally:
         F._lib.call("frcnn_set_option", b"winograd", 0)
+        F._lib.call("frcnn_set_option", b"split_bf16", 1)
 
 
 def _fullsize(F, O):

@@ -38,12 +38,13 @@ def run(kind, name, reps=5):
         else:
             F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O, Ho, Wo, F.ptr(w), Cin, k, pad, F.ptr(gin), 0, s)
     once()
-    F._lib.call("frcnn_prof_enable", 0xF)
+    conv = [i for i, n in enumerate(F._lib.KC_NAMES) if n.startswith("conv_")]
+    F._lib.call("frcnn_prof_enable", sum(1 << i for i in conv))
     for _ in range(reps):
         once()
     F._lib.call("frcnn_prof_enable", 0)
     F._lib.call("frcnn_prof_collect", la, ms, fl, by)
-    t = sum(ms[i] for i in range(4)) / reps
+    t = sum(ms[i] for i in conv) / reps
     flops = 2.0 * O * Cin * k * k * Ho * Wo
     print("%-6s %-5s %8.1f us  %6.1f TFLOP/s  (%.2f GFLOP)" % (kind, name, t * 1e3, flops / t / 1e9, flops / 1e9), flush=True)
 

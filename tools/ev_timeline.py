@@ -16,7 +16,7 @@ f = F.create_objective(model, w, g, it, stats); st = dict(learningRate=1e-4, alp
 for _ in range(8): F.rmsprop(f, w, st)
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-mask = int(os.environ.get("EV_MASK", "0x7FF"), 0)
+mask = int(os.environ.get("EV_MASK", "0x1FFF"), 0)
 F._lib.call("frcnn_prof_enable", mask)
 for _ in range(n): F.rmsprop(f, w, st)
 torch.cuda.synchronize()
