@@ -182,10 +182,10 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
                          const float* weight, const float* bias, int O, int k, int pad, float* out,
                          void* stream) {
   float* wf = nullptr;
-  if (!get_winograd() && conv_x3_eligible(C, O, k)) {   // split-bf16 operand form (convx.hip)
-    FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O)));
-    int rcx = conv_x3_pack(weight, O, C, 0, wf, S(stream));
-    if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, pad, out, OUT_STORE, 0, S(stream));
+  if (!get_winograd() && conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
+    FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
+    int rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream));
+    if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wf);
     return rcx;
@@ -209,9 +209,9 @@ int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const 
                                 int pad, float* gin, int accumulate, void* stream) {
   float* wd = nullptr;
   if (!get_winograd() && conv_x3_eligible(O, C, k)) {
-    FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C)));
-    int rcx = conv_x3_pack(weight, O, C, 1, wd, S(stream));
-    if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
+    FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C, k)));
+    int rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream));
+    if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wd);
     return rcx;

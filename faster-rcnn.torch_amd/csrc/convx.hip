@@ -47,10 +47,10 @@ int get_split_bf16() {
 }
 
 bool conv_x3_eligible(int Cin, int M, int k) {
-  return get_split_bf16() && k == 3 && Cin % CX_CH == 0 && Cin >= CX_CH && M % CX_BM == 0;
+  return get_split_bf16() && (k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && Cin >= CX_CH && M % CX_BM == 0;
 }
 
-size_t conv_x3_pack_bytes(int Kchan, int M) { return (size_t)(M / CX_BM) * (Kchan / CX_CH) * 9 * CX_ASTAGE; }
+size_t conv_x3_pack_bytes(int Kchan, int M, int k) { return (size_t)(M / CX_BM) * (Kchan / CX_CH) * k * k * CX_ASTAGE; }
 
 // ---- three-way bf16 split of 8 values -> three 16-byte plane entries
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
@@ -78,50 +78,61 @@ __device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint
 // dst, per (m tile, chunk, tap): one A stage [plane][half][128][8] -- exactly the LDS image.
 //  mode 0 (fwd):   A[m][kc][tap] = W[m][kc][tap]            (W is [O][C][3][3]: M = O, K channels = C)
 //  mode 1 (dgrad): A[m][kc][tap] = W[kc][m][8 - tap]        (M = C, K channels = O; the flipped filter)
-// One block = one (M tile, chunk) pair: its 128 x 16 x 9 source floats are contiguous runs (mode 0: 144 floats per filter
-// row; mode 1: 1152 floats per K channel), read coalesced into LDS, split, and written as the nine 12 KB stages.
-#define PX_PITCH 145   // floats per LDS row (odd: the stride-9 reads of a lane's 8 channels spread over the banks)
-__device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
+// One block = one (M tile, chunk) pair: its 128 x 16 x k*k source floats are contiguous runs (mode 0: 16 k*k floats per
+// filter row; mode 1: 128 k*k floats per K channel), read coalesced into LDS (ROWS filter rows at a time), split, and
+// written as the k*k 12 KB stages.
+#define PX_FLOATS (CX_BM * 145)   // LDS floats of the pack kernels: 128 rows x (144 + 1) for k = 3
+template <int KS, int ROWS>
+__device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
+  constexpr int KK = KS * KS, PITCH = CX_CH * KK + 1;   // odd pitch: the stride-KK reads of a lane's 8 channels spread over the banks
+  static_assert(ROWS * PITCH <= PX_FLOATS, "pack tile does not fit");
   const float* __restrict__ w = weights + j.w_off;
   const int M = j.mode == 0 ? j.O : j.C, KC = j.mode == 0 ? j.C : j.O;
   const int nCh = KC / CX_CH, pairs = (M / CX_BM) * nCh;
   const int tid = threadIdx.x;
   for (int pr = blk; pr < pairs; pr += nblk) {
     const int mt = pr / nCh, chunk = pr - mt * nCh;
-    // tile[r][kc16 * 9 + tap] (source tap order), r = filter row inside the M tile
-    if (j.mode == 0) {
-      for (int e = tid; e < CX_BM * 144; e += 256) {
-        const int r = e / 144, q = e - r * 144;
-        tile[r * PX_PITCH + q] = w[((size_t)(mt * CX_BM + r) * j.C + chunk * CX_CH) * 9 + q];
+    char* base = reinterpret_cast<char*>(j.dst) + (size_t)pr * KK * CX_ASTAGE;
+    for (int r0 = 0; r0 < CX_BM; r0 += ROWS) {
+      // tile[r][kc16 * KK + tap] (source tap order), r = filter row inside this group of ROWS rows
+      if (j.mode == 0) {
+        for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
+          const int r = e / (CX_CH * KK), q = e - r * (CX_CH * KK);
+          tile[r * PITCH + q] = w[((size_t)(mt * CX_BM + r0 + r) * j.C + chunk * CX_CH) * KK + q];
+        }
+      } else {
+        for (int e = tid; e < CX_CH * ROWS * KK; e += 256) {
+          const int kc = e / (ROWS * KK), q = e - kc * (ROWS * KK);   // q = r * KK + tap, contiguous in the source
+          const int r = q / KK, tap = q - r * KK;
+          tile[r * PITCH + kc * KK + tap] = w[((size_t)(chunk * CX_CH + kc) * j.C + mt * CX_BM + r0) * KK + q];
+        }
       }
-    } else {
-      for (int e = tid; e < CX_CH * CX_BM * 9; e += 256) {
-        const int kc = e / (CX_BM * 9), q = e - kc * (CX_BM * 9);   // q = r * 9 + tap, contiguous in the source
-        const int r = q / 9, tap = q - r * 9;
-        tile[r * PX_PITCH + kc * 9 + tap] = w[((size_t)(chunk * CX_CH + kc) * j.C + mt * CX_BM) * 9 + q];
-      }
-    }
-    __syncthreads();
-    char* base = reinterpret_cast<char*>(j.dst) + (size_t)pr * 9 * CX_ASTAGE;
-    for (int it = tid; it < 9 * 2 * CX_BM; it += 256) {
-      const int r = it % CX_BM, h = (it / CX_BM) & 1, tap = it / (2 * CX_BM);
-      const int st = j.mode == 0 ? tap : 8 - tap;   // source tap (mode 1: the flipped filter)
-      float v[8];
+      __syncthreads();
+      for (int it = tid; it < KK * 2 * ROWS; it += 256) {
+        const int r = it % ROWS, h = (it / ROWS) & 1, tap = it / (2 * ROWS);
+        const int st = j.mode == 0 ? tap : KK - 1 - tap;   // source tap (mode 1: the flipped filter)
+        float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = tile[r * PX_PITCH + (8 * h + i) * 9 + st];
-      uint4 H, Mi, L;
-      split8(v, H, Mi, L);
-      char* stage = base + (size_t)tap * CX_ASTAGE;
-      *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * CX_BM + r) * 16) = H;
-      *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * CX_BM + r) * 16) = Mi;
-      *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * CX_BM + r) * 16) = L;
+        for (int i = 0; i < 8; ++i) v[i] = tile[r * PITCH + (8 * h + i) * KK + st];
+        uint4 H, Mi, L;
+        split8(v, H, Mi, L);
+        char* stage = base + (size_t)tap * CX_ASTAGE;
+        *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * CX_BM + r0 + r) * 16) = H;
+        *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * CX_BM + r0 + r) * 16) = Mi;
+        *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * CX_BM + r0 + r) * 16) = L;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
+}
+__device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
+  if (j.k == 3) pack_x_job<3, 128>(weights, j, blk, nblk, tile);
+  else if (j.k == 5) pack_x_job<5, 32>(weights, j, blk, nblk, tile);
+  else pack_x_job<7, 16>(weights, j, blk, nblk, tile);
 }
 
 __global__ __launch_bounds__(256) void pack_x3_multi_kernel(const float* __restrict__ weights, const PackXJob* __restrict__ jobs, int njobs) {
-  __shared__ float tile[CX_BM * PX_PITCH];
+  __shared__ float tile[PX_FLOATS];
   int jb = 0;
   while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_begin) ++jb;
   const PackXJob j = jobs[jb];
@@ -129,14 +140,14 @@ __global__ __launch_bounds__(256) void pack_x3_multi_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ weights, PackXJob j) {
-  __shared__ float tile[CX_BM * PX_PITCH];
+  __shared__ float tile[PX_FLOATS];
   pack_x3_job(weights, j, blockIdx.x, gridDim.x, tile);
 }
 
-PackXJob conv_x3_pack_job(long w_off, int O, int C, int mode, void* dst) {
+PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst) {
   PackXJob j;
-  j.w_off = w_off; j.O = O; j.C = C; j.mode = mode; j.dst = dst;
-  j.total = (long)O * C * 9;
+  j.w_off = w_off; j.O = O; j.C = C; j.k = k; j.mode = mode; j.dst = dst;
+  j.total = (long)O * C * k * k;
   j.blk_begin = 0; j.nblk = 1;
   return j;
 }
@@ -160,8 +171,8 @@ int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs
 }
 
 // one pack by itself (op-level entry points and tests)
-int conv_x3_pack(const float* w, int O, int C, int mode, void* dst, hipStream_t s) {
-  PackXJob j = conv_x3_pack_job(0, O, C, mode, dst);
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s) {
+  PackXJob j = conv_x3_pack_job(0, O, C, k, mode, dst);
   int grid = conv_x3_pack_assign_blocks(&j, 1);
   FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_kernel, dim3(grid), dim3(256), 0, w, j);
   FR_LAUNCH_CHECK();
@@ -182,8 +193,9 @@ struct CxArgs {
   int out_mode;           // 0 store, 1 add, 3 split-K slab
 };
 
-template <bool SLOPE, bool SCALE>
+template <int KS, bool SLOPE, bool SCALE>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
+  constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   const int split = v / nT;
   const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
   const int m0 = mt_id * CX_BM;
-  const int PW = p.TW + 2, plane = (p.TH + 2) * PW;
+  const int PW = p.TW + KS - 1, plane = (p.TH + KS - 1) * PW;
   const int NT = p.TH * p.TW;
   const int HW = p.H * p.W;
   const size_t hw_bytes = (size_t)HW * 4;
@@ -250,13 +262,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
 
   const int cbeg = split * p.chunksPerSplit;
   const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
-  const int nStages = (cend - cbeg) * 9;
+  const int nStages = (cend - cbeg) * KK;
 
   char* const As = smem;
   char* const Bs = smem + 3 * CX_ASTAGE;
 
   // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
-  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * 9 * CX_ASTAGE +
+  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * CX_ASTAGE +
                            (size_t)wave * 3072 + lane * 16;
   auto dma_stage = [&](int stage, int buf) {
     const char* src = wsrc + (size_t)stage * CX_ASTAGE;
@@ -341,21 +353,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const char* Bcur = Bs + ((chunk - cbeg) & 1) * CX_BBUF;
     char* Bnext = Bs + (((chunk - cbeg) & 1) ^ 1) * CX_BBUF;
+    const int rot = KK % 3 == 0 ? 0 : ((chunk - cbeg) * KK) % 3;   // A ring slot of the chunk's first tap
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap, ++stage) {
+    for (int tap = 0; tap < KK; ++tap, ++stage) {
       // stage's A image has landed in every wave's part (DMA retires in order: at most the next stage's three
       // instructions -- and, right after a chunk's first tap, the patch loads issued behind them -- may be in flight)
       if (stage + 1 >= nStages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       __syncthreads();
-      if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2) % 3);
+      if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2 + rot) % 3);
       if (tap == 0) {   // the next chunk's patch: requested now, split and written to the other buffer at tap 4
         more = chunk + 1 < cend;
         if (more) load_patch(chunk + 1);
       }
-      const int ky = tap / 3, kx = tap - ky * 3;
-      compute(As + (tap % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
+      const int ky = tap / KS, kx = tap - ky * KS;
+      compute(As + ((tap + rot) % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
       if (tap == 4 && more) store_patch(Bnext);
     }
   }
@@ -419,52 +432,54 @@ static int x3_workspace(size_t need, float** out, int slot) {
 }
 
 // output tile TH x TW <= 128 pixels with a patch plane <= CX_PP that wastes the least work
-static void x3_choose_tile(int Ho, int Wo, int* TH, int* TW) {
+static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
   long best = -1;
   int bth = 1, btw = 1;
   for (int tw = 1; tw <= std::min(Wo, CX_NTMAX); ++tw) {
     if (tw < 8 && Wo >= 8) continue;
     int th = std::min(CX_NTMAX / tw, Ho);
-    while (th > 1 && (th + 2) * (tw + 2) > CX_PP) --th;
-    if (th < 1 || (th + 2) * (tw + 2) > CX_PP) continue;
+    while (th > 1 && (th + k - 1) * (tw + k - 1) > CX_PP) --th;
+    if (th < 1 || (th + k - 1) * (tw + k - 1) > CX_PP) continue;
     long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
-    long cost = tiles * CX_NTMAX * 64 + tiles * (th + 2) * (tw + 2);  // MFMA slots + halo traffic
+    long cost = tiles * CX_NTMAX * 64 + tiles * (th + k - 1) * (tw + k - 1);  // MFMA slots + halo traffic
     if (best < 0 || cost < best || (cost == best && tw > btw)) { best = cost; bth = th; btw = tw; }
   }
   *TH = bth; *TW = btw;
 }
 
-template <bool SLOPE, bool SCALE>
+template <int KS, bool SLOPE, bool SCALE>
 static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<SLOPE, SCALE>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, SLOPE, SCALE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
+  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
-            const float* bias, int M, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot) {
-  FR_CHECK(Cin % CX_CH == 0 && M % CX_BM == 0, "conv_x3: %d channels -> %d filters is not a split-bf16 shape", Cin, M);
+            const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot) {
+  FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % CX_BM == 0,
+           "conv_x3: %d channels -> %d filters, %dx%d is not a split-bf16 shape", Cin, M, k, k);
   FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
   CxArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.pad = pad;
-  a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
-  FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, pad=%d)", H, W, pad);
-  x3_choose_tile(a.Ho, a.Wo, &a.TH, &a.TW);
+  a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
+  FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
+  x3_choose_tile(a.Ho, a.Wo, k, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
   a.mTiles = M / CX_BM;
   a.nChunks = Cin / CX_CH;
   const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
-  // split K until one round of blocks fills the 2 x 256 resident slots, keeping >= 4 chunks (36 stages) per split
-  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, 512 / blocks), 16), std::max(1, a.nChunks / 4));
+  // split K until one round of blocks fills the 2 x 256 resident slots, keeping >= 36 stages (4 chunks of a 3x3) per split
+  const int min_chunks = cdiv(36, k * k);
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, 512 / blocks), 16), std::max(1, a.nChunks / min_chunks));
   if (const char* e = getenv("FRCNN_X3_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
@@ -475,10 +490,16 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
-  if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * 9 * (double)a.Ho * a.Wo;
+  if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
-  if (in_slope) rc = in_scale ? launch_x3<true, true>(a, algo_flops, s) : launch_x3<true, false>(a, algo_flops, s);
-  else rc = in_scale ? launch_x3<false, true>(a, algo_flops, s) : launch_x3<false, false>(a, algo_flops, s);
+  const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
+  if (k == 3) {
+    rc = act == 3 ? launch_x3<3, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, true, false>(a, algo_flops, s)
+       : act == 1 ? launch_x3<3, false, true>(a, algo_flops, s) : launch_x3<3, false, false>(a, algo_flops, s);
+  } else {   // anchor nets: their input is a pooled map (activation already applied by the pooling kernel)
+    FR_CHECK(act == 0, "conv_x3: a %dx%d launch takes no fused input activation", k, k);
+    rc = k == 5 ? launch_x3<5, false, false>(a, algo_flops, s) : launch_x3<7, false, false>(a, algo_flops, s);
+  }
   FR_TRY(rc);
   if (slab) {
     long total = (long)M * a.Ho * a.Wo;

@@ -235,10 +235,12 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
   static const int wino_dgrad = getenv("FRCNN_WINO_DGRAD") ? atoi(getenv("FRCNN_WINO_DGRAD")) : 0;
   c.wino_d = wino_dgrad && c.block >= 0 && need_dgrad && conv_wino_eligible(c.Cout, c.Ho, c.Wo, c.Cin, c.k, c.k - 1 - c.pad);
   // 3x3 launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time
-  c.x_f = !c.wino_f && conv_x3_eligible(c.Cin, c.Cout, c.k);
+  // (the 5x5 / 7x7 anchor nets keep the fp32 kernel: on their 25x46 / 23x44 maps the split form's 8x10-pixel tiles fill 63 %
+  // of an MFMA tile and its 7.2 M weights would have to be split every step -- measured 3.59 ms/step with them against 3.38)
+  c.x_f = !c.wino_f && c.k == 3 && conv_x3_eligible(c.Cin, c.Cout, c.k);
   c.x_d = !c.wino_d && c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
-  if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout)));
-  if (c.x_d) FR_TRY(c.wxd.ensure(conv_x3_pack_bytes(c.Cout, c.Cin)));
+  if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout, c.k)));
+  if (c.x_d) FR_TRY(c.wxd.ensure(conv_x3_pack_bytes(c.Cout, c.Cin, c.k)));
   if (c.wino_f) FR_TRY(c.wu.ensure(conv_wino_filter_floats(c.Cin, c.Cout) * 4));
   if (c.wino_d) FR_TRY(c.wud.ensure(conv_wino_filter_floats(c.Cout, c.Cin) * 4));
   return FRCNN_OK;
@@ -340,8 +342,8 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
   {  // split-bf16 pack jobs
     std::vector<PackXJob> all, fwd;
     auto add = [&](Conv& c) {
-      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, 0, c.wx.p)); fwd.push_back(all.back()); }
-      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, 1, c.wxd.p));
+      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p)); fwd.push_back(all.back()); }
+      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p));
     };
     for (auto& c : m->convs) add(c);
     for (auto& hd : m->heads) add(hd.c3);
@@ -556,7 +558,7 @@ static int fork_to(frcnn_model* m, hipStream_t s, hipStream_t to, size_t idx) {
 static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, int ws_slot) {
   const Block& in = m->blocks[h.input];
   if (h.c3.x_f)
-    FR_TRY(conv_x3(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wx.p, w + h.c3.b_off, h.c3.Cout, 0,
+    FR_TRY(conv_x3(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wx.p, w + h.c3.b_off, h.c3.Cout, h.c3.k, 0,
                    h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
   else
     FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
@@ -622,7 +624,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
       IgemmPool pl = {blk.pooled.f(), (unsigned char*)blk.pidx.p, w + c.a_off,
                       (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
       if (c.x_f)
-        FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.pad, c.x.f(), OUT_STORE, 0, s));
+        FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.k, c.pad, c.x.f(), OUT_STORE, 0, s));
       else if (c.wino_f)
         FR_TRY(conv_wino(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wu.f(), w + c.b_off, c.Cout, c.x.f(), OUT_STORE, 0, s));
       else
@@ -938,7 +940,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
       if (c.x_d)
-        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k - 1 - c.pad, gin, gmode, fl, s));
+        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s));
       else if (c.wino_d)
         FR_TRY(conv_wino(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wud.f(), nullptr, c.Cin, gin, gmode, fl, s));
       else

@@ -213,3 +213,37 @@ def test_weight_gradient_with_fused_activation(F, O):
     F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, F.ptr(da), F.ptr(ds), F.ptr(dg), O_, 3, pad, F.ptr(gw),
                 F.ptr(gb), F.stream_ptr())
     assert_close(gw.numpy(), gw_want, 1e-4, "split-bf16 conv wgrad + act")
+
+
+@pytest.mark.parametrize("C_,H,W,O_,k", [(384, 29, 50, 256, 5), (384, 29, 50, 256, 7), (32, 17, 23, 128, 5), (16, 9, 30, 128, 7)])
+def test_anchor_net_kernel_sizes(F, O, both_forms, C_, H, W, O_, k):
+    """The 5x5 and 7x7 valid convolutions of the anchor nets (models/model_utilities.lua:31, vgg_small.lua:13-14) in the
+    same form: forward and input gradient."""
+    rng = np.random.RandomState(C_ + k)
+    x = rng.randn(C_, H, W).astype(np.float32)
+    w = (rng.randn(O_, C_, k, k) * np.sqrt(2.0 / (k * k * O_))).astype(np.float32)
+    b = rng.randn(O_).astype(np.float32)
+    want = O.conv2d_fwd(x, w, b, 0)
+    dx, dw, db = _dev(F, x), _dev(F, w), _dev(F, b)
+
+    def fwd():
+        out = F.DeviceTensor.empty(want.shape)
+        F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), F.ptr(db), O_, k, 0, F.ptr(out), F.stream_ptr())
+        return out.numpy()
+    split, direct = both_forms(fwd)
+    assert not np.array_equal(split, direct), "the option did not switch the kernel"
+    assert_close(split, want, 1e-4, "split-bf16 %dx%d conv fwd" % (k, k))
+    assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
+    if C_ % 128 == 0 and O_ % 16 == 0:   # input gradient: M = C
+        Ho, Wo = H - k + 1, W - k + 1
+        g = rng.randn(O_, Ho, Wo).astype(np.float32)
+        gwant = O.conv2d_bwd_input(g, w, 0, H, W)
+        dg = _dev(F, g)
+
+        def bwd():
+            gin = F.DeviceTensor.empty((C_, H, W))
+            F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, Ho, Wo, F.ptr(dw), C_, k, 0, F.ptr(gin), 0, F.stream_ptr())
+            return gin.numpy()
+        s2, d2 = both_forms(bwd)
+        assert not np.array_equal(s2, d2)
+        assert_close(s2, gwant, 1e-4, "split-bf16 %dx%d conv dgrad" % (k, k))
