@@ -25,12 +25,14 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = dict(launches=max(len(fv), len(wv)),
                              fetch_bytes_per_launch_corrected=2.0 * sum(fv) / max(len(fv), 1),
                              write_bytes_per_launch=sum(wv) / max(len(wv), 1))
-k3 = [k for k in out["kernels"] if k.startswith("conv_igemm_kernel<3, 8")]
-n = sum(out["kernels"][k]["launches"] for k in k3)
-if n:
-    out["conv_igemm_k3_bytes_per_launch"] = round(sum(out["kernels"][k]["launches"] * (out["kernels"][k]["fetch_bytes_per_launch_corrected"] + out["kernels"][k]["write_bytes_per_launch"]) for k in k3) / n)
+for key, prefix in (("conv_igemm_k3", "conv_igemm_kernel<3, 8"), ("conv_x3", "conv_x3_kernel<3"), ("conv_wgradx", "conv_wgradx_kernel")):
+    ks = [k for k in out["kernels"] if k.startswith(prefix)]
+    n = sum(out["kernels"][k]["launches"] for k in ks)
+    if n:
+        out[key + "_bytes_per_launch"] = round(sum(out["kernels"][k]["launches"] * (out["kernels"][k]["fetch_bytes_per_launch_corrected"] + out["kernels"][k]["write_bytes_per_launch"]) for k in ks) / n)
 rm = next((v for k, v in out["kernels"].items() if k.startswith("rmsprop_kernel")), None)
 if rm:
     out["calibration_rmsprop"] = dict(fetch_corrected=rm["fetch_bytes_per_launch_corrected"], write=rm["write_bytes_per_launch"])
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print("conv_igemm_k3 bytes/launch:", out.get("conv_igemm_k3_bytes_per_launch"), " rmsprop:", out.get("calibration_rmsprop"))
+print("bytes/launch: conv_x3", out.get("conv_x3_bytes_per_launch"), " conv_wgradx", out.get("conv_wgradx_bytes_per_launch"),
+      " conv_igemm_k3", out.get("conv_igemm_k3_bytes_per_launch"), " rmsprop:", out.get("calibration_rmsprop"))

@@ -31,21 +31,27 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/be
 cd $R
 cp $O/stats/*/*kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
 python tools/timeline.py $O/stats 12 > $O/${TAG}_step_timeline.txt 2>&1
-# 3. the bench line itself (un-profiled), with the CPU baseline, the parity object and the other legs
+# 3. the bench line itself (un-profiled), with the CPU baseline, the parity object and the other legs (roofline.traffic is
+#    read from profiles/pmc_traffic.json: the table of pass 1 goes there first)
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 # 4. the other configurations and options
 {
   echo "# MI355X, $TAG: configurations and options beside the bench line (commands as run on the GPU box)"
   echo "# per-layer convolution kernels, vgg_small 800x450 shapes -- python tools/bench_conv.py fwd|dgrad|wgrad"
   python tools/bench_conv.py fwd 2>/dev/null; python tools/bench_conv.py dgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null; python tools/bench_conv.py wgrad 2>/dev/null
-  echo "# the same with the Winograd F(2x2,3x3) form of the eligible 3x3 layers -- FRCNN_WINO=1 python tools/bench_conv.py fwd|dgrad"
-  FRCNN_WINO=1 python tools/bench_conv.py fwd b2c1 b2c2 b3c1 b3c2 2>/dev/null; FRCNN_WINO=1 python tools/bench_conv.py dgrad b2c1 b2c2 b3c2 2>/dev/null
+  echo "# the same with the fp32 matrix-core kernels only -- FRCNN_SPLIT_BF16=0 python tools/bench_conv.py fwd|dgrad|wgrad"
+  FRCNN_SPLIT_BF16=0 python tools/bench_conv.py fwd 2>/dev/null; FRCNN_SPLIT_BF16=0 python tools/bench_conv.py dgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null; FRCNN_SPLIT_BF16=0 python tools/bench_conv.py wgrad 2>/dev/null
+  echo "# ... and with the Winograd F(2x2,3x3) form of the eligible 3x3 layers (fp32) -- FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd|dgrad"
+  FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd b2c1 b2c2 b3c1 b3c2 2>/dev/null; FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py dgrad b2c1 b2c2 b3c2 2>/dev/null
+  echo "# sustained v_mfma_f32_32x32x16_bf16 rate (no memory traffic) -- tools/bin/mfma_peak_bf16"
+  tools/bin/mfma_peak_bf16 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
-  for e in "FRCNN_WINO=0" "FRCNN_WINO=1" "FRCNN_WINO=1 FRCNN_WINO_DGRAD=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
+  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_SPLIT_BF16=0 FRCNN_WINO=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
     echo -n "$e: "; env $e python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
   done
   echo "# config 5 shapes on one GPU -- python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline"
-  for e in "FRCNN_WINO=0" "FRCNN_WINO=1"; do
+  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0"; do
     echo -n "$e: "; env $e python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'images/s', d['ms_per_step'], 'ms/step; conv_igemm 3x3', r['achieved'], 'TFLOP/s live,', r['isolated']['achieved'], 'alone')"
   done
   echo "# config 2 -- python tools/bench_detect.py 30   (Detector:detect on 3x450x800 frames; CLASSES=200: config/imagenet.lua class count)"
