@@ -33,11 +33,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define CX_BM 128                       // filters per block
 #define CX_CH 16                        // channels per chunk (one MFMA K step per tap)
-#define CX_PP 228                       // patch positions per (plane, half) in LDS (pitch); patch plane <= CX_PP
+#ifndef CX_OCC
+#define CX_OCC 3                        // blocks per CU the kernel is laid out for (2: A ring of 3 + double-buffered patch)
+#endif
+#if CX_OCC == 3
+#define CX_PP 204                       // patch positions per (plane, half) in LDS (pitch); patch plane <= CX_PP
+#define CX_NA 2                         // A ring slots
+#define CX_NB 1                         // patch buffers
+#else
+#define CX_PP 228
+#define CX_NA 3
+#define CX_NB 2
+#endif
 #define CX_NTMAX 128                    // pixels per block
 #define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage: [plane 3][half 2][128 filters][8 bf16]
 #define CX_BBUF (6 * CX_PP * 16)        // bytes of one B buffer: [plane 3][half 2][CX_PP positions][8 bf16]
-#define CX_LDS (3 * CX_ASTAGE + 2 * CX_BBUF)
+#define CX_LDS (CX_NA * CX_ASTAGE + CX_NB * CX_BBUF)
 
 static int g_splitbf16 = -1;   // -1: not decided yet (environment FRCNN_SPLIT_BF16, default on)
 void set_split_bf16(int on) { g_splitbf16 = on ? 1 : 0; }
@@ -194,7 +205,7 @@ struct CxArgs {
 };
 
 template <int KS, bool SLOPE, bool SCALE>
-__global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
+__global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   const int nStages = (cend - cbeg) * KK;
 
   char* const As = smem;
-  char* const Bs = smem + 3 * CX_ASTAGE;
+  char* const Bs = smem + CX_NA * CX_ASTAGE;
 
   // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
   const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * CX_ASTAGE +
@@ -280,32 +291,30 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
   };
 
   float vb[2][8];
-  float sc[2][8];
+  int patch_chunk = 0;
   auto load_patch = [&](int chunk) {
     const char* srcB = reinterpret_cast<const char*>(p.in) + (size_t)chunk * CX_CH * hw_bytes;
+    patch_chunk = chunk;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int j = 0; j < 8; ++j) vb[it][j] = *reinterpret_cast<const float*>(srcB + j * hw_bytes + gofs[it]);
-    if (SCALE) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + chunk * CX_CH + 8 * gsel[it]);
-        const float4 s0 = sp[0], s1 = sp[1];
-        sc[it][0] = s0.x; sc[it][1] = s0.y; sc[it][2] = s0.z; sc[it][3] = s0.w;
-        sc[it][4] = s1.x; sc[it][5] = s1.y; sc[it][6] = s1.z; sc[it][7] = s1.w;
-      }
-    }
   };
   auto store_patch = [&](char* Bb) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
+      float sc[8];
+      if (SCALE) {   // (L1 / L2 hits; fetched here rather than held in registers since the patch was requested)
+        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + patch_chunk * CX_CH + 8 * gsel[it]);
+        const float4 s0 = sp[0], s1 = sp[1];
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      }
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = vb[it][j];
         if (SLOPE) t = t > 0.f ? t : slope * t;
-        if (SCALE) t *= sc[it][j];
+        if (SCALE) t *= sc[j];
         x[j] = gok[it] ? t : 0.f;
       }
       uint4 H, Mi, L;
@@ -342,6 +351,39 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
   };
 
+#if CX_OCC == 3
+  // Three blocks per CU (44 KB of LDS, <= 168 registers): A ring of two stages -- stage s+1 is requested right after the
+  // barrier of stage s, into the slot stage s-1 was read from -- and ONE patch buffer: at a chunk boundary every wave
+  // has passed the barrier of the new chunk's first stage before the new patch (in registers since the old chunk's first
+  // tap) is split and written, and a second barrier publishes it.
+  load_patch(cbeg);
+  dma_stage(0, 0);
+  store_patch(Bs);
+  bool more = false;
+  int stage = 0;
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const int par = KK % 2 == 0 ? 0 : (chunk - cbeg) & 1;   // A ring slot of the chunk's first tap
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap, ++stage) {
+      // stage's A image (requested one stage ago) has landed in every wave's part; right after a chunk's first tap the
+      // patch loads issued behind it may still be in flight
+      if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (stage + 1 < nStages) dma_stage(stage + 1, (tap + 1 + par) & 1);
+      if (tap == 0) {
+        if (chunk > cbeg) {   // the patch of this chunk: every wave is done with the previous one
+          store_patch(Bs);
+          __syncthreads();
+        }
+        more = chunk + 1 < cend;
+        if (more) load_patch(chunk + 1);
+      }
+      const int ky = tap / KS, kx = tap - ky * KS;
+      compute(As + ((tap + par) & 1) * CX_ASTAGE, Bs, (ky * PW + kx) * 16);
+    }
+  }
+#else
   // ---- prologue: patch of the first chunk, A stages 0 and 1
   load_patch(cbeg);
   dma_stage(0, 0);
@@ -372,6 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(CxArgs p) {
       if (tap == 4 && more) store_patch(Bnext);
     }
   }
+
+#endif
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
   const long HoWo = (long)p.Ho * p.Wo;
@@ -477,9 +521,9 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   a.mTiles = M / CX_BM;
   a.nChunks = Cin / CX_CH;
   const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
-  // split K until one round of blocks fills the 2 x 256 resident slots, keeping >= 36 stages (4 chunks of a 3x3) per split
+  // split K until one round of blocks fills the CX_OCC x 256 resident slots, keeping >= 36 stages (4 chunks of a 3x3) per split
   const int min_chunks = cdiv(36, k * k);
-  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, 512 / blocks), 16), std::max(1, a.nChunks / min_chunks));
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, (256 * CX_OCC) / blocks), 16), std::max(1, a.nChunks / min_chunks));
   if (const char* e = getenv("FRCNN_X3_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
