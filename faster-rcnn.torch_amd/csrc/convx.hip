@@ -17,8 +17,9 @@
 //
 // GEMM view: D[m = filter][n = pixel] = sum_{tap, c} W[m][c][tap] * X[c][pixel + tap];  block = 128 filters x (TH x TW <=
 // 128) pixels, 2 x 2 waves of 64 x 64 (four 32x32 accumulators), K step = 16 channels of one tap (lane half h takes
-// channels 8h..8h+7), stage = one tap of a 16-channel chunk: A ring of three 12 KB stages (DMA two stages ahead), B patch
-// double-buffered per chunk.  75-79 KB of LDS -> two blocks per CU.
+// channels 8h..8h+7), stage = one tap of a 16-channel chunk: A ring of two 12 KB stages (LDS-DMA one stage ahead), one patch
+// buffer per block.  44 KB of LDS, <= 168 registers -> three blocks per CU (CX_OCC; -DCX_OCC=2 builds the first layout: ring
+// of three, double-buffered patch, 79 KB).
 #include <cstdlib>
 
 #include "kernels.h"
