@@ -45,6 +45,7 @@ python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
   echo "# ... and with the Winograd F(2x2,3x3) form of the eligible 3x3 layers (fp32) -- FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd|dgrad"
   FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd b2c1 b2c2 b3c1 b3c2 2>/dev/null; FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py dgrad b2c1 b2c2 b3c2 2>/dev/null
   echo "# sustained v_mfma_f32_32x32x16_bf16 rate (no memory traffic) -- tools/bin/mfma_peak_bf16"
+  [ -x tools/bin/mfma_peak_bf16 ] || { mkdir -p tools/bin; hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_bf16.hip -o tools/bin/mfma_peak_bf16 >/dev/null 2>&1; }
   tools/bin/mfma_peak_bf16 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
   for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_SPLIT_BF16=0 FRCNN_WINO=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
