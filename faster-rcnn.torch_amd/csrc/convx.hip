@@ -47,7 +47,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CX_NB 2
 #endif
 #define CX_NTMAX 128                    // pixels per block
-#define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage: [plane 3][half 2][128 filters][8 bf16]
+#define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage of a 128-filter block: [plane 3][half 2][128 filters][8 bf16]
 #define CX_BBUF (6 * CX_PP * 16)        // bytes of one B buffer: [plane 3][half 2][CX_PP positions][8 bf16]
 #define CX_LDS (CX_NA * CX_ASTAGE + CX_NB * CX_BBUF)
 
@@ -59,10 +59,12 @@ int get_split_bf16() {
 }
 
 bool conv_x3_eligible(int Cin, int M, int k) {
-  return get_split_bf16() && (k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && Cin >= CX_CH && M % CX_BM == 0;
+  return get_split_bf16() && (k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && Cin >= CX_CH && M % (k == 3 ? 64 : 128) == 0;
 }
 
-size_t conv_x3_pack_bytes(int Kchan, int M, int k) { return (size_t)(M / CX_BM) * (Kchan / CX_CH) * k * k * CX_ASTAGE; }
+// filters per block: 128 (2 x 2 waves of 64 x 64), or 64 (1 x 4 waves of 64 filters x 32 pixels) when 128 does not divide M
+int conv_x3_bm(int M) { return M % 128 == 0 ? 128 : 64; }
+size_t conv_x3_pack_bytes(int Kchan, int M, int k) { return (size_t)M * (Kchan / CX_CH) * k * k * 96; }   // 6 x 16 bytes per filter, chunk and tap
 
 // ---- three-way bf16 split of 8 values -> three 16-byte plane entries
 __device__ __forceinline__ unsigned cvt2(float a, float b) {
@@ -100,23 +102,24 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
   static_assert(ROWS * PITCH <= PX_FLOATS, "pack tile does not fit");
   const float* __restrict__ w = weights + j.w_off;
   const int M = j.mode == 0 ? j.O : j.C, KC = j.mode == 0 ? j.C : j.O;
-  const int nCh = KC / CX_CH, pairs = (M / CX_BM) * nCh;
+  const int BM = j.bm, AST = 6 * BM * 16;
+  const int nCh = KC / CX_CH, pairs = (M / BM) * nCh;
   const int tid = threadIdx.x;
   for (int pr = blk; pr < pairs; pr += nblk) {
     const int mt = pr / nCh, chunk = pr - mt * nCh;
-    char* base = reinterpret_cast<char*>(j.dst) + (size_t)pr * KK * CX_ASTAGE;
-    for (int r0 = 0; r0 < CX_BM; r0 += ROWS) {
+    char* base = reinterpret_cast<char*>(j.dst) + (size_t)pr * KK * AST;
+    for (int r0 = 0; r0 < BM; r0 += ROWS) {
       // tile[r][kc16 * KK + tap] (source tap order), r = filter row inside this group of ROWS rows
       if (j.mode == 0) {
         for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
           const int r = e / (CX_CH * KK), q = e - r * (CX_CH * KK);
-          tile[r * PITCH + q] = w[((size_t)(mt * CX_BM + r0 + r) * j.C + chunk * CX_CH) * KK + q];
+          tile[r * PITCH + q] = w[((size_t)(mt * BM + r0 + r) * j.C + chunk * CX_CH) * KK + q];
         }
       } else {
         for (int e = tid; e < CX_CH * ROWS * KK; e += 256) {
           const int kc = e / (ROWS * KK), q = e - kc * (ROWS * KK);   // q = r * KK + tap, contiguous in the source
           const int r = q / KK, tap = q - r * KK;
-          tile[r * PITCH + kc * KK + tap] = w[((size_t)(chunk * CX_CH + kc) * j.C + mt * CX_BM + r0) * KK + q];
+          tile[r * PITCH + kc * KK + tap] = w[((size_t)(chunk * CX_CH + kc) * j.C + mt * BM + r0) * KK + q];
         }
       }
       __syncthreads();
@@ -128,17 +131,18 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
         for (int i = 0; i < 8; ++i) v[i] = tile[r * PITCH + (8 * h + i) * KK + st];
         uint4 H, Mi, L;
         split8(v, H, Mi, L);
-        char* stage = base + (size_t)tap * CX_ASTAGE;
-        *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * CX_BM + r0 + r) * 16) = H;
-        *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * CX_BM + r0 + r) * 16) = Mi;
-        *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * CX_BM + r0 + r) * 16) = L;
+        char* stage = base + (size_t)tap * AST;
+        *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * BM + r0 + r) * 16) = H;
+        *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * BM + r0 + r) * 16) = Mi;
+        *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * BM + r0 + r) * 16) = L;
       }
       __syncthreads();
     }
   }
 }
 __device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
-  if (j.k == 3) pack_x_job<3, 128>(weights, j, blk, nblk, tile);
+  if (j.k == 3 && j.bm == 128) pack_x_job<3, 128>(weights, j, blk, nblk, tile);
+  else if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
   else if (j.k == 5) pack_x_job<5, 32>(weights, j, blk, nblk, tile);
   else pack_x_job<7, 16>(weights, j, blk, nblk, tile);
 }
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
 PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst) {
   PackXJob j;
   j.w_off = w_off; j.O = O; j.C = C; j.k = k; j.mode = mode; j.dst = dst;
+  j.bm = conv_x3_bm(mode == 0 ? O : C);
   j.total = (long)O * C * k * k;
   j.blk_begin = 0; j.nblk = 1;
   return j;
@@ -169,7 +174,7 @@ int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs) {
   for (int i = 0; i < njobs; ++i) {
     jobs[i].blk_begin = b;
     const int M = jobs[i].mode == 0 ? jobs[i].O : jobs[i].C, KC = jobs[i].mode == 0 ? jobs[i].C : jobs[i].O;
-    jobs[i].nblk = (M / CX_BM) * (KC / CX_CH);   // one block per (M tile, chunk) pair
+    jobs[i].nblk = (M / jobs[i].bm) * (KC / CX_CH);   // one block per (M tile, chunk) pair
     b += jobs[i].nblk;
   }
   return b;
@@ -205,13 +210,18 @@ struct CxArgs {
   int out_mode;           // 0 store, 1 add, 3 split-K slab
 };
 
-template <int KS, bool SLOPE, bool SCALE>
+// WM = waves along the filter dimension: 2 -> block = 128 filters, 2 x 2 waves of 64 x 64 (four 32x32 accumulators each);
+// 1 -> block = 64 filters, 1 x 4 waves of 64 filters x 32 pixels (two accumulators each) for layers whose filter count is
+// not a multiple of 128 (the 64-channel input gradients).
+template <int KS, int WM, bool SLOPE, bool SCALE>
 __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   constexpr int KK = KS * KS;
+  constexpr int BMK = 64 * WM, NTW = WM, AST = 6 * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
+  static_assert(CX_OCC == 3 || WM == 2, "the two-blocks-per-CU layout exists for 128-filter blocks only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
   const int h = lane >> 5, li = lane & 31;
 
   // XCD-aware order (see conv.hip): consecutive virtual indices of one XCD are the M tiles of one pixel tile
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   const int nt_id = v % nT;
   const int split = v / nT;
   const int ty0 = (nt_id / p.tilesX) * p.TH, tx0 = (nt_id % p.tilesX) * p.TW;
-  const int m0 = mt_id * CX_BM;
+  const int m0 = mt_id * BMK;
   const int PW = p.TW + KS - 1, plane = (p.TH + KS - 1) * PW;
   const int NT = p.TH * p.TW;
   const int HW = p.H * p.W;
@@ -254,21 +264,21 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   const float slope = SLOPE ? *p.in_slope : 1.f;
 
   // ---- lane offsets of the MFMA operand reads
-  const unsigned aoff = (unsigned)((h * CX_BM + wm * 64 + li) * 16);
-  unsigned boff[2];
+  const unsigned aoff = (unsigned)((h * BMK + wm * 64 + li) * 16);
+  unsigned boff[NTW];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    int q = wn * 64 + nt * 32 + li;
+  for (int nt = 0; nt < NTW; ++nt) {
+    int q = wn * (32 * NTW) + nt * 32 + li;
     q = q < NT ? q : NT - 1;
     const int ty = q / p.TW, tx = q - ty * p.TW;
     boff[nt] = (unsigned)((h * CX_PP + ty * PW + tx) * 16);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NTW; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -277,18 +287,25 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   const int nStages = (cend - cbeg) * KK;
 
   char* const As = smem;
-  char* const Bs = smem + CX_NA * CX_ASTAGE;
+  char* const Bs = smem + CX_NA * AST;
 
-  // A stage DMA: 12 KB = 12 wave instructions of 1 KB, three per wave
-  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * CX_ASTAGE +
-                           (size_t)wave * 3072 + lane * 16;
+  // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves
+  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * AST + lane * 16;
   auto dma_stage = [&](int stage, int buf) {
-    const char* src = wsrc + (size_t)stage * CX_ASTAGE;
-    char* dst = As + buf * CX_ASTAGE + wave * 3072;
+    const char* src = wsrc + (size_t)stage * AST;
+    char* dst = As + buf * AST;
+    if (NDMA % 4 == 0) {   // a wave's instructions cover consecutive kilobytes
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      for (int i = 0; i < NDMA / 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave * (NDMA / 4) + i) * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave * (NDMA / 4) + i) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < (NDMA + 3) / 4; ++i)
+        if (wave + 4 * i < NDMA)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * i) * 1024),
+                                           (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
   };
 
   float vb[2][8];
@@ -331,14 +348,14 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 
   // one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + 2 B)), 24 MFMAs
   auto compute = [&](const char* Ab, const char* Bb, int tapoff) {
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[2][3], b[NTW][3];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * CX_BM + mt * 32) * 16);
+        a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * BMK + mt * 32) * 16);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
         b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
     }
     // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
   };
 
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
         if (more) load_patch(chunk + 1);
       }
       const int ky = tap / KS, kx = tap - ky * KS;
-      compute(As + ((tap + par) & 1) * CX_ASTAGE, Bs, (ky * PW + kx) * 16);
+      compute(As + ((tap + par) & 1) * AST, Bs, (ky * PW + kx) * 16);
     }
   }
 #else
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
         if (more) load_patch(chunk + 1);
       }
       const int ky = tap / KS, kx = tap - ky * KS;
-      compute(As + ((tap + rot) % 3) * CX_ASTAGE, Bcur, (ky * PW + kx) * 16);
+      compute(As + ((tap + rot) % 3) * AST, Bcur, (ky * PW + kx) * 16);
       if (tap == 4 && more) store_patch(Bnext);
     }
   }
@@ -425,8 +442,8 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   auto store_tile = [&](auto mode_c) {
     constexpr int OM = decltype(mode_c)::value;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int q = wn * 64 + nt * 32 + li;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int q = wn * (32 * NTW) + nt * 32 + li;
       const int ty = q / p.TW, tx = q - ty * p.TW;
       const int oy = ty0 + ty, ox = tx0 + tx;
       if (q < NT && oy < p.Ho && ox < p.Wo) {
@@ -492,24 +509,25 @@ static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
-template <int KS, bool SLOPE, bool SCALE>
+template <int KS, int WM, bool SLOPE, bool SCALE>
 static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, SLOPE, SCALE>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, SLOPE, SCALE>), dim3(grid), dim3(256), CX_LDS, a);
+  const size_t lds = (size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * CX_BBUF;
+  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot) {
-  FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % CX_BM == 0,
+  FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % 64 == 0,
            "conv_x3: %d channels -> %d filters, %dx%d is not a split-bf16 shape", Cin, M, k, k);
   FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
   CxArgs a;
@@ -519,7 +537,8 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
   x3_choose_tile(a.Ho, a.Wo, k, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
-  a.mTiles = M / CX_BM;
+  const int bm = conv_x3_bm(M);
+  a.mTiles = M / bm;
   a.nChunks = Cin / CX_CH;
   const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
   // split K until one round of blocks fills the CX_OCC x 256 resident slots, keeping >= 36 stages (4 chunks of a 3x3) per split
@@ -538,12 +557,19 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
-  if (k == 3) {
-    rc = act == 3 ? launch_x3<3, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, true, false>(a, algo_flops, s)
-       : act == 1 ? launch_x3<3, false, true>(a, algo_flops, s) : launch_x3<3, false, false>(a, algo_flops, s);
+  if (k == 3 && bm == 128) {
+    rc = act == 3 ? launch_x3<3, 2, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 2, true, false>(a, algo_flops, s)
+       : act == 1 ? launch_x3<3, 2, false, true>(a, algo_flops, s) : launch_x3<3, 2, false, false>(a, algo_flops, s);
+  } else if (k == 3) {
+#if CX_OCC == 3
+    rc = act == 3 ? launch_x3<3, 1, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 1, true, false>(a, algo_flops, s)
+       : act == 1 ? launch_x3<3, 1, false, true>(a, algo_flops, s) : launch_x3<3, 1, false, false>(a, algo_flops, s);
+#else
+    FR_CHECK(false, "conv_x3: 64-filter blocks need the three-blocks-per-CU layout");
+#endif
   } else {   // anchor nets: their input is a pooled map (activation already applied by the pooling kernel)
-    FR_CHECK(act == 0, "conv_x3: a %dx%d launch takes no fused input activation", k, k);
-    rc = k == 5 ? launch_x3<5, false, false>(a, algo_flops, s) : launch_x3<7, false, false>(a, algo_flops, s);
+    FR_CHECK(act == 0 && bm == 128, "conv_x3: a %dx%d launch takes no fused input activation and 128-filter blocks", k, k);
+    rc = k == 5 ? launch_x3<5, 2, false, false>(a, algo_flops, s) : launch_x3<7, 2, false, false>(a, algo_flops, s);
   }
   FR_TRY(rc);
   if (slab) {

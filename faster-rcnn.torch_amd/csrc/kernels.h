@@ -53,9 +53,9 @@ int conv_wino(const float* in, int Cin, int H, int W, const float* in_slope, con
 // accuracy of the fp32 matrix-core kernel at 6/16 of its matrix-pipe time.  wp = stages packed by conv_x3_pack*.
 void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 launches take this form, 0 = fp32 MFMA only
 int get_split_bf16();
-bool conv_x3_eligible(int Cin, int M, int k);   // k in {3, 5, 7}, Cin % 16 == 0, M % 128 == 0 (and the option is on)
+bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)
 size_t conv_x3_pack_bytes(int Kchan, int M, int k);
-struct PackXJob { long w_off; long total; void* dst; int O, C, k, mode, blk_begin, nblk; };   // mode 0 forward, 1 input gradient
+struct PackXJob { long w_off; long total; void* dst; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
 PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst);
 int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);

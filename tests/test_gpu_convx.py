@@ -52,6 +52,8 @@ SHAPES = [
     (16, 9, 11, 128, 1),        # one chunk, a map smaller than a tile
     (48, 31, 45, 128, 0),       # valid convolution (anchor-net geometry)
     (384, 29, 50, 256, 0),      # the 3x3 anchor net on the last map
+    (64, 57, 100, 64, 1),       # 64 filters: 64-filter blocks (1 x 4 waves of 64 x 32)
+    (32, 23, 37, 192, 1),       # 192 = 3 x 64 filters
 ]
 
 
@@ -122,9 +124,10 @@ def test_fused_activation_of_the_producing_layer(F, O, both_forms):
         assert_close(out.numpy(), want, 1e-4, "split-bf16 conv fwd + act")
 
 
-@pytest.mark.parametrize("C_,H,W,O_,pad", [(128, 57, 100, 64, 1), (256, 38, 63, 512, 1), (128, 31, 45, 48, 0)])
+@pytest.mark.parametrize("C_,H,W,O_,pad", [(128, 57, 100, 64, 1), (256, 38, 63, 512, 1), (128, 31, 45, 48, 0),
+                                            (64, 57, 100, 128, 1)])   # the last: M = 64 input channels (64-filter blocks)
 def test_input_gradient(F, O, both_forms, C_, H, W, O_, pad):
-    """updateGradInput: M = C input channels (a multiple of 128), K = O filters (a multiple of 16)."""
+    """updateGradInput: M = C input channels (a multiple of 64), K = O filters (a multiple of 16)."""
     rng = np.random.RandomState(C_ * 7 + O_)
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     g = rng.randn(O_, Ho, Wo).astype(np.float32)
