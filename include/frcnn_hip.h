@@ -52,7 +52,7 @@ int frcnn_device_name(char *buf_host, int len);
  * Winograd F(2x2, 3x3) form (2.25x fewer multiplications, same result to fp32 rounding); applies to the operator-level
  * entry points at once and to a model from its next (re)shaping on.
  * "split_bf16" (default 1; environment FRCNN_SPLIT_BF16): the 3x3 convolutions whose shapes fit (forward and input gradient:
- * input channels a multiple of 16, filters a multiple of 128; weight gradient: both multiples of 64) run in the split-operand
+ * input channels a multiple of 16, filters a multiple of 64; weight gradient: both multiples of 64) run in the split-operand
  * form: fp32 tensors in and out, fp32 accumulation, every fp32 product formed from six exact bf16 x bf16 partial products of
  * three-way split operands on the bf16 matrix cores (24 significand bits per operand; against an fp64 reference the error
  * equals that of the fp32 matrix-core kernels, tests/test_gpu_convx.py).  0 = fp32 matrix-core kernels only.  Applies to the
