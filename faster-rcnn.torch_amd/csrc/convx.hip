@@ -63,7 +63,11 @@ bool conv_x3_eligible(int Cin, int M, int k) {
 }
 
 // filters per block: 128 (2 x 2 waves of 64 x 64), or 64 (1 x 4 waves of 64 filters x 32 pixels) when 128 does not divide M
-int conv_x3_bm(int M) { return M % 128 == 0 ? 128 : 64; }
+int conv_x3_bm(int M) {
+  static const int force = getenv("FRCNN_X3_BM") ? atoi(getenv("FRCNN_X3_BM")) : 0;
+  if (force == 64) return 64;
+  return M % 128 == 0 ? 128 : 64;
+}
 size_t conv_x3_pack_bytes(int Kchan, int M, int k) { return (size_t)M * (Kchan / CX_CH) * k * k * 96; }   // 6 x 16 bytes per filter, chunk and tap
 
 // ---- three-way bf16 split of 8 values -> three 16-byte plane entries
