@@ -127,6 +127,8 @@ FULL_LAYERS = [
     (256, 57, 100, 384, 3, 1),    # b4c1: split-K slabs + reduce
     (384, 29, 50, 256, 7, 0),     # a4: 7x7 anchor net, 24 splits
     (256, 55, 98, 18, 1, 0),      # 1x1 head, M = 18
+    (64, 300, 500, 64, 3, 1),     # vgg_large.lua block 1 widths on a 500x300 map: 64-filter blocks of the split form, both ways
+    (64, 225, 400, 128, 3, 1),    # b2c1: 128-filter blocks forward, 64-filter blocks for the input gradient
 ]
 
 
