@@ -190,20 +190,34 @@ int prelu_dropout_backward(const float* gy, const float* x, long n, const float*
 }
 
 // nn.LogSoftMax per row (max-shifted), fp32 result
+// one wave per row (lanes over the classes, fp64 max / sum by lane exchanges): with config/imagenet.lua's 201 classes a
+// thread-per-row loop of 201 fp64 exponentials took 100 us per call
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
 __global__ void log_softmax_rows_kernel(const float* __restrict__ x, int R, int n, float* __restrict__ y) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   const float* xr = x + (size_t)r * n;
-  double m = xr[0];
-  for (int i = 1; i < n; ++i) m = xr[i] > m ? (double)xr[i] : m;
+  double m = -1.0e300;
+  for (int i = lane; i < n; i += 64) m = xr[i] > m ? (double)xr[i] : m;
+  m = wave_max_f64(m);
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += exp((double)xr[i] - m);
+  for (int i = lane; i < n; i += 64) s += exp((double)xr[i] - m);
+  s = wave_sum_f64(s);
   const double lse = m + log(s);
-  for (int i = 0; i < n; ++i) y[(size_t)r * n + i] = (float)((double)xr[i] - lse);
+  for (int i = lane; i < n; i += 64) y[(size_t)r * n + i] = (float)((double)xr[i] - lse);
 }
 int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s) {
   if (R <= 0) return FRCNN_OK;
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 8.0, s, log_softmax_rows_kernel, dim3(cdiv(R, 64)), dim3(64), 0, x, R,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 8.0, s, log_softmax_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, x, R,
             n, y);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
@@ -212,16 +226,17 @@ int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s) {
 // gx = gy - exp(lsm) * sum_j gy_j
 __global__ void log_softmax_backward_kernel(const float* __restrict__ gy, const float* __restrict__ lsm, int R,
                                             int n, float* __restrict__ gx) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   double sum = 0.0;
-  for (int i = 0; i < n; ++i) sum += gy[(size_t)r * n + i];
-  for (int i = 0; i < n; ++i)
+  for (int i = lane; i < n; i += 64) sum += gy[(size_t)r * n + i];
+  sum = wave_sum_f64(sum);
+  for (int i = lane; i < n; i += 64)
     gx[(size_t)r * n + i] = (float)((double)gy[(size_t)r * n + i] - exp((double)lsm[(size_t)r * n + i]) * sum);
 }
 int log_softmax_backward(const float* gy, const float* lsm, int R, int n, float* gx, hipStream_t s) {
   if (R <= 0) return FRCNN_OK;
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 12.0, s, log_softmax_backward_kernel, dim3(cdiv(R, 64)), dim3(64), 0,
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 12.0, s, log_softmax_backward_kernel, dim3(cdiv(R, 4)), dim3(256), 0,
             gy, lsm, R, n, gx);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
