@@ -156,7 +156,7 @@ int roi_pool_backward(float* gmap, int C, int H, int W, const float* gout, const
     return FRCNN_OK;
   }
   if ((size_t)H * W * 4 <= 64 * 1024) {
-    FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_lds_kernel, dim3(C), dim3(256), (size_t)H * W * 4, gmap, C,
+    FR_LAUNCH(KC_ROI, 0, total * 12.0, s, roi_pool_backward_lds_kernel, dim3(C), dim3(1024), (size_t)H * W * 4, gmap, C,
               H * W, gout, idx, R, kh * kw);
     FR_LAUNCH_CHECK();
     return FRCNN_OK;
