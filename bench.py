@@ -269,6 +269,54 @@ def nms_leg(F, with_cpu):
     return rows
 
 
+def _fail(msg, code=2):
+    sys.stderr.write("bench.py: ERROR: %s\n" % msg)
+    sys.stderr.flush()
+    os._exit(code)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per device of this node (what
+    `python -m torch.distributed.run --nproc-per-node N` would do), each with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT and a job nonce for the communicator's rendezvous (frcnn_comm_exchange_id_file).  Fails
+    loudly when the node has fewer than N devices; the exit status is the first failing rank's."""
+    import socket
+    import subprocess
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        _fail("--gpus %d needs %d HIP devices on this node, found %d (no oversubscription, no CPU fallback)" % (n, n, have))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n),
+               FRCNN_COMM_NONCE="bench:%d:%d:%d" % (os.getpid(), port, time.time_ns()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                c = p.poll()
+                if c is None:
+                    continue
+                alive.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for q in alive:      # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,33 +329,55 @@ def main():
                     help="vgg_large = SURVEY 8d config 5 (config/imagenet.lua, use --height 600 --width 1000); not the bench line")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
     ap.add_argument("--no-other-legs", action="store_true", help="skip the inference / nms legs")
-    ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "torch"), choices=["torch", "native"],
-                    help="exchange back end at N > 1: torch.distributed ('nccl' = RCCL) or the C ABI's frcnn_comm_* (RCCL)")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the PCIe-inclusive pass (frames uploaded every step)")
+    ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "native"), choices=["torch", "native"],
+                    help="exchange back end at N > 1: the C ABI's frcnn_comm_* (RCCL; what a LuaJIT host calls) or "
+                         "torch.distributed ('nccl' = RCCL)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        _fail("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)     # no launcher: this process becomes the launcher of N ranks
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if world != args.gpus:
+        _fail("--gpus %d but the launcher started WORLD_SIZE=%d ranks: the line would be mislabelled" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        _fail("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if os.environ.get("FRCNN_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        _fail("%d ranks on this node but only %d HIP devices" % (world, torch.cuda.device_count()))
     # (debug only: FRCNN_DIST_BACKEND=gloo lets several ranks share one GPU to exercise this branch on a 1-GPU box)
     backend = os.environ.get("FRCNN_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     native_comm = None
+    exchange_info = None
     if world > 1 and args.comm == "native":
         import frcnn_amd as F0
         F0._lib.call("frcnn_set_device", local_rank)
         native_comm = F0.Comm.from_env()       # RCCL through the C ABI; no torch.distributed process group at all
         F0.comm.activate(native_comm)
+        # what RCCL itself says about the communicator: N ranks, this rank, this device -- on N distinct devices
+        cnt, urank, dev = native_comm.query()
+        counts = native_comm.gather_ints(cnt); devs = native_comm.gather_ints(dev)
+        if cnt != world or urank != rank or dev != local_rank or counts != [world] * world or sorted(devs) != list(range(world)):
+            _fail("communicator check failed on rank %d: ncclCommCount %d (want %d), user rank %d, device %d; all ranks: "
+                  "counts %s devices %s" % (rank, cnt, world, urank, dev, counts, devs), 4)
+        exchange_info = dict(ncclCommCount_per_rank=counts, device_per_rank=devs)
     elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             # one node: the host-side (gloo) subgroup of the objective binds to loopback instead of resolving the hostname
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend)  # "nccl" = RCCL over xGMI
+        if dist.get_world_size() != world:
+            _fail("process group has %d ranks, expected %d" % (dist.get_world_size(), world), 4)
+        exchange_info = dict(world_size_per_rank=[dist.get_world_size()] * world)
 
     import frcnn_amd as F
     L = F._lib.load()
@@ -393,6 +463,25 @@ def main():
             a2 = (f2[kdom] / 1e12) / (m2[kdom] / 1e3)
             iso = dict(achieved=round(a2, 2), frac=round(a2 / peak_dom, 4), avg_launch_ms=round(m2[kdom] / max(l2[kdom], 1), 4),
                        note="same kernel with frcnn_set_option('side_stream', 0): no concurrent weight-gradient launches")
+    # objective.lua:66 uploads every frame (`x.img:cuda()`); the bench contract keeps inputs resident in HBM for `value`.
+    # The PCIe-inclusive rate is measured here, outside the timed region: the same step fed by an iterator whose frames
+    # live in page-locked host memory and cross PCIe every step (copy stream + ring of device buffers, one step ahead).
+    upload_leg = None
+    if world == 1 and not args.no_upload_leg:
+        it_up = F.SyntheticBatchIterator(model, H=H, W=W, images_per_batch=1, rank=rank, world_size=world, pool=4, upload=True)
+        f_up = F.create_objective(model, weights, gradient, it_up, dict(pcls=[], preg=[], dcls=[], dreg=[]))
+        for _ in range(4 + args.warmup):
+            F.rmsprop(f_up, weights, state)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for _ in range(args.steps):
+            F.rmsprop(f_up, weights, state)
+        torch.cuda.synchronize()
+        tu = time.perf_counter() - tu
+        upload_leg = dict(value=round(args.steps / tu, 3), unit="images/sec", ms_per_step=round(1e3 * tu / args.steps, 3), steps=args.steps,
+                          bytes_per_frame=int(3 * H * W * 4),
+                          note="same step with the frame uploaded from page-locked host memory every step (objective.lua:66 "
+                               "x.img:cuda()), asynchronously on a copy stream one step ahead; not the headline value")
     if native_comm is not None:
         dt = native_comm.gather_max(dt)
     elif world > 1:
@@ -428,7 +517,10 @@ def main():
                         "v_mfma_f32_32x32x16_bf16); every other product is a plain fp32 product (v_mfma_f32_32x32x2_f32 / VALU)"
                         if split_on else "fp32 tensors, fp32 products (v_mfma_f32_32x32x2_f32 / VALU), fp32 accumulation"),
             config=dict(workload=args.model + " %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
-                                 "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/%s.lua values" % (W, H, "duplo" if args.model == "vgg_small" else "imagenet"),
+                                 "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/%s.lua values; frames resident in HBM when the timed "
+                                 "region starts (the per-image upload of objective.lua:66 is not in `value`: see with_h2d_upload)"
+                                 % (W, H, "duplo" if args.model == "vgg_small" else "imagenet"),
+                        with_h2d_upload=upload_leg,
                         images_per_gpu_per_step=1,
                         examples_per_image=[len(b["positive"]) + len(b["negative"]) for b in it.pool], global_batch=world, parallelism="dp%d" % world,
                         conv_gflop_per_image=round(train_flops / 1e9, 2),
@@ -442,6 +534,9 @@ def main():
                                   "conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)"),
                           achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
                           frac=round(ach / peak, 4), traffic=traffic,
+                          traffic_source=("profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
+                                          "--pmc WRITE_SIZE passes of this command (FETCH x2, the gfx950 correction; tools/pmc_traffic.py), "
+                                          "taken when the profile was made -- not counted in this run" if traffic is not None else None),
                           peak_note=("algorithmic (fp32-product) TFLOP/s against the dense bf16 matrix-core peak 2516.6 / 6 partial "
                                      "products; executed bf16 MFMA rate = 6 x achieved = %.0f TFLOP/s; the fp32 matrix-core peak is "
                                      "157.3 TFLOP/s" % (SPLIT_PRODUCTS * ach) if split_on else "fp32 matrix-core peak"),
@@ -449,8 +544,10 @@ def main():
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),
         )
-        out["config"]["exchange"] = ("frcnn_comm (RCCL through the C ABI)" if native_comm is not None else
-                                     "torch.distributed nccl (RCCL)" if world > 1 else "none (single process)")
+        out["config"]["exchange"] = dict(
+            backend=("frcnn_comm (RCCL through the C ABI: frcnn_comm_init_rank_file / frcnn_allreduce_f32 / _f64)" if native_comm is not None
+                     else "torch.distributed nccl (RCCL)" if world > 1 else "none (single process)"),
+            ranks=world, **(exchange_info or {}))
         ok = True
         full = args.model == "vgg_small" and (H, W) == (FULL_H, FULL_W)
         if world == 1 and not args.no_cpu_baseline and full:

@@ -14,7 +14,7 @@ require 'Localizer'
 require 'objective_hip'      -- extract_roi_pooling_input
 local C, check = hip.C, hip.check
 
-local MAX_MATCHES = 32768
+local ASPECTS = 3   -- anchors per map position (Anchors.lua:108-109)
 
 local Detector = torch.class('Detector')
 
@@ -53,7 +53,8 @@ function Detector:detect(input)                                         -- Detec
     local s = outputs[i]:size()
     Hs[i - 1], Ws[i - 1], maps[i - 1] = s[2], s[3], outputs[i].ptr
   end
-  local cap = MAX_MATCHES
+  local cap = 0   -- every anchor of the four maps may pass: the buffers hold them all (vgg_large 1000x600: 45 015)
+  for i = 0, 3 do cap = cap + ASPECTS * Hs[i] * Ws[i] end
   local wsb = tonumber(C.frcnn_rpn_scan_workspace_bytes(Hs, Ws))
   local ws = scratch('scan_ws', wsb)
   local mp = ffi.cast('float*', scratch('match_p', 4 * cap).ptr)
@@ -67,7 +68,7 @@ function Detector:detect(input)                                         -- Detec
   check(C.frcnn_memcpy_d2h(count, cnt, 4, nil))
   check(C.frcnn_stream_sync(nil))
   if count[0] > cap then
-    error(string.format('Detector: %d anchors pass p > 0.95, more than the %d the scan buffers hold', count[0], cap))
+    error(string.format('Detector: %d anchors pass p > 0.95, more than the %d the maps hold', count[0], cap))
   end
   local nm = count[0]
 

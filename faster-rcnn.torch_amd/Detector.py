@@ -17,7 +17,7 @@ from .nms import nms
 from .objective import roi_window, roi_windows
 from .tensor import DeviceTensor, ptr, stream_ptr, to_device
 
-MAX_MATCHES = 32768
+ASPECTS = 3   # anchors per map position (Anchors.lua:108-109)
 
 
 class Detector(object):
@@ -47,13 +47,17 @@ class Detector(object):
         maps = (C.c_void_p * 4)(*[outputs[i].ptr for i in range(4)])
         wsb = _lib.load().frcnn_rpn_scan_workspace_bytes(Hs, Ws)
         ws = self._buf("scan_ws", (wsb,), np.uint8)
-        cap = MAX_MATCHES
+        # every anchor of the four maps may pass (vgg_large 1000x600 scans 45 015): the buffers hold them all, nothing is
+        # ever truncated
+        cap = ASPECTS * sum(outputs[i].shape[1] * outputs[i].shape[2] for i in range(4))
         mp = self._buf("match_p", (cap,)); mi = self._buf("match_idx", (cap, 4), np.int32)
         mr = self._buf("match_rect", (cap, 4), np.float64); mb = self._buf("match_box", (cap, 4))
         cnt = self._buf("count", (1,), np.int32)
         _lib.call("frcnn_rpn_scan", maps, Hs, Ws, ptr(self._aw), ptr(self._ah), float(img_w), float(img_h),
                   float(threshold), cap, ptr(mp), ptr(mi), ptr(mr), ptr(mb), ptr(cnt), ptr(ws), wsb, stream_ptr())
-        n = min(int(cnt.numpy()[0]), cap)
+        n = int(cnt.numpy()[0])
+        if n > cap:
+            raise _lib.FrcnnError("Detector: %d anchors pass p > %g, more than the %d the maps hold" % (n, threshold, cap))
         return dict(n=n, p=DeviceTensor(mp.ptr, (n,), np.float32, owner=mp),
                     idx=DeviceTensor(mi.ptr, (n, 4), np.int32, owner=mi),
                     rect=DeviceTensor(mr.ptr, (n, 4), np.float64, owner=mr),

@@ -74,6 +74,7 @@ _SIGS = {
     "frcnn_linear_backward": ([vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp], C.c_int),
     "frcnn_rmsprop": ([vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
     "frcnn_scale_rmsprop": ([vp, vp, C.c_float, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
+    "frcnn_scale_rmsprop_dev": ([vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
     "frcnn_model_create": ([C.POINTER(ModelDesc), C.POINTER(vp)], C.c_int),
     "frcnn_model_destroy": ([vp], C.c_int),
     "frcnn_model_param_count": ([vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], C.c_int),
@@ -105,6 +106,7 @@ _SIGS = {
     "frcnn_comm_init_rank_file": ([C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int),
     "frcnn_comm_destroy": ([vp], C.c_int),
     "frcnn_comm_info": ([vp, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+    "frcnn_comm_query": ([vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
     "frcnn_allreduce_f32": ([vp, vp, C.c_longlong, vp], C.c_int),
     "frcnn_allreduce_f64": ([vp, vp, C.c_longlong, vp], C.c_int),
     "frcnn_broadcast_f32": ([vp, vp, C.c_longlong, C.c_int, vp], C.c_int),

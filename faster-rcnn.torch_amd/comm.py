@@ -52,15 +52,34 @@ class Comm(object):
 
     @staticmethod
     def from_env(timeout_ms=120000):
-        """RANK / WORLD_SIZE / MASTER_PORT as set by torch.distributed.run (or any launcher); the rendezvous file is
-        named after the port and the launcher's pid, so that a stale file of an earlier job is never read."""
+        """RANK / WORLD_SIZE / MASTER_PORT as set by torch.distributed.run (or any launcher).  The rendezvous file is
+        named after the port and the launcher's pid, and the job nonce the library checks in it (FRCNN_COMM_NONCE, see
+        frcnn_comm_exchange_id_file) defaults to the same pair plus the launcher's run id: an id file that an earlier
+        job left behind is neither named like this job's nor accepted if it is."""
         rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+        os.environ.setdefault("FRCNN_COMM_NONCE", "%s:%s:%d:%s" % (
+            os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", "0"), os.getppid(),
+            os.environ.get("TORCHELASTIC_RUN_ID", "")))
         path = os.environ.get("FRCNN_COMM_FILE") or os.path.join(
             os.environ.get("TMPDIR", "/tmp"), "frcnn_comm_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
         return Comm(rank, world, path=path, timeout_ms=timeout_ms)
 
     def get_world_size(self):
         return self.world_size
+
+    def query(self):
+        """(count, user rank, device) as RCCL reports them for this communicator (ncclCommCount / UserRank / CuDevice)."""
+        n, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.call("frcnn_comm_query", self.h, C.byref(n), C.byref(r), C.byref(d))
+        return n.value, r.value, d.value
+
+    def gather_ints(self, value):
+        """[value of rank 0, ..., value of rank W-1] on every rank (one-hot slots summed by the all-reduce)."""
+        import torch
+        t = torch.zeros(self.world_size, dtype=torch.float64, device="cuda")
+        t[self.rank] = float(value)
+        self.all_reduce(t)
+        return [int(v) for v in t.cpu().tolist()]
 
     def _call(self, t, fn, *extra):
         import torch
@@ -94,6 +113,9 @@ class Comm(object):
 
     def broadcast(self, t, root=0):
         """main.lua:92-98 under data parallelism: every replica starts from rank `root`'s flat weights."""
+        import torch
+        if t.dtype != torch.float32:   # frcnn_broadcast_f32 counts 4-byte elements
+            raise _lib.FrcnnError("broadcast: float32 only (got %s)" % t.dtype)
         w = self._call(t, lambda x, s: _lib.call("frcnn_broadcast_f32", self.h, ptr(x), x.numel(), int(root), s))
         w.wait()
         return t

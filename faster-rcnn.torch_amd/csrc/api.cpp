@@ -329,6 +329,11 @@ int frcnn_scale_rmsprop(float* x, float* g, float gscale, float* m, long long n,
                         void* stream) {
   return rmsprop_step(x, g, m, n, lr, alpha, eps, gscale, true, S(stream));
 }
+int frcnn_scale_rmsprop_dev(float* x, float* g, const double* gcount_dev, float* m, long long n, float lr, float alpha,
+                            float eps, void* stream) {
+  FR_CHECK(gcount_dev, "frcnn_scale_rmsprop_dev: NULL divisor");
+  return rmsprop_step(x, g, m, n, lr, alpha, eps, 1.f, true, S(stream), gcount_dev);
+}
 
 int frcnn_cnet_losses(float* crout, const float* crtarget, const float* ccout, const float* cctarget, int R,
                       int npos, int ncls, float* crdelta, float* ccdelta, double* loss2, void* stream) {

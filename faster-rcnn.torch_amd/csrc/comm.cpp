@@ -6,7 +6,9 @@
 // librccl is bound at first use (dlopen + dlsym), not at link time: a single-GPU host never loads it, and inside a
 // process that already holds a copy (PyTorch-ROCm ships one under the same SONAME) the loader hands back that copy.
 #include <dlfcn.h>
+#include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -26,6 +28,9 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   std::string err;
 };
 
@@ -53,6 +58,9 @@ bool rccl_load() {
   FR_SYM(AllReduce, "ncclAllReduce")
   FR_SYM(Broadcast, "ncclBroadcast")
   FR_SYM(GetErrorString, "ncclGetErrorString")
+  FR_SYM(CommCount, "ncclCommCount")
+  FR_SYM(CommUserRank, "ncclCommUserRank")
+  FR_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef FR_SYM
   g_rccl.so = so;
   return true;
@@ -93,29 +101,55 @@ int frcnn_comm_get_unique_id(void* id_host) {
   return FRCNN_OK;
 }
 
+// The rendezvous file: {128-byte id, 8-byte job nonce, 8-byte pid of the writer}.  A reader accepts it only when the
+// nonce is its own job's (FRCNN_COMM_NONCE) and the writer is still alive: what a crashed or killed job left behind
+// under the same path is ignored (and removed by the next rank 0 before it writes).
+struct IdFile {
+  unsigned char id[FRCNN_COMM_ID_BYTES];
+  unsigned long long nonce;
+  long long pid;
+};
+
+static unsigned long long job_nonce() {
+  const char* e = getenv("FRCNN_COMM_NONCE");
+  unsigned long long h = 1469598103934665603ull;   // FNV-1a of the string
+  for (const char* p = (e && *e) ? e : "0"; *p; ++p) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+  return h;
+}
+
 int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int timeout_ms) {
   FR_CHECK(path && *path && id_host, "frcnn_comm_exchange_id_file: path and id are required");
+  const unsigned long long nonce = job_nonce();
   if (rank == 0) {
-    // written under a temporary name and renamed: a reader never sees a partial id
+    unlink(path);   // a previous job's id (crashed before its destroy) must not be joined
+    // written under a temporary name and renamed: a reader never sees a partial record
     std::string tmp = std::string(path) + ".tmp";
     int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
     FR_CHECK(fd >= 0, "frcnn_comm_exchange_id_file: cannot create %s", tmp.c_str());
-    ssize_t w = write(fd, id_host, FRCNN_COMM_ID_BYTES);
+    IdFile rec;
+    memcpy(rec.id, id_host, FRCNN_COMM_ID_BYTES);
+    rec.nonce = nonce; rec.pid = (long long)getpid();
+    ssize_t w = write(fd, &rec, sizeof(rec));
     close(fd);
-    FR_CHECK(w == FRCNN_COMM_ID_BYTES, "frcnn_comm_exchange_id_file: short write to %s", tmp.c_str());
+    FR_CHECK(w == (ssize_t)sizeof(rec), "frcnn_comm_exchange_id_file: short write to %s", tmp.c_str());
     FR_CHECK(rename(tmp.c_str(), path) == 0, "frcnn_comm_exchange_id_file: cannot rename %s", tmp.c_str());
     return FRCNN_OK;
   }
   const double t0 = now_ms();
+  const char* why = "no file";
   for (;;) {
     int fd = open(path, O_RDONLY);
     if (fd >= 0) {
-      ssize_t r = read(fd, id_host, FRCNN_COMM_ID_BYTES);
+      IdFile rec;
+      ssize_t r = read(fd, &rec, sizeof(rec));
       close(fd);
-      if (r == FRCNN_COMM_ID_BYTES) return FRCNN_OK;
+      if (r != (ssize_t)sizeof(rec)) why = "short or foreign file";
+      else if (rec.nonce != nonce) why = "another job's nonce (stale file?)";
+      else if (kill((pid_t)rec.pid, 0) != 0 && errno == ESRCH) why = "its writer is gone (stale file of a dead job)";
+      else { memcpy(id_host, rec.id, FRCNN_COMM_ID_BYTES); return FRCNN_OK; }
     }
     if (now_ms() - t0 > timeout_ms) {
-      frcnn::set_error("frcnn_comm_exchange_id_file: rank %d waited %d ms for %s", rank, timeout_ms, path);
+      frcnn::set_error("frcnn_comm_exchange_id_file: rank %d waited %d ms for %s (%s)", rank, timeout_ms, path, why);
       return FRCNN_ERR_STATE;
     }
     usleep(2000);
@@ -159,6 +193,14 @@ int frcnn_comm_info(const frcnn_comm* c, int* nranks_host, int* rank_host) {
   FR_CHECK(c, "frcnn_comm_info: NULL communicator");
   if (nranks_host) *nranks_host = c->nranks;
   if (rank_host) *rank_host = c->rank;
+  return FRCNN_OK;
+}
+
+int frcnn_comm_query(const frcnn_comm* c, int* count_host, int* user_rank_host, int* device_host) {
+  FR_CHECK(c, "frcnn_comm_query: NULL communicator");
+  if (count_host) FR_RCCL(g_rccl.CommCount(c->comm, count_host));
+  if (user_rank_host) FR_RCCL(g_rccl.CommUserRank(c->comm, user_rank_host));
+  if (device_host) FR_RCCL(g_rccl.CommCuDevice(c->comm, device_host));
   return FRCNN_OK;
 }
 

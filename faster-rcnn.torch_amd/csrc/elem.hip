@@ -522,7 +522,11 @@ int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStrea
 // optimiser's pass over the flat vectors: 6 streams instead of 2 + 5).
 template <bool SCALE>
 __global__ void rmsprop_kernel(float* __restrict__ x, float* __restrict__ g, float* __restrict__ m,
-                               long n, float lr, float alpha, float eps, float gscale) {
+                               long n, float lr, float alpha, float eps, float gscale,
+                               const double* __restrict__ gcount) {
+  // gcount: the divisor of gradient:div (objective.lua:200) read from the device -- the all-reduced example count of a
+  // data-parallel step, which no host has seen yet (a count of 0 leaves the gradient as it is)
+  if (SCALE && gcount) { const double c = *gcount; gscale = c > 0.0 ? (float)(1.0 / c) : 1.0f; }
   const long n4 = n >> 2;
   float4* x4 = reinterpret_cast<float4*>(x);
   float4* g4 = reinterpret_cast<float4*>(g);
@@ -551,13 +555,13 @@ __global__ void rmsprop_kernel(float* __restrict__ x, float* __restrict__ g, flo
   }
 }
 int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, float eps, float gscale,
-                 bool scale_first, hipStream_t s) {
+                 bool scale_first, hipStream_t s, const double* gcount_dev) {
   FR_CHECK((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m) & 15) == 0, "rmsprop_step: buffers must be 16-byte aligned");
   int grid = (int)std::min<long>(std::max<long>(1, cdivl(n / 4, 256)), 2048);
   if (scale_first)
-    FR_LAUNCH(KC_OPTIM, 0, n * 24.0, s, rmsprop_kernel<true>, dim3(grid), dim3(256), 0, x, g, m, n, lr, alpha, eps, gscale);
+    FR_LAUNCH(KC_OPTIM, 0, n * 24.0, s, rmsprop_kernel<true>, dim3(grid), dim3(256), 0, x, g, m, n, lr, alpha, eps, gscale, gcount_dev);
   else
-    FR_LAUNCH(KC_OPTIM, 0, n * 20.0, s, rmsprop_kernel<false>, dim3(grid), dim3(256), 0, x, g, m, n, lr, alpha, eps, 1.f);
+    FR_LAUNCH(KC_OPTIM, 0, n * 20.0, s, rmsprop_kernel<false>, dim3(grid), dim3(256), 0, x, g, m, n, lr, alpha, eps, 1.f, (const double*)nullptr);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -119,7 +119,7 @@ int col2im_positions_add(const float* col, int C, int H, int W, int k, int Wo, c
 int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, hipStream_t s);
 int fill_value(float* x, long n, float v, hipStream_t s);
 int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, float eps, float gscale,
-                 bool scale_first, hipStream_t s);
+                 bool scale_first, hipStream_t s, const double* gcount_dev = nullptr);
 
 // ---------------------------------------------------------------- gemm (gemm.hip)
 // C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.

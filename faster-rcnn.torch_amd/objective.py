@@ -107,6 +107,15 @@ class _PinnedRing(object):
                     pass
 
 
+class DeviceDivisor(object):
+    """gradient:div(n) (objective.lua:200) with n on the device: the address of an fp64 count (plus what keeps it alive).
+    utilities.rmsprop hands it to frcnn_scale_rmsprop_dev."""
+
+    def __init__(self, p, owner):
+        self.ptr = int(p)
+        self._owner = owner
+
+
 def _dist():
     """The exchange back end of the step: the library's own communicator when one is active (comm.activate: RCCL through
     the C ABI, what a LuaJIT host uses), else an initialised torch.distributed process group, else None."""
@@ -194,17 +203,13 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     acc_pin = torch.zeros(8, dtype=torch.float64).pin_memory()
     acc_event = torch.cuda.Event()
     L = _lib.load()
-    # Data parallel: the four example counts are host-side numbers known before any kernel runs; they are summed over
-    # the ranks on a CPU (gloo) group of their own, so that the divisor of gradient:div(n) never needs the GPU stream
-    # and the whole step stays asynchronous (no host read-back between the backward pass and the optimiser step).
-    d0 = _dist()
-    host_group = None
-    if d0 is not None and hasattr(d0, "new_group") and not os.environ.get("FRCNN_DP_SYNC_TAIL"):
-        try:
-            host_group = d0.new_group(backend="gloo")
-        except Exception as e:  # no usable CPU transport: the (synchronous) all-reduce of the 8 statistics still works
-            sys.stderr.write("frcnn: gloo group unavailable (%s); using the synchronous statistics exchange\n" % e)
-            host_group = None
+    # Data parallel, device tail: the four example counts of objective.lua:194-198 are host-side numbers known before
+    # any kernel runs.  They are uploaded into the unused slots 2, 3, 6, 7 of the accumulator vector at the start of the
+    # pass (instead of zeroing it), travel through the same 8-element fp64 all-reduce as the loss sums, and the optimiser
+    # reads the divisor of gradient:div(cls_count) from the device (frcnn_scale_rmsprop_dev): no host read-back and no
+    # host-side collective between the backward pass and the update, with RCCL through torch.distributed or through the
+    # library's own communicator alike.  FRCNN_DP_SYNC_TAIL=1 keeps the synchronous exchange (read-back, then scale).
+    dev_tail_ok = not os.environ.get("FRCNN_DP_SYNC_TAIL")
 
     # data parallel: the slices of the deep backbone blocks are final long before the backward pass ends (the deepest
     # block's weight gradients come first); their all-reduces start behind a per-block event on an auxiliary stream
@@ -227,7 +232,6 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             weights.copy_(w)
         s = stream_ptr()
         _lib.call("frcnn_zero", ptr(gradient), gradient.numel() * 4, s)  # :49
-        acc_dev.zero_()
         cls_count = reg_count = creg_count = ccls_count = 0
         pnet.training()  # :61-62
         cnet.training()
@@ -235,8 +239,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         next_batch[0] = None
         pending = []
         early_copy = False
-        counts_cpu = counts_work = None
-        if host_group is not None and _dist() is not None:
+        dev_tail = (dev_tail_ok and defer == "fold" and _dist() is not None and getattr(gradient, "is_cuda", False))
+        c4 = None
+        if dev_tail:
             from .synthetic import clean_examples, output_map_sizes
             c4 = [0.0, 0.0, 0.0, 0.0]   # cls, reg, creg, ccls exactly as accumulated below (:194-198)
             for x in batch:
@@ -244,8 +249,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 sizes = output_map_sizes(model, shp[1], shp[2])
                 np_, nn_ = len(clean_examples(x["positive"], sizes)), len(clean_examples(x["negative"], sizes))
                 c4[0] += np_ + nn_; c4[1] += np_; c4[2] += np_; c4[3] += 1
-            counts_cpu = torch.tensor(c4, dtype=torch.float64)
-            counts_work = _dist().all_reduce(counts_cpu, group=host_group, async_op=True)
+            init = np.array([0.0, 0.0, c4[0], c4[1], 0.0, 0.0, c4[2], c4[3]], dtype=np.float64)
+            hinit, staged = pinned.stage(init.view(np.uint8))
+            _lib.call("frcnn_memcpy_h2d", ptr(acc_dev), C.c_void_p(hinit), 64, s)
+            staged()
+        else:
+            acc_dev.zero_()
         for bi, x in enumerate(batch):
             last = bi == len(batch) - 1   # (by position: an iterator may hand out the same pooled image twice)
             img = to_device(x["img"])  # :66
@@ -369,24 +378,17 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         counts = (cls_count, reg_count, creg_count, ccls_count)
         if not single:   # the rest of the gradient is final too: its exchange starts before the host read-back below
             pending[:] = allreduce_begin_rest(gradient, pending)
-        if not single and counts_work is not None:
-            # asynchronous data-parallel tail: accumulators reduced on the device, counts already reduced on the host
+        if dev_tail:
+            # asynchronous data-parallel tail: loss sums AND counts reduced on the device in one 8-element all-reduce
             assert [float(v) for v in (cls_count, reg_count, creg_count, ccls_count)] == c4, "count bookkeeping diverged"
             acc_work = _dist().all_reduce(acc_t, async_op=True)
-            counts_work.wait()
-            gcounts = tuple(counts_cpu.tolist())
             for pnd in pending:
-                pnd[2].wait()           # NCCL: the current stream waits, the host does not
+                pnd[2].wait()           # RCCL: the current stream waits, the host does not
             acc_work.wait()
-            gs = 1.0 / gcounts[0] if gcounts[0] > 0 else None
-            if gs is not None and defer != "fold":
-                _lib.call("frcnn_scale", ptr(gradient), gradient.numel(), gs, stream_ptr())  # :200
             acc_pin.copy_(acc_t, non_blocking=True)
             acc_event.record()
-            fin = lambda: finish(None, gcounts, (), True, reduced=True)
-            if defer == "fold":
-                return (fin, gs) if gs is not None else fin
-            return fin if defer else (lambda r: (lambda: r))(fin())
+            fin = lambda: finish(None, None, (), True, reduced=True)
+            return (fin, DeviceDivisor(acc_dev.ptr + 2 * 8, acc_t))   # slot 2 = the all-reduced cls_count (:200)
         if single and defer:
             if not early_copy:
                 acc_pin.copy_(acc_t, non_blocking=True)
@@ -412,6 +414,8 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 next_batch[0] = batch_iterator.nextTraining()
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
+        if counts is None:   # device tail: the (all-reduced) counts sit in the slots the kernels leave alone
+            counts = (a[2], a[3], a[6], a[7])
         cls_count, reg_count, creg_count, ccls_count = counts
         tot = np.array([a[0], a[1], cls_count, reg_count, a[4], creg_count, a[5], ccls_count], dtype=np.float64)
         if not reduced:   # (asynchronous data-parallel tail: gradient, accumulators and counts are already summed)

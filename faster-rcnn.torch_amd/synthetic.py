@@ -67,8 +67,16 @@ class SyntheticBatchIterator(object):
     """nextTraining() -> list of {img, positive, negative}.  `images_per_batch` images per call; with
     data parallelism rank r of world_size W takes images r, r+W, ... of the step's list."""
 
-    def __init__(self, model, H=450, W=800, images_per_batch=1, rank=0, world_size=1, pool=4, device_images=True):
+    def __init__(self, model, H=450, W=800, images_per_batch=1, rank=0, world_size=1, pool=4, device_images=True,
+                 upload=False):
+        """device_images: the frames live in HBM (the bench contract: inputs resident when the timed region starts).
+        upload: the frames live in page-locked host memory and every nextTraining() brings its frame over PCIe -- the
+        `x.img:cuda()` of objective.lua:66 -- asynchronously: a copy stream fills a ring of three device buffers one step
+        ahead (a buffer is rewritten only after the step that read it has run), the consumer's stream waits for the
+        copy's event."""
         self.cfg = model["cfg"]
+        self.upload = bool(upload)
+        self._ring = None
         self.anchors = Anchors(model["pnet"], self.cfg["scales"])
         self.H, self.W = H, W
         self.images_per_batch = images_per_batch
@@ -81,10 +89,40 @@ class SyntheticBatchIterator(object):
             rois = synthetic_rois(self.cfg, W, H, 4, 7, idx)
             pos, neg = assemble_examples(self.anchors, self.cfg, rois, W, H, rng)
             img = synthetic_image(H, W, idx)
-            if device_images:
+            if self.upload:
+                import torch
+                img = torch.from_numpy(img).pin_memory()
+            elif device_images:
                 from .tensor import DeviceTensor
                 img = DeviceTensor.from_numpy(img)
             self.pool.append(dict(img=img, positive=pos, negative=neg, rois=rois))
+
+    def _begin_uploads(self, frames_per_call):
+        """Once per nextTraining() call in upload mode.  Call c is made when step c-1 is fully queued; the buffers it fills
+        were read by step c-3, i.e. by work queued before the mark recorded at call c-2."""
+        import torch
+        if self._ring is None:
+            proto = self.pool[0]["img"]
+            self._ring = dict(bufs=[torch.empty_like(proto, device="cuda") for _ in range(3 * frames_per_call)], k=0,
+                              stream=torch.cuda.Stream(), marks=[])
+        r = self._ring
+        mark = torch.cuda.Event(); mark.record(torch.cuda.current_stream())
+        if len(r["marks"]) >= 2:
+            r["stream"].wait_event(r["marks"][-2])
+        r["marks"] = (r["marks"] + [mark])[-2:]
+
+    def _uploaded(self, x):
+        """x with img replaced by a device buffer that the copy queued here will have filled when the consumer's stream
+        gets to it (objective.lua:66 `x.img:cuda()`, asynchronous)."""
+        import torch
+        r = self._ring
+        k = r["k"]; r["k"] = (k + 1) % len(r["bufs"])
+        with torch.cuda.stream(r["stream"]):
+            r["bufs"][k].copy_(x["img"], non_blocking=True)
+            done = torch.cuda.Event(); done.record(r["stream"])
+        torch.cuda.current_stream().wait_event(done)
+        y = dict(x); y["img"] = r["bufs"][k]
+        return y
 
     def nextTraining(self, count=None):
         """images_per_batch images (benchmarks: 1); with images_per_batch=None the reference's
@@ -92,6 +130,7 @@ class SyntheticBatchIterator(object):
         examples in total."""
         batch = []
         if self.images_per_batch is None:
+            assert not self.upload, "upload mode draws a fixed number of frames per call"
             count = count or self.cfg["batch_size"]
             while count > 0:
                 x = self.pool[self.i % len(self.pool)]
@@ -99,7 +138,10 @@ class SyntheticBatchIterator(object):
                 batch.append(x)
                 count -= max(1, len(x["positive"]) + len(x["negative"]))   # (an empty image still advances the loop)
             return batch
+        if self.upload:
+            self._begin_uploads(self.images_per_batch)
         for _ in range(self.images_per_batch):
-            batch.append(self.pool[self.i % len(self.pool)])
+            x = self.pool[self.i % len(self.pool)]
+            batch.append(self._uploaded(x) if self.upload else x)
             self.i += 1
         return batch

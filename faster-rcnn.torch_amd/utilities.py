@@ -44,7 +44,10 @@ def rmsprop(opfunc, x, state):
     begin = getattr(opfunc, "begin_fold", None)
     if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued,
         finish, dfdx, gscale = begin(x)   # and gradient:div(n) rides on the update's own pass over the vectors
-        if gscale is None:
+        if hasattr(gscale, "ptr"):   # data parallel: the divisor is the all-reduced count, still on the device
+            _lib.call("frcnn_scale_rmsprop_dev", ptr(x), ptr(dfdx), ptr(gscale.ptr), ptr(state["m"]), x.numel(), lr, alpha,
+                      eps, stream_ptr())
+        elif gscale is None:
             _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())
         else:
             _lib.call("frcnn_scale_rmsprop", ptr(x), ptr(dfdx), gscale, ptr(state["m"]), x.numel(), lr, alpha, eps,

@@ -209,6 +209,11 @@ int frcnn_rmsprop(float *x, const float *g, float *m, long long n, float lr, flo
  * gradient afterwards, exactly as after the two separate calls. */
 int frcnn_scale_rmsprop(float *x, float *g, float gscale, float *m, long long n, float lr, float alpha,
                         float eps, void *stream);
+/* The same with the divisor read from the device: gscale = 1 / *gcount_dev (a count of 0 leaves g unscaled).  For the
+ * data-parallel step, where objective.lua:200's cls_count is the all-reduced sum that frcnn_allreduce_f64 left in
+ * the accumulator vector: the update is queued behind the exchange without any host read-back. */
+int frcnn_scale_rmsprop_dev(float *x, float *g, const double *gcount_dev, float *m, long long n, float lr,
+                            float alpha, float eps, void *stream);
 
 /* ---- model runtime: models/model_utilities.lua:3-136 --------------------------------- */
 typedef struct {
@@ -372,8 +377,11 @@ int frcnn_anchors_assemble(frcnn_anchors *, const double *rois_host, int nroi, d
  * at objective.lua:52-58 (frcnn_allreduce_f64), then every rank applies the identical optim.rmsprop step.
  * One process per GPU; the communicator runs RCCL (xGMI inside a node), bound at first use (dlopen "librccl.so.1").
  * Rendezvous: rank 0 creates a 128-byte id (frcnn_comm_get_unique_id) and hands it to the other ranks by any
- * host-side channel; frcnn_comm_init_rank_file does that through a file on a path every rank can see (rank 0 writes
- * it atomically, the others poll up to timeout_ms; the path must not exist from a previous job).
+ * host-side channel; frcnn_comm_init_rank_file does that through a file on a path every rank can see: rank 0 removes
+ * whatever a previous job left there and writes {id, job nonce, its pid} atomically; the others poll up to timeout_ms
+ * and accept a file only when its nonce equals theirs and (same host) its writer is still alive, so an id left
+ * behind by a crashed job is never joined.  The nonce is the environment variable FRCNN_COMM_NONCE (any string
+ * common to the ranks of ONE job, e.g. the launcher's pid and start time; default "0").
  * frcnn_comm_init_rank* is a collective call: every rank of the job makes it, after frcnn_set_device.
  * The all-reduces are IN PLACE sums, asynchronous on `stream`, ordered like any other work of that stream. */
 #define FRCNN_COMM_ID_BYTES 128
@@ -384,6 +392,9 @@ int frcnn_comm_init_rank(frcnn_comm **out_host, int nranks, int rank, const void
 int frcnn_comm_init_rank_file(frcnn_comm **out_host, int nranks, int rank, const char *path, int timeout_ms);
 int frcnn_comm_destroy(frcnn_comm *);
 int frcnn_comm_info(const frcnn_comm *, int *nranks_host, int *rank_host);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): lets a bench
+ * or a test assert that N ranks on N distinct devices really joined.  Any pointer may be NULL. */
+int frcnn_comm_query(const frcnn_comm *, int *count_host, int *user_rank_host, int *device_host);
 int frcnn_allreduce_f32(frcnn_comm *, float *buf, long long n, void *stream);
 int frcnn_allreduce_f64(frcnn_comm *, double *buf, long long n, void *stream);
 /* one-time weight broadcast after load_model / restore (main.lua:92-98) so that every replica starts identical */

@@ -42,6 +42,71 @@ def test_file_rendezvous_times_out_with_a_message(F, tmp_path):
         F._lib.call("frcnn_comm_init_rank", C.byref(C.c_void_p()), 2, 5, C.create_string_buffer(128))   # rank >= nranks
 
 
+def _write_id_file(path, nonce, pid_alive):
+    """rank 0's side of the rendezvous in a child process with its own FRCNN_COMM_NONCE; the child exits (dead writer)
+    unless pid_alive, in which case it lingers until the file is removed."""
+    import subprocess, sys
+    code = ("import ctypes as C, os, sys, time; sys.path.insert(0, %r); import frcnn_amd as F; "
+            "F._lib.call('frcnn_comm_exchange_id_file', %r.encode(), 0, C.create_string_buffer(bytes([7]) * 128, 128), 1000); "
+            "print('written', flush=True); "
+            + ("[time.sleep(0.05) for _ in range(600) if os.path.exists(%r)]" % path if pid_alive else "pass")) % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    env = dict(os.environ, FRCNN_COMM_NONCE=nonce)
+    p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE)
+    assert p.stdout.readline().strip() == b"written"
+    return p
+
+
+def test_stale_id_files_are_not_joined(F, tmp_path, monkeypatch):
+    """an id file a crashed job left behind (dead writer, or another job's nonce) must not be accepted; a
+    live writer of THIS job is; and rank 0 replaces whatever it finds."""
+    path = str(tmp_path / "id")
+    monkeypatch.setenv("FRCNN_COMM_NONCE", "job-A")
+    # 1) same nonce, but the writer is dead (the job crashed and was restarted under the same launcher id)
+    p = _write_id_file(path, "job-A", pid_alive=False); p.wait(30)
+    assert os.path.exists(path)
+    with pytest.raises(F.FrcnnError, match="writer is gone"):
+        F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, C.create_string_buffer(128), 300)
+    # 2) a live writer, another job's nonce
+    p = _write_id_file(path, "job-B", pid_alive=True)
+    try:
+        with pytest.raises(F.FrcnnError, match="another job"):
+            F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, C.create_string_buffer(128), 300)
+    finally:
+        os.unlink(path); p.wait(60)
+    # 3) a live writer of this job is accepted
+    p = _write_id_file(path, "job-A", pid_alive=True)
+    try:
+        buf = C.create_string_buffer(128)
+        F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, buf, 2000)
+        assert buf.raw == bytes([7]) * 128
+    finally:
+        os.unlink(path); p.wait(60)
+    # 4) rank 0 overwrites a stale file with its own record
+    open(path, "wb").write(b"x" * 144)
+    F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 0, C.create_string_buffer(bytes(range(128)), 128), 1000)
+    buf = C.create_string_buffer(128)
+    F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, buf, 2000)   # (this process is the live writer)
+    assert buf.raw == bytes(range(128)) and os.path.getsize(path) == 144
+
+
+def test_bench_refuses_a_world_it_cannot_run():
+    """VERDICT r2 missing #1: `bench.py --gpus N` must never print an N=1 line labelled otherwise.  Without N devices on
+    the node it exits non-zero with a message (here: no device at all; on a 1-GPU box: tests/test_gpu_rccl2.py)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this node could run two ranks")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs 2 HIP devices" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "mislabelled" in r.stderr and r.stdout.strip() == ""
+
+
 @pytest.mark.gpu
 def test_one_rank_communicator_on_the_gpu(F, tmp_path):
     import torch
@@ -50,6 +115,10 @@ def test_one_rank_communicator_on_the_gpu(F, tmp_path):
         n, r = C.c_int(), C.c_int()
         F._lib.call("frcnn_comm_info", comm.h, C.byref(n), C.byref(r))
         assert (n.value, r.value) == (1, 0)
+        assert comm.query() == (1, 0, torch.cuda.current_device())    # ncclCommCount / UserRank / CuDevice
+        assert comm.gather_ints(41) == [41]
+        with pytest.raises(F.FrcnnError):
+            comm.broadcast(torch.zeros(4, dtype=torch.float64, device="cuda"))    # frcnn_broadcast_f32 counts 4-byte elements
         g = torch.randn(26784106, device="cuda")          # the flat gradient of vgg_small / duplo (107 MB)
         want = g.clone()
         w1 = comm.all_reduce(g[1000:5_000_000], async_op=True)    # buckets, as the objective issues them
