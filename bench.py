@@ -237,6 +237,71 @@ def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
     return out
 
 
+def large_leg(F, with_cpu, steps=12):
+    """BASELINE config 5's one-GPU workload: vgg_large (models/vgg_large.lua:5-22), one synthetic 3x600x1000 frame per step,
+    config/imagenet.lua values (200 classes, scales 48..384, 6x6 ROI pooling): images/sec of the training step, the live
+    roofline fraction of its dominant kernel, and -- one sample, ~30 s -- the CPU restatement's step on the same frame with
+    the parity of loss and gradient."""
+    import torch
+    H, W = 600, 1000
+    cfg = dict(F.imgnet_cfg)
+    model = F.vgg_large(cfg)
+    weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
+    it = F.SyntheticBatchIterator(model, H=H, W=W, images_per_batch=1, pool=4)
+    stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+    f = F.create_objective(model, weights, gradient, it, stats)
+    state = dict(learningRate=1e-4, alpha=0.9)
+    for _ in range(6):
+        F.rmsprop(f, weights, state)
+    torch.cuda.synchronize()
+    conv_mask = sum(1 << F._lib.KC_NAMES.index(n) for n in CONV_CLASSES)
+    nk = len(F._lib.KC_NAMES)
+    sink = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+    F._lib.call("frcnn_prof_collect", *sink)      # (drain)
+    sampled = 0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        on = i % 4 == 0
+        if on:
+            F._lib.call("frcnn_prof_enable", conv_mask); sampled += 1
+        F.rmsprop(f, weights, state)
+        if on:
+            F._lib.call("frcnn_prof_enable", 0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    launches, ms, fl, by = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+    F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
+    k = F._lib.KC_NAMES.index("conv_x3")
+    peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
+    _, train_flops = conv_flops_per_image(model, H, W)
+    out = dict(metric="images/sec (vgg_large 1000x600 fwd+bwd, config/imagenet.lua: 200 classes, 45 015 anchors, 6x6 ROI pooling)",
+               value=round(1.0 / dt, 2), ms_per_step=round(dt * 1e3, 3), steps=steps,
+               examples_per_image=[len(b["positive"]) + len(b["negative"]) for b in it.pool],
+               conv_gflop_per_image=round(train_flops / 1e9, 1), whole_step_conv_tflops=round(train_flops / 1e12 / dt, 1),
+               roofline=dict(bound="mfma", kernel="conv_x3_kernel", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                             frac=round(ach / peak, 4), launches_per_step=launches[k] / max(sampled, 1),
+                             avg_launch_ms=round(ms[k] / max(launches[k], 1), 4)))
+    if with_cpu:
+        O, oracle_model, oracle_tables = _oracle()
+        om = oracle_model(O, cfg, model["layers"], model["anchor_nets"], model["class_layers"])
+        nat = model["native"]
+        w0 = nat.init_parameters(42)
+        bn0 = np.concatenate([np.zeros(1024, np.float32), np.ones(1024, np.float32)])
+        inp = parity_inputs(F, cfg, model, H, W)
+        tables = oracle_tables(inp["pos"], inp["neg"], inp["rois"])
+        dtc, o_loss, o_grad = cpu_train_step(O, om, tables, w0, inp, bn0)
+        g_loss, g_grad = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
+        rel = float(np.linalg.norm(g_grad.astype(np.float64) - o_grad) / np.linalg.norm(o_grad.astype(np.float64)))
+        out["cpu_baseline"] = dict(value=round(1.0 / dtc, 5), unit="images/sec", cores=O.get_threads(), kind="port",
+                                   sample="ONE training step of the CPU restatement on the same 3x600x1000 frame, %d examples (%.1f s, no warm-up)" % (inp["R"], dtc))
+        out["parity"] = dict(loss_gpu=g_loss, loss_oracle=float(o_loss), gradient_rel_l2=rel, examples=inp["R"],
+                             ok=bool(abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3))
+    del f, it, model, weights, gradient
+    torch.cuda.empty_cache()
+    return out
+
+
 def nms_leg(F, with_cpu):
     """BASELINE.md 4(c): nms() alone at n = 300 / 2000 / 6000 / 26544 boxes (unique y2 keys), thresholds 0.25 and 0.1;
     boxes resident in HBM, ids read back; median of 10.  CPU restatement: 1 thread (nms.lua is a serial loop)."""
@@ -563,9 +628,11 @@ def main():
                                  loss_gpu=g_loss, loss_oracle=float(o_loss), loss_tolerance=1e-5,
                                  gradient_rel_l2=rel, gradient_tolerance=1e-3, examples=inp["R"], ok=bool(ok))
             if not args.no_other_legs:
-                out["other_legs"] = dict(inference=inference_leg(F, cfg, model, weights, w0, bn0, True), nms=nms_leg(F, True))
+                out["other_legs"] = dict(inference=inference_leg(F, cfg, model, weights, w0, bn0, True), nms=nms_leg(F, True),
+                                         vgg_large=large_leg(F, True))
                 ok = ok and all(r["ids_identical"] for r in out["other_legs"]["nms"]) \
-                    and out["other_legs"]["inference"]["parity"]["nms_ids_identical_on_gpu_boxes"]
+                    and out["other_legs"]["inference"]["parity"]["nms_ids_identical_on_gpu_boxes"] \
+                    and out["other_legs"]["vgg_large"]["parity"]["ok"]
         print(json.dumps(out))
         if not ok:
             sys.stderr.write("bench.py: PARITY FAILURE (see the 'parity' / 'other_legs' objects of the JSON line)\n")

@@ -80,6 +80,7 @@ _SIGS = {
     "frcnn_model_param_count": ([vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], C.c_int),
     "frcnn_model_param_table": ([vp, vp, C.c_int, C.POINTER(C.c_int)], C.c_int),
     "frcnn_model_localizer_layers": ([vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)], C.c_int),
+    "frcnn_model_debug_buffer": ([vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_longlong)], C.c_int),
     "frcnn_pnet_forward": ([vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_ulonglong, vp], C.c_int),
     "frcnn_pnet_forward_async_heads": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp], C.c_int),
     "frcnn_pnet_output": ([vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),

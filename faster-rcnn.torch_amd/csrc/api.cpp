@@ -182,21 +182,13 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
                          const float* weight, const float* bias, int O, int k, int pad, float* out,
                          void* stream) {
   float* wf = nullptr;
-  if (!get_winograd() && conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
+  if (conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
     FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
     int rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream));
     if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wf);
     return rcx;
-  }
-  if (conv_wino_eligible(C, H, W, O, k, pad)) {
-    FR_HIP(hipMalloc((void**)&wf, conv_wino_filter_floats(C, O) * 4));
-    int rcw = conv_wino_filter(weight, O, C, 0, wf, S(stream));
-    if (rcw == FRCNN_OK) rcw = conv_wino(in, C, H, W, in_slope, in_scale, wf, bias, O, out, OUT_STORE, 0, S(stream));
-    (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(wf);
-    return rcw;
   }
   FR_HIP(hipMalloc((void**)&wf, conv_pack_floats(C, O, k) * 4));
   int rc = conv_pack_weights(weight, O, C, k, wf, nullptr, S(stream));
@@ -208,21 +200,13 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
 int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const float* weight, int C, int k,
                                 int pad, float* gin, int accumulate, void* stream) {
   float* wd = nullptr;
-  if (!get_winograd() && conv_x3_eligible(O, C, k)) {
+  if (conv_x3_eligible(O, C, k)) {
     FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C, k)));
     int rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream));
     if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wd);
     return rcx;
-  }
-  if (conv_wino_eligible(O, Ho, Wo, C, k, k - 1 - pad)) {
-    FR_HIP(hipMalloc((void**)&wd, conv_wino_filter_floats(O, C) * 4));
-    int rcw = conv_wino_filter(weight, O, C, 1, wd, S(stream));
-    if (rcw == FRCNN_OK) rcw = conv_wino(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
-    (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(wd);
-    return rcw;
   }
   FR_HIP(hipMalloc((void**)&wd, conv_pack_floats(O, C, k) * 4));
   int rc = conv_pack_weights(weight, O, C, k, nullptr, wd, S(stream));

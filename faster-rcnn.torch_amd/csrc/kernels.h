@@ -34,20 +34,6 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
                double algo_flops, hipStream_t s, int ws_slot = 0,  // ws_slot: split-K workspace (0 | 1)
                const IgemmPool* pool = nullptr, bool* pool_fused = nullptr);
 
-// ---- Winograd F(2x2, 3x3) form of the 3x3 / pad 1 convolution (wino.hip): same result as conv_igemm up to rounding,
-// 2.25x fewer multiplications.  U = transformed filters (conv_wino_filter; transposed != 0: the input-gradient filters).
-bool conv_wino_eligible(int Cin, int H, int W, int M, int k, int pad);
-void set_winograd(int on);   // option "winograd": 0 off (default), 1 eligible forward launches (+ input gradients with FRCNN_WINO_DGRAD=1)
-int get_winograd();
-size_t conv_wino_filter_floats(int Kchan, int M);
-int conv_wino_filter(const float* w, int O, int C, int transposed, float* U, hipStream_t s);
-struct WinoFilterJob { long w_off; float* dst; int O, C, transposed, Mpad, Kpad, blk_begin, nblk; };
-WinoFilterJob conv_wino_filter_job(long w_off, int O, int C, int transposed, float* dst);
-int conv_wino_filter_assign_blocks(WinoFilterJob* jobs, int njobs);   // -> grid size
-int conv_wino_filter_multi(const float* weights, const WinoFilterJob* jobs_dev, int njobs, int grid, hipStream_t s);
-int conv_wino(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* U,
-              const float* bias, int M, float* out, int out_mode, double algo_flops, hipStream_t s);
-
 // ---- split-bf16 operand form of the 3x3 convolution (convx.hip): fp32 tensors in and out, every product formed from six
 // exact bf16 x bf16 partial products (three-way split of both operands) accumulated in fp32 on the bf16 matrix cores -- the
 // accuracy of the fp32 matrix-core kernel at 6/16 of its matrix-pipe time.  wp = stages packed by conv_x3_pack*.

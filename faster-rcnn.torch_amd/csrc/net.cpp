@@ -46,8 +46,6 @@ struct Conv {
   long w_off, b_off, a_off;   // flat offsets; a_off = PReLU slope following this conv (-1: none)
   int block, step;            // backbone position (block -1 for head convs)
   DevBuf wf, wd;              // packed weights (forward / input-gradient)
-  DevBuf wu, wud;             // Winograd-transformed filters (wino.hip) for the launches that take that form
-  bool wino_f = false, wino_d = false;
   DevBuf wx, wxd;             // split-bf16 operand stages (convx.hip) for the launches that take that form
   bool x_f = false, x_d = false;
   DevBuf x, gx;               // pre-activation output and its gradient
@@ -101,8 +99,6 @@ struct frcnn_model {
   DevBuf zero_arena;           // delta_outputs[1..n+1] followed by the pooled-map gradients: zeroed by ONE memset each
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
-  DevBuf wino_jobs;            // device table of WinoFilterJob: [training jobs (fwd + dgrad filters)] [forward-only jobs]
-  int n_wino_all = 0, n_wino_fwd = 0, wino_grid_all = 0, wino_grid_fwd = 0;
   DevBuf x3_jobs;              // device table of PackXJob, same arrangement
   int n_x3_all = 0, n_x3_fwd = 0, x3_grid_all = 0, x3_grid_fwd = 0;
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
@@ -226,23 +222,13 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
     FR_TRY(c.wd.ensure(conv_pack_floats(c.Cout, c.Cin, c.k) * 4));
     FR_HIP(hipMemset(c.wd.p, 0, c.wd.bytes));
   }
-  // 3x3 / pad 1 layers with enough 16 x 16-pixel blocks take the Winograd F(2x2, 3x3) form (2.25x fewer MFMA cycles)
-  c.wino_f = c.block >= 0 && conv_wino_eligible(c.Cin, H, W, c.Cout, c.k, c.pad);
-  // The input-gradient launches keep the direct kernel by default: a Winograd block owns its CU (148 KB of LDS, 512
-  // registers per lane), so the weight-gradient launches of the side stream cannot run beside it -- measured on the training
-  // step: 228.1 images/s with both passes in Winograd form, 227.0 with the forward pass only, but the direct kernel's share
-  // of the matrix pipe while it shares the CUs (roofline.frac, live) drops from 0.59 to 0.53.  FRCNN_WINO_DGRAD=1 turns it on.
-  static const int wino_dgrad = getenv("FRCNN_WINO_DGRAD") ? atoi(getenv("FRCNN_WINO_DGRAD")) : 0;
-  c.wino_d = wino_dgrad && c.block >= 0 && need_dgrad && conv_wino_eligible(c.Cout, c.Ho, c.Wo, c.Cin, c.k, c.k - 1 - c.pad);
   // 3x3 launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time
   // (the 5x5 / 7x7 anchor nets keep the fp32 kernel: on their 25x46 / 23x44 maps the split form's 8x10-pixel tiles fill 63 %
   // of an MFMA tile and its 7.2 M weights would have to be split every step -- measured 3.59 ms/step with them against 3.38)
-  c.x_f = !c.wino_f && c.k == 3 && conv_x3_eligible(c.Cin, c.Cout, c.k);
-  c.x_d = !c.wino_d && c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
+  c.x_f = c.k == 3 && conv_x3_eligible(c.Cin, c.Cout, c.k);
+  c.x_d = c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
   if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout, c.k)));
   if (c.x_d) FR_TRY(c.wxd.ensure(conv_x3_pack_bytes(c.Cout, c.Cin, c.k)));
-  if (c.wino_f) FR_TRY(c.wu.ensure(conv_wino_filter_floats(c.Cin, c.Cout) * 4));
-  if (c.wino_d) FR_TRY(c.wud.ensure(conv_wino_filter_floats(c.Cout, c.Cin) * 4));
   return FRCNN_OK;
 }
 
@@ -324,21 +310,6 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     FR_TRY(m->pack_jobs.ensure(both.size() * sizeof(PackJob)));
     FR_HIP(hipMemcpy(m->pack_jobs.p, both.data(), both.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
-  {  // Winograd filter-transform jobs (one table-driven launch per forward pass)
-    std::vector<WinoFilterJob> all, fwd;
-    for (auto& c : m->convs) {
-      if (c.wino_f) { all.push_back(conv_wino_filter_job(c.w_off, c.Cout, c.Cin, 0, c.wu.f())); fwd.push_back(all.back()); }
-      if (c.wino_d) all.push_back(conv_wino_filter_job(c.w_off, c.Cout, c.Cin, 1, c.wud.f()));
-    }
-    m->n_wino_all = (int)all.size(); m->n_wino_fwd = (int)fwd.size();
-    m->wino_grid_all = conv_wino_filter_assign_blocks(all.data(), m->n_wino_all);
-    m->wino_grid_fwd = conv_wino_filter_assign_blocks(fwd.data(), m->n_wino_fwd);
-    all.insert(all.end(), fwd.begin(), fwd.end());
-    if (!all.empty()) {
-      FR_TRY(m->wino_jobs.ensure(all.size() * sizeof(WinoFilterJob)));
-      FR_HIP(hipMemcpy(m->wino_jobs.p, all.data(), all.size() * sizeof(WinoFilterJob), hipMemcpyHostToDevice));
-    }
-  }
   {  // split-bf16 pack jobs
     std::vector<PackXJob> all, fwd;
     auto add = [&](Conv& c) {
@@ -386,7 +357,7 @@ int frcnn_model_create(const frcnn_model_desc* desc, frcnn_model** out) {
 
 int frcnn_model_destroy(frcnn_model* m) {
   if (!m) return FRCNN_OK;
-  auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.wu.release(); c.wud.release(); c.wx.release(); c.wxd.release(); c.x.release(); c.gx.release(); };
+  auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.wx.release(); c.wxd.release(); c.x.release(); c.gx.release(); };
   for (auto& c : m->convs) rel(c);
   for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); }
   for (auto& h : m->heads) {
@@ -397,7 +368,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release();
   }
-  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->wino_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
+  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
@@ -460,7 +431,6 @@ int frcnn_get_option(const char* name, int* value) {
   FR_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
-  if (strcmp(name, "winograd") == 0) { *value = get_winograd(); return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
@@ -471,7 +441,6 @@ int frcnn_set_option(const char* name, int value) {
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
-  if (strcmp(name, "winograd") == 0) { set_winograd(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   FR_CHECK(false, "set_option: unknown option '%s'", name);
   return FRCNN_OK;
 }
@@ -600,11 +569,6 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
   else
     FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
-  // transformed filters of the Winograd launches (weights change every optimiser step): one table-driven launch
-  if (training)
-    FR_TRY(conv_wino_filter_multi(w, (const WinoFilterJob*)m->wino_jobs.p, m->n_wino_all, m->wino_grid_all, s));
-  else
-    FR_TRY(conv_wino_filter_multi(w, (const WinoFilterJob*)m->wino_jobs.p + m->n_wino_all, m->n_wino_fwd, m->wino_grid_fwd, s));
   if (training)
     FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p, m->n_x3_all, m->x3_grid_all, s));
   else
@@ -625,8 +589,6 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
                       (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
       if (c.x_f)
         FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.k, c.pad, c.x.f(), OUT_STORE, 0, s));
-      else if (c.wino_f)
-        FR_TRY(conv_wino(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wu.f(), w + c.b_off, c.Cout, c.x.f(), OUT_STORE, 0, s));
       else
         FR_TRY(conv_igemm(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wf.f(), w + c.b_off, c.Cout, c.k, c.pad,
                           c.x.f(), OUT_STORE, 0, s, 0, last ? &pl : nullptr, last ? &pooled_in_conv : nullptr));
@@ -692,6 +654,34 @@ int frcnn_pnet_output(frcnn_model* m, int i, float** ptr, int* C, int* H, int* W
     Block& b = m->blocks.back();
     *ptr = b.pooled.f(); *C = m->d.filters[m->d.nblocks - 1]; *H = b.Hp; *W = b.Wp;
   }
+  return FRCNN_OK;
+}
+
+int frcnn_model_debug_buffer(frcnn_model* m, int kind, int index, void** ptr, long long* bytes) {
+  FR_CHECK(m && ptr && bytes, "frcnn_model_debug_buffer: NULL argument");
+  const DevBuf* b = nullptr;
+  size_t n = 0;
+  switch (kind) {
+    case 0: {
+      FR_CHECK(index >= 0 && index < (int)m->convs.size() && m->H > 0, "debug_buffer: backbone convolution %d (after a forward pass)", index);
+      const Conv& c = m->convs[index]; b = &c.x; n = (size_t)c.Cout * c.Ho * c.Wo * 4;
+    } break;
+    case 1: {
+      FR_CHECK(index >= 0 && index < (int)m->blocks.size() && m->H > 0, "debug_buffer: block %d (after a forward pass)", index);
+      const Block& k = m->blocks[index]; b = &k.pidx; n = (size_t)m->d.filters[index] * k.Hp * k.Wp;
+    } break;
+    case 2: {
+      FR_CHECK(index >= 0 && index < (int)m->heads.size() && m->H > 0, "debug_buffer: anchor net %d (after a forward pass)", index);
+      const Conv& c = m->heads[index].c3; b = &c.x; n = (size_t)c.Cout * c.Ho * c.Wo * 4;
+    } break;
+    case 3: {
+      FR_CHECK(index >= 0 && index < (int)m->cls.size() && m->R > 0, "debug_buffer: classification layer %d (after frcnn_cnet_forward)", index);
+      const ClsLayer& L = m->cls[index]; b = L.bn ? &L.pre : &L.lin; n = (size_t)m->R * L.n * 4;
+    } break;
+    default: FR_CHECK(false, "debug_buffer: unknown kind %d", kind);
+  }
+  FR_CHECK(b->p && b->bytes >= n, "debug_buffer: buffer not allocated yet");
+  *ptr = b->p; *bytes = (long long)n;
   return FRCNN_OK;
 }
 
@@ -941,8 +931,6 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
       if (c.x_d)
         FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s));
-      else if (c.wino_d)
-        FR_TRY(conv_wino(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wud.f(), nullptr, c.Cin, gin, gmode, fl, s));
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
                           c.k - 1 - c.pad, gin, gmode, fl, s));

@@ -356,6 +356,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 acc_pin.copy_(acc_t, non_blocking=True)
                 acc_event.record()
                 early_copy = True
+            debug["E"] = E
             pnet.backward(img, delta_outputs)  # :189
             if last and _dist() is not None and early_blocks and getattr(gradient, "is_cuda", False):
                 if aux_stream[0] is None:
@@ -402,6 +403,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
 
     dp_gscale = [None]
+    debug = dict(scratch=scratch, E=0)
     next_batch = [None]
     prefetch_batches = os.environ.get("FRCNN_PREFETCH_BATCH", "1") != "0"
 
@@ -450,6 +452,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         r = run(w, "fold")
         return (r[0], gradient, r[1]) if isinstance(r, tuple) else (r, gradient, None)
     lossAndGradient.begin_fold = begin_fold
+    lossAndGradient.debug = debug   # (tests: the scratch buffers and the example count of the image being processed)
     return lossAndGradient
 
 

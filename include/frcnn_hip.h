@@ -48,9 +48,6 @@ int frcnn_device_name(char *buf_host, int len);
  * gradient partials of the activation backward passes, the scatter-adds of the ROI-pooling and sparse anchor-net backward
  * passes, the anchor deltas of two examples naming one anchor) switch to order-independent forms -- partials folded in
  * index order, gathers, 64-bit fixed-point accumulation -- so that two runs on the same inputs are bit-identical.
- * "winograd" (default 0; environment FRCNN_WINO): 3x3 / pad 1 convolutions with enough 16 x 16-pixel blocks run in the
- * Winograd F(2x2, 3x3) form (2.25x fewer multiplications, same result to fp32 rounding); applies to the operator-level
- * entry points at once and to a model from its next (re)shaping on.
  * "split_bf16" (default 1; environment FRCNN_SPLIT_BF16): the 3x3 convolutions whose shapes fit (forward and input gradient:
  * input channels a multiple of 16, filters a multiple of 64; weight gradient: both multiples of 64) run in the split-operand
  * form: fp32 tensors in and out, fp32 accumulation, every fp32 product formed from six exact bf16 x bf16 partial products of
@@ -263,6 +260,15 @@ int frcnn_pnet_forward_async_heads(frcnn_model *, const float *weights, const fl
  * forward (callers that keep results must copy: objective.lua:119). */
 int frcnn_pnet_output(frcnn_model *, int i, float **ptr_host, int *C_host, int *H_host,
                       int *W_host);
+/* Inspection of what the last forward pass left in HBM -- for parity tests, which hand the path's DISCRETE decisions
+ * (max-pool window winners, PReLU branches) to the CPU restatement so that gradients can be compared at the strict
+ * tolerance (oracle/frcnn_oracle.h orc_set_decisions).  The pointer stays owned by the model and valid until the next
+ * forward pass of another image size.
+ *   kind 0: pre-activation output of backbone convolution `index` (float [O][Ho][Wo]; model_utilities.lua:8)
+ *   kind 1: arg-max of block `index`'s 2x2 ceil-mode max pool (unsigned char [C][Hp][Wp], value dy*2+dx; :23)
+ *   kind 2: pre-activation output of anchor net `index`'s k x k convolution (float [n][Ho][Wo]; :31)
+ *   kind 3: input of classification layer `index`'s PReLU (float [R][n]; :85-86), after frcnn_cnet_forward */
+int frcnn_model_debug_buffer(frcnn_model *, int kind, int index, void **ptr_host, long long *bytes_host);
 /* delta_outputs[i] (objective.lua:78-84): gradient buffers with the shapes of the outputs. */
 int frcnn_pnet_delta(frcnn_model *, int i, float **ptr_host);
 int frcnn_pnet_zero_deltas(frcnn_model *, void *stream);

@@ -174,6 +174,25 @@ void orc_cnet_backward(const orc_model *, const float *weights, const orc_cnet_s
  * neg_idx: int[nn][4]; neg_rect double[nn][4].  Examples must already be cleanAnchors()-ed.
  * acc: double[8] {cls_loss, reg_loss, cls_count, reg_count, creg_loss, creg_count,
  * ccls_loss, ccls_count} accumulated (objective.lua:52-58).  grad accumulates, NOT divided. */
+/* Decision injection -- TESTS ONLY.  Discrete choices of the path (max-pool window winner, adaptive max-pool cell
+ * winner, PReLU branch) that the caller wants taken as given (`inject`: the device's own choices) and / or written out
+ * as this restatement takes them (`record`: caller-allocated buffers of the same shapes, written during the next
+ * orc_pnet_forward / orc_cnet_forward / orc_train_image).  NULL entries (or a NULL struct) leave that decision to the
+ * restatement.  Global state: set, run, reset to (NULL, NULL).
+ *   pool_idx[b]   int32  [C][Hp][Wp]  flat y*W+x into the pooled layer's (activated) input plane, block b
+ *   conv_pos[i]   uint8  [O][Ho][Wo]  1 where backbone conv i's pre-activation takes the x > 0 branch
+ *   head_pos[h]   uint8  [n][Ho][Wo]  the same for anchor net h's k x k convolution
+ *   cnet_pos[l]   uint8  [R][n]       the same for classification layer l (PReLU input = BN output / Linear output)
+ *   roi_idx       int32  [R][planes*kh*kw] flat y*W+x into the last pooled map's plane (orc_train_image only) */
+typedef struct {
+  const int32_t *pool_idx[8];
+  const uint8_t *conv_pos[32];
+  const uint8_t *head_pos[8];
+  const uint8_t *cnet_pos[8];
+  const int32_t *roi_idx;
+} orc_decisions;
+void orc_set_decisions(const orc_decisions *inject, orc_decisions *record);
+
 void orc_train_image(const orc_model *, const float *weights, float *grad, const float *img,
                      int H, int W, const int *pos_idx, const double *pos_rect, int np,
                      const double *rois, const int *roi_class, int nroi, const int *neg_idx,

@@ -83,6 +83,41 @@ static tens tnew(int C, int H, int W) {
 }
 static long tnum(const tens *t) { return (long)t->C * t->H * t->W; }
 
+/* ---- decision injection (tests only; frcnn_oracle.h) -------------------------------------------------
+ * The path has three kinds of DISCRETE decisions -- the arg-max of a max-pooling window, the arg-max of an adaptive
+ * max-pooling cell, the branch of a PReLU -- that an fp32 evaluation and this fp64-accumulating one may take
+ * differently when two candidates (or an activation and zero) agree to rounding.  One differing decision re-routes a
+ * gradient path, which is not an arithmetic error of either side.  With a decision set injected, every such choice is
+ * TAKEN FROM THE CALLER (the device's own choices) and everything else is computed here as always, so that the
+ * comparison of the gradients tests the arithmetic at the strict tolerance; a second run without injection, recording
+ * its own choices, lets the test count how many differ. */
+static const orc_decisions *g_inject = NULL;
+static orc_decisions *g_record = NULL;
+void orc_set_decisions(const orc_decisions *inject, orc_decisions *record) { g_inject = inject; g_record = record; }
+
+static void prelu_fwd_d(const float *x, long n, float a, const uint8_t *pos, uint8_t *rec, float *y) {
+#pragma omp parallel for
+  for (long i = 0; i < n; ++i) {
+    int p = pos ? pos[i] != 0 : x[i] > 0.0f;
+    if (rec) rec[i] = (uint8_t)(x[i] > 0.0f);
+    y[i] = p ? x[i] : a * x[i];
+  }
+}
+static double prelu_bwd_d(const float *x, const float *gy, long n, float a, const uint8_t *pos, float *gx) {
+  if (!pos) return orc_prelu_bwd(x, gy, n, a, gx);
+  double ga = 0;
+#pragma omp parallel for reduction(+ : ga)
+  for (long i = 0; i < n; ++i) {
+    if (pos[i]) {
+      gx[i] = gy[i];
+    } else {
+      gx[i] = a * gy[i];
+      ga += (double)x[i] * (double)gy[i];
+    }
+  }
+  return ga;
+}
+
 #define MAXC 32
 struct orc_pnet_state {
   int nconv;                 /* backbone convs */
@@ -91,6 +126,7 @@ struct orc_pnet_state {
   int ck[MAXC], cpad[MAXC], cblock[MAXC], cstep[MAXC];
   float cscale_eval[MAXC];   /* (1-p) or 1 */
   const float *cmask[MAXC];  /* training keep mask per channel or NULL */
+  const uint8_t *cpos[MAXC], *hpos[8]; /* injected PReLU branches (caller-owned) or NULL */
   int training;
   tens cy[MAXC];             /* activated (PReLU + dropout) output of each conv, owned */
   int last_conv[8];          /* index of the last conv of each block (pool input = cy[..]) */
@@ -119,8 +155,9 @@ void orc_pnet_state_free(orc_pnet_state *s) {
 
 /* y = scale_c * prelu(x)  (nn.PReLU then nn.SpatialDropout, model_utilities.lua:9-12) */
 static void act_apply(const tens *x, float a, const float *mask, float eval_scale, int training,
-                      tens *y) {
+                      const uint8_t *pos, uint8_t *rec, tens *y) {
   long hw = (long)x->H * x->W;
+#pragma omp parallel for
   for (int c = 0; c < x->C; ++c) {
     float sc = 1.0f;
     if (mask && training) sc = mask[c];
@@ -128,7 +165,9 @@ static void act_apply(const tens *x, float a, const float *mask, float eval_scal
     const float *xp = x->d + c * hw;
     float *yp = y->d + c * hw;
     for (long t = 0; t < hw; ++t) {
-      float v = xp[t] > 0.0f ? xp[t] : a * xp[t];
+      int p = pos ? pos[c * hw + t] != 0 : xp[t] > 0.0f;
+      if (rec) rec[c * hw + t] = (uint8_t)(xp[t] > 0.0f);
+      float v = p ? xp[t] : a * xp[t];
       yp[t] = sc == 1.0f ? v : v * sc;
     }
   }
@@ -159,7 +198,9 @@ void orc_pnet_forward(const orc_model *m, const float *w, const float *img, int 
       s->cmask[nc] = has_drop && drop_masks ? drop_masks[b] : NULL;
       s->cscale_eval[nc] = has_drop ? (float)(1.0 - m->dropout[b]) : 1.0f;
       tens y = tnew(O, Ho, Wo);
-      act_apply(&s->cx[nc], a, s->cmask[nc], s->cscale_eval[nc], training, &y);
+      s->cpos[nc] = g_inject ? g_inject->conv_pos[nc] : NULL;
+      act_apply(&s->cx[nc], a, s->cmask[nc], s->cscale_eval[nc], training, s->cpos[nc],
+                g_record ? (uint8_t *)g_record->conv_pos[nc] : NULL, &y);
       s->cy[nc] = y;
       if (st == m->conv_steps[b] - 1) s->last_conv[b] = nc;
       cur = y;
@@ -169,6 +210,17 @@ void orc_pnet_forward(const orc_model *m, const float *w, const float *img, int 
     s->pooled[b] = tnew(cur.C, Hp, Wp);
     s->pidx[b] = (int32_t *)malloc(sizeof(int32_t) * (size_t)cur.C * Hp * Wp);
     orc_maxpool2x2_ceil_fwd(cur.d, cur.C, cur.H, cur.W, s->pooled[b].d, s->pidx[b]);
+    {
+      long np_ = (long)cur.C * Hp * Wp, plane = (long)cur.H * cur.W, pp = (long)Hp * Wp;
+      if (g_record && g_record->pool_idx[b]) memcpy((int32_t *)g_record->pool_idx[b], s->pidx[b], sizeof(int32_t) * np_);
+      if (g_inject && g_inject->pool_idx[b]) { /* the caller's window winners: value and route follow them */
+        const int32_t *inj = g_inject->pool_idx[b];
+        for (long i = 0; i < np_; ++i) {
+          s->pidx[b][i] = inj[i];
+          s->pooled[b].d[i] = cur.d[(i / pp) * plane + inj[i]];
+        }
+      }
+    }
     cur = s->pooled[b];
   }
   s->nconv = nc;
@@ -184,7 +236,8 @@ void orc_pnet_forward(const orc_model *m, const float *w, const float *img, int 
     float a = w[off + wsz + n];
     off += wsz + n + 1;
     s->hy[h] = tnew(n, Ho, Wo);
-    orc_prelu_fwd(s->hx[h].d, tnum(&s->hx[h]), a, s->hy[h].d);
+    s->hpos[h] = g_inject ? g_inject->head_pos[h] : NULL;
+    prelu_fwd_d(s->hx[h].d, tnum(&s->hx[h]), a, s->hpos[h], g_record ? (uint8_t *)g_record->head_pos[h] : NULL, s->hy[h].d);
     s->hout[h] = tnew(HEAD_OUT, Ho, Wo);
     orc_conv2d_fwd(s->hy[h].d, n, Ho, Wo, w + off, w + off + (long)HEAD_OUT * n, HEAD_OUT, 1, 1, 0,
                    s->hout[h].d);
@@ -230,7 +283,7 @@ void orc_pnet_backward(const orc_model *m, const float *w, const orc_pnet_state 
     tens ghy = tnew(n, hy->H, hy->W);
     orc_conv2d_bwd_input(delta[h], HEAD_OUT, hy->H, hy->W, w + off1, n, 1, 1, 0, hy->H, hy->W, ghy.d);
     tens ghx = tnew(n, hy->H, hy->W);
-    double ga = orc_prelu_bwd(hx->d, ghy.d, tnum(hx), w[off + wsz + n], ghx.d);
+    double ga = prelu_bwd_d(hx->d, ghy.d, tnum(hx), w[off + wsz + n], s->hpos[h], ghx.d);
     grad[off + wsz + n] = (float)((double)grad[off + wsz + n] + ga);
     orc_conv2d_bwd_weight(in->d, in->C, in->H, in->W, ghx.d, n, k, k, 0, grad + off, grad + off + wsz);
     tens gin = tnew(in->C, in->H, in->W);
@@ -257,7 +310,7 @@ void orc_pnet_backward(const orc_model *m, const float *w, const orc_pnet_state 
             for (long t = 0; t < hw; ++t) g.d[c * hw + t] *= s->cmask[nc][c];
       }
       tens gx = tnew(O, x->H, x->W);
-      double ga = orc_prelu_bwd(x->d, g.d, tnum(x), w[off + wsz + O], gx.d);
+      double ga = prelu_bwd_d(x->d, g.d, tnum(x), w[off + wsz + O], s->cpos[nc], gx.d);
       grad[off + wsz + O] = (float)((double)grad[off + wsz + O] + ga);
       orc_conv2d_bwd_weight(in->d, in->C, in->H, in->W, gx.d, O, k, k, p, grad + off,
                             grad + off + wsz);
@@ -293,6 +346,7 @@ struct orc_cnet_state {
   float *pre[8];   /* PReLU input */
   float *post[8];  /* after dropout = next input (aliases in[l+1]) */
   const float *mask[8];
+  const uint8_t *pos[8];   /* injected PReLU branches (caller-owned) or NULL */
   int training;
   float *cls_logits;
   float *cls_lsm;
@@ -372,7 +426,8 @@ void orc_cnet_forward(const orc_model *m, const float *weights, const float *x, 
     float a = w[off];
     off += 1;
     s->post[l] = (float *)malloc(sizeof(float) * (size_t)R * n);
-    orc_prelu_fwd(s->pre[l], (long)R * n, a, s->post[l]);
+    s->pos[l] = g_inject ? g_inject->cnet_pos[l] : NULL;
+    prelu_fwd_d(s->pre[l], (long)R * n, a, s->pos[l], g_record ? (uint8_t *)g_record->cnet_pos[l] : NULL, s->post[l]);
     s->mask[l] = NULL;
     if (m->cls_dropout[l] > 0 && training) { /* nn.Dropout v2: y = x*mask/(1-p) [ext] */
       const float *mk = drop_masks ? drop_masks[l] : NULL;
@@ -442,7 +497,7 @@ void orc_cnet_backward(const orc_model *m, const float *weights, const orc_cnet_
       for (long i = 0; i < (long)R * n; ++i) g[i] = g[i] * (s->mask[l][i] * inv);
     }
     float *gpre = (float *)malloc(sizeof(float) * (size_t)R * n);
-    double ga = orc_prelu_bwd(s->pre[l], g, (long)R * n, w[o_pr], gpre);
+    double ga = prelu_bwd_d(s->pre[l], g, (long)R * n, w[o_pr], s->pos[l], gpre);
     grad[o_pr] = (float)((double)grad[o_pr] + ga);
     free(g);
     float *glin = gpre;
@@ -564,6 +619,16 @@ void orc_train_image(const orc_model *m, const float *weights, float *grad, cons
     orc_adaptive_max_pool_fwd(fm, planes, fH, fW, win, kh, kw, cinput + (size_t)(np + e) * D,
                               pidx + (size_t)(np + e) * D);
     cctarget[np + e] = (float)(m->class_count + 1); /* :159 bgclass */
+  }
+  if (g_record && g_record->roi_idx && R > 0) memcpy((int32_t *)g_record->roi_idx, pidx, sizeof(int32_t) * (size_t)R * D);
+  if (g_inject && g_inject->roi_idx && R > 0) { /* the caller's cell winners (see orc_set_decisions) */
+    const int32_t *inj = g_inject->roi_idx;
+    long plane = (long)fH * fW;
+    int cell = kh * kw;
+    for (long i = 0; i < (long)R * D; ++i) {
+      pidx[i] = inj[i];
+      cinput[i] = fm[((i % D) / cell) * plane + inj[i]];
+    }
   }
   if (R > 0) { /* :146-186 */
     int nc = m->class_count + 1;

@@ -105,6 +105,8 @@ def lib():
     L.orc_cnet_backward.argtypes = [C.POINTER(Model), fp, C.c_void_p, fp, fp, fp, fp]
     L.orc_prelu_bwd.restype = C.c_double
     L.orc_rmsprop.argtypes = [fp, fp, fp, C.c_long, C.c_float, C.c_float, C.c_float]
+    L.orc_set_decisions.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_set_decisions.restype = None
     L.orc_prelu_fwd.argtypes = [fp, C.c_long, C.c_float, fp]
     L.orc_prelu_bwd.argtypes = [fp, fp, C.c_long, C.c_float, fp]
     _lib = L
@@ -388,7 +390,49 @@ def train_image(m, weights, grad, img, pos_idx, pos_rect, rois, roi_class, neg_i
     return acc
 
 
-def detect(m, weights, bn_running, img, cap=32768):
+class _Decisions(C.Structure):
+    _fields_ = [("pool_idx", C.c_void_p * 8), ("conv_pos", C.c_void_p * 32), ("head_pos", C.c_void_p * 8),
+                ("cnet_pos", C.c_void_p * 8), ("roi_idx", C.c_void_p)]
+
+
+def _decisions_struct(d):
+    """dict(pool_idx=[int32 arrays], conv_pos=[uint8], head_pos=[uint8], cnet_pos=[uint8], roi_idx=int32) -> C struct + keep-alive."""
+    st = _Decisions()
+    keep = []
+    for name, dt in (("pool_idx", np.int32), ("conv_pos", np.uint8), ("head_pos", np.uint8), ("cnet_pos", np.uint8)):
+        for i, a in enumerate(d.get(name) or []):
+            if a is None:
+                continue
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"], (name, i, a.dtype)
+            keep.append(a)
+            getattr(st, name)[i] = a.ctypes.data
+    a = d.get("roi_idx")
+    if a is not None:
+        assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+        keep.append(a)
+        st.roi_idx = a.ctypes.data
+    return st, keep
+
+
+class decisions(object):
+    """with O.decisions(inject=..., record=...): the oracle calls inside take the discrete choices of `inject` as given
+    and / or write their own into the (pre-allocated) arrays of `record` (frcnn_oracle.h orc_set_decisions)."""
+
+    def __init__(self, inject=None, record=None):
+        self.inject, self.record = inject, record
+
+    def __enter__(self):
+        self._i = _decisions_struct(self.inject) if self.inject is not None else None
+        self._r = _decisions_struct(self.record) if self.record is not None else None
+        lib().orc_set_decisions(C.byref(self._i[0]) if self._i else None, C.byref(self._r[0]) if self._r else None)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_decisions(None, None)
+        return False
+
+
+def detect(m, weights, bn_running, img, cap=65536):
     img = f32(img); _, H, W = img.shape
     nc = m.class_count + 1
     match_p = np.zeros(cap, dtype=np.float32); match_idx = np.zeros((cap, 4), dtype=np.int32)

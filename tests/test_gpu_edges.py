@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from util import VGG_SMALL_CLS, VGG_SMALL_HEADS, VGG_SMALL_LAYERS, assert_close, oracle_model
-from test_gpu_model import _OneBatch, _compare_gradient, _masks
+from test_gpu_model import _OneBatch, _compare_gradient, _masks, check_pnet_forward_backward
 
 pytestmark = pytest.mark.gpu
 
@@ -24,38 +24,7 @@ def test_odd_image_sizes(F, O, setup, H, W):
     s = setup
     rng = np.random.RandomState(H)
     img = F.synthetic_image(H, W, 4)
-    masks = _masks(rng, s["model"])
-    pnet = s["model"]["pnet"]
-    pnet.training(); pnet.drop_masks = masks
-    try:
-        outs = pnet.forward(img)
-        want, st = O.pnet_forward(s["om"], s["w"], img, True, masks)
-        assert [o.shape for o in outs] == [w.shape for w in want]
-        for i, (o, w) in enumerate(zip(outs, want)):
-            assert_close(o.numpy(), w, 1e-4, "pnet output %d" % (i + 1))
-        deltas = [(rng.randn(*w.shape) / np.sqrt(w.size)).astype(np.float32) for w in want]
-        g_want = np.zeros_like(s["w"])
-        O.pnet_backward(s["om"], s["w"], st, deltas, g_want)
-        s["gradient"].zero_()
-        dev = pnet.delta_outputs(zero=True)
-        for d, h in zip(dev, deltas):
-            d.copy_from_numpy(h)
-        pnet.backward(img, dev)
-        # A max-pool arg-max near-tie (two window entries within fp32 rounding of each other: the fp32-MFMA
-        # activations and the fp64-accumulated oracle activations may order them differently) re-routes one
-        # gradient element and shows at the 1e-3 level in every tensor below that pooling layer (seen here for
-        # 131x173: one window of block 4; 97x211: none) -- same tolerance and reasoning as the end-to-end test.
-        g = s["gradient"].cpu().numpy()
-        nat = s["model"]["native"]
-        class _NoScalars(object):   # the PReLU slope gradients are single numbers summed with cancellation:
-            param_table = [t for t in nat.param_table if t[1] > 1]   # one re-routed element moves them by percents
-        _compare_gradient(_NoScalars, g, g_want, lo=0, hi=nat.pnet_params, tol_l2=1e-2, elementwise=False)
-        # anchor nets: above every pooling decision; a PReLU sign decision of one hidden unit (256 per anchor net) within
-        # rounding of zero may still differ -- seen for 97x211: unit 158 of the 5x5 net, which carries the whole excess
-        # (3.2e-3 of the squared error against 2e-11 in every other row)
-        _compare_gradient(nat, g, g_want, lo=3321095, hi=nat.pnet_params, flip_rows=(256, 2))
-    finally:
-        pnet.drop_masks = None
+    check_pnet_forward_backward(F, O, s, img, _masks(rng, s["model"]), rng, what="odd size")
 
 
 def test_no_examples_and_negatives_only(F, setup):

@@ -4,6 +4,7 @@ image size the oracle finishes in seconds (3x128x176, real vgg_small topology)."
 import numpy as np
 import pytest
 
+import decisions
 from util import VGG_SMALL_CLS, VGG_SMALL_HEADS, VGG_SMALL_LAYERS, assert_close, oracle_model, oracle_tables
 
 pytestmark = pytest.mark.gpu
@@ -27,31 +28,50 @@ def _masks(rng, model):
             for l in model["layers"]]
 
 
+def check_pnet_forward_backward(F, O, s, img, masks, rng, what="pnet"):
+    """pnet:forward / :backward with dense random deltas against the oracle, the device's discrete decisions (max-pool
+    winners, PReLU branches) injected into the oracle (tests/decisions.py): outputs 1e-4, EVERY gradient tensor of the
+    proposal net at SURVEY 8d's strict bars (1e-3 L2 per tensor + 1e-4 elementwise), nothing left out."""
+    model = s["model"]
+    pnet = model["pnet"]
+    nat = model["native"]
+    _, H, W = img.shape
+    pnet.training()
+    pnet.drop_masks = masks
+    try:
+        outs = pnet.forward(img)
+        dec = decisions.capture(F, model, H, W)
+        own = decisions.blank_like(dec)
+        g_want = np.zeros_like(s["w"])
+        with O.decisions(inject=dec, record=own):
+            want, st = O.pnet_forward(s["om"], s["w"], img, True, masks)
+            assert [o.shape for o in outs] == [w.shape for w in want]
+            for i, (o, w) in enumerate(zip(outs, want)):
+                assert_close(o.numpy(), w, 1e-4, "%s output %d" % (what, i + 1))
+            deltas = [(rng.randn(*w.shape) / np.sqrt(w.size)).astype(np.float32) for w in want]
+            O.pnet_backward(s["om"], s["w"], st, deltas, g_want)
+        s["gradient"].zero_()
+        dev_deltas = pnet.delta_outputs(zero=True)
+        for d, h in zip(dev_deltas, deltas):
+            d.copy_from_numpy(h)
+        pnet.backward(img, dev_deltas)
+        g = s["gradient"].cpu().numpy()
+        _compare_gradient(nat, g, g_want, lo=0, hi=nat.pnet_params)
+        diff = decisions.count_differences(dec, own)
+        print("%s %dx%d: decisions the oracle would have taken differently: %s" % (what, W, H, {k: "%d of %d" % v for k, v in diff.items()}))
+        for kind, (nd, nt) in diff.items():
+            assert nd <= max(4, 2e-5 * nt), (kind, nd, nt)
+    finally:
+        pnet.drop_masks = None
+    return outs
+
+
 def test_pnet_forward_backward(F, O, setup):
     s = setup
     rng = np.random.RandomState(0)
     img = F.synthetic_image(H, W, 0)
-    masks = _masks(rng, s["model"])
+    check_pnet_forward_backward(F, O, s, img, _masks(rng, s["model"]), rng)
     pnet = s["model"]["pnet"]
-    pnet.training()
-    pnet.drop_masks = masks
-    outs = pnet.forward(img)
-    want, st = O.pnet_forward(s["om"], s["w"], img, True, masks)
-    assert [o.shape for o in outs] == [w.shape for w in want]
-    for i, (o, w) in enumerate(zip(outs, want)):
-        assert_close(o.numpy(), w, 1e-4, "pnet output %d" % (i + 1))
-    # backward with dense random deltas
-    deltas = [(rng.randn(*w.shape) / np.sqrt(w.size)).astype(np.float32) for w in want]
-    g_want = np.zeros_like(s["w"])
-    O.pnet_backward(s["om"], s["w"], st, deltas, g_want)
-    s["gradient"].zero_()
-    dev_deltas = pnet.delta_outputs(zero=True)
-    for d, h in zip(dev_deltas, deltas):
-        d.copy_from_numpy(h)
-    pnet.backward(img, dev_deltas)
-    g = s["gradient"].cpu().numpy()
-    _compare_gradient(s["model"]["native"], g, g_want, lo=0, hi=s["model"]["native"].pnet_params)
-    pnet.drop_masks = None
     # evaluate(): SpatialDropout scales by (1-p)
     pnet.evaluate()
     outs = pnet.forward(img)
@@ -60,14 +80,9 @@ def test_pnet_forward_backward(F, O, setup):
         assert_close(o.numpy(), w, 1e-4, "pnet eval output %d" % (i + 1))
 
 
-def _compare_gradient(native, g, g_want, lo, hi, tol_l2=1e-3, elementwise=True, flip_rows=None):
-    """1e-3 relative on the L2 norm per tensor + 1e-4 abs-or-relative elementwise.
-
-    flip_rows=(rows, n): a PReLU whose input is within fp32 rounding of zero may take the other branch on the GPU than in the
-    fp64-accumulating oracle (the same kind of decision as a max-pool arg-max near-tie).  Such a flip changes the gradient of
-    ONE hidden unit at one position, i.e. exactly one row (output unit) of the weight tensor that produced it and nothing
-    else.  With flip_rows, a weight tensor of `rows` output units that misses the tolerance is re-checked with its (at most
-    n) worst rows left out -- they must carry the whole excess: every other row has to meet the strict tolerance."""
+def _compare_gradient(native, g, g_want, lo, hi, tol_l2=1e-3, elementwise=True):
+    """1e-3 relative on the L2 norm per tensor + 1e-4 abs-or-relative elementwise, for every tensor of the
+    parameter table whose offset lies in [lo, hi)."""
     for off, cnt, kind, aux in native.param_table:
         if not (lo <= off < hi):
             continue
@@ -76,24 +91,7 @@ def _compare_gradient(native, g, g_want, lo, hi, tol_l2=1e-3, elementwise=True, 
         err = np.linalg.norm(a - b)
         # absolute floor: tensors whose true gradient is ~0 (e.g. a Linear bias feeding BatchNorm) hold only
         # fp32 rounding noise of relative size 1e-6 of the neighbouring activations' gradients
-        ok = err <= tol_l2 * nb + 1e-6 * np.sqrt(cnt)
-        if not ok and flip_rows and flip_rows[0] == "conv3x3" and kind == 0 and aux % 9 == 0:
-            flip_rows_t = (int(aux) // 9, flip_rows[1])   # rows = filters of a 3x3 layer (aux = k*k*Cout)
-        elif not ok and flip_rows and flip_rows[0] == "conv3x3" and kind == 1:
-            flip_rows_t = (int(cnt), flip_rows[1])        # bias: one element per filter
-        else:
-            flip_rows_t = flip_rows
-        if not ok and flip_rows_t and flip_rows_t[0] != "conv3x3" and kind in (0, 1, 2) and cnt % flip_rows_t[0] == 0:
-            rows, nmax = flip_rows_t
-            e = ((a - b).reshape(rows, -1) ** 2).sum(1)
-            worst = np.argsort(-e)[:nmax]
-            keep = np.ones(rows, bool); keep[worst] = False
-            a, b = a.reshape(rows, -1)[keep].ravel(), b.reshape(rows, -1)[keep].ravel()
-            err = np.linalg.norm(a - b)
-            ok = err <= tol_l2 * nb + 1e-6 * np.sqrt(cnt)
-            print("tensor @%d: rows %s (decision flips) carry %.3e of the squared error, the other %d rows %.3e"
-                  % (off, worst, e[worst].sum(), rows - nmax, e[keep].sum()))
-        assert ok, "tensor @%d kind %d: |a-b|=%.3e |b|=%.3e" % (off, kind, err, nb)
+        assert err <= tol_l2 * nb + 1e-6 * np.sqrt(cnt), "tensor @%d kind %d: |a-b|=%.3e |b|=%.3e" % (off, kind, err, nb)
         scale = max(1e-30, np.abs(b).max())
         if not elementwise:
             continue
@@ -165,17 +163,12 @@ def check_loss_and_gradient(F, O, s, H, W, nimages=2, nrois=3, negatives=8, head
     nat = model["native"]
     n1, n2 = [l["n"] for l in model["class_layers"]]
     bn0 = nat.bn_running.cpu().numpy().copy()
-    # the oracle needs explicit cnet masks per image (R differs): draw them and hand the same to both
-    g_want = np.zeros_like(s["w"]); acc = np.zeros(8); bn_o = bn0.copy()
+    # explicit cnet masks per image (R differs): drawn once, handed to both sides
     stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
     cm_per_image = []
     for (img, rois, pos, neg) in oracle_in:
         R = len(pos) + len(neg)
-        cm = [(rng_m.rand(R, n1) > 0.5).astype(np.float32), (rng_m.rand(R, n2) > 0.5).astype(np.float32)]
-        cm_per_image.append(cm)
-        O.train_image(s["om"], s["w"], g_want, img, *oracle_tables(pos, neg, rois), pm, cm, bn_o, acc)
-    g_want /= acc[2]
-    want = dict(pcls=acc[0] / acc[2], preg=acc[1] / acc[3], dcls=acc[6] / acc[7], dreg=acc[4] / acc[5])
+        cm_per_image.append([(rng_m.rand(R, n1) > 0.5).astype(np.float32), (rng_m.rand(R, n2) > 0.5).astype(np.float32)])
 
     cnet = model["cnet"]
     orig_forward = cnet.forward
@@ -187,34 +180,41 @@ def check_loss_and_gradient(F, O, s, H, W, nimages=2, nrois=3, negatives=8, head
     cnet.forward = fwd
     try:
         f = F.create_objective(model, s["weights"], s["gradient"], _OneBatch(batch, anchors), stats)
-        loss, grad = f(s["weights"])
+        # the device's discrete decisions (pool winners, PReLU branches, ROI cell winners) of every image, copied out
+        # right before that image's backward pass
+        with decisions.CaptureBeforeBackward(F, model, f) as cap:
+            loss, grad = f(s["weights"])
     finally:
         cnet.forward = orig_forward
         cnet.drop_masks = None
         model["pnet"].drop_masks = None
+    assert len(cap.captured) == nimages
+    # ---- the oracle, taking those decisions as given (and recording the ones it would have taken itself) -------------
+    g_want = np.zeros_like(s["w"]); acc = np.zeros(8); bn_o = bn0.copy()
+    differing = {}
+    for k, (img, rois, pos, neg) in enumerate(oracle_in):
+        own = decisions.blank_like(cap.captured[k])
+        with O.decisions(inject=cap.captured[k], record=own):
+            O.train_image(s["om"], s["w"], g_want, img, *oracle_tables(pos, neg, rois), pm, cm_per_image[k], bn_o, acc)
+        for kind, (nd, nt) in decisions.count_differences(cap.captured[k], own).items():
+            a, b = differing.get(kind, (0, 0))
+            differing[kind] = (a + nd, b + nt)
+    g_want /= acc[2]
+    want = dict(pcls=acc[0] / acc[2], preg=acc[1] / acc[3], dcls=acc[6] / acc[7], dreg=acc[4] / acc[5])
     for k in ("pcls", "preg", "dcls", "dreg"):
         assert abs(stats[k][-1] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, stats[k][-1], want[k])
     assert abs(loss - (want["pcls"] + want["preg"])) <= 1e-5 * max(1.0, abs(loss))
-    # End-to-end tolerance 1e-2 (per-tensor relative L2) instead of 1e-3: with SPARSE deltas (a few dozen
-    # examples) a single max-pool arg-max decision that differs between the fp32-MFMA activations and the
-    # fp64-accumulated oracle activations (two window entries closer than ~1e-6 relative; observed: 1 of
-    # 33 792 block-4 windows) re-routes one gradient path and shows up at the 1e-3 level in the tensors below
-    # it, although every kernel is exact to 1e-6 given the same arg-max (op-level tests, and the dense-delta
-    # pnet test above, hold 1e-4 / 1e-3).  SURVEY 8d: "pooling argmax when no ties: exact".
-    # (The backbone's PReLU slope gradients are single numbers summed with cancellation: one re-routed element moves them by
-    # percents -- they are left out below the anchor nets, as in tests/test_gpu_edges.py; every scalar above is checked.)
+    # SURVEY 8d's bars on EVERY tensor of the flat gradient -- 1e-3 relative on the L2 norm per tensor, 1e-4 elementwise --
+    # no tensor left out, no row set aside: with the routes fixed, what is compared is arithmetic.
+    _compare_gradient(nat, grad.cpu().numpy(), g_want, 0, nat.total_params, tol_l2=1e-3, elementwise=True)
     lo = model["pnet"].heads_param_range()[0]
-    class _NoBackboneScalars(object):
-        param_table = [t for t in nat.param_table if t[1] > 1 or t[0] >= lo]
-    # A re-routed pooled gradient element also changes ONE row (the pooled channel) of the weight gradient of the layer that
-    # feeds the pooling by much more than the rest: at most two such rows per tensor are set aside (flip_rows), the others must
-    # meet the bar.
-    _compare_gradient(_NoBackboneScalars, grad.cpu().numpy(), g_want, 0, nat.total_params, tol_l2=1e-2, elementwise=False,
-                      flip_rows=("conv3x3", 2))
-    # tensors ABOVE the first pooling decision on the backward path are unaffected: heads and cnet hold 1e-4
     if heads_lo is not None:
         assert lo == heads_lo
-    _compare_gradient(nat, grad.cpu().numpy(), g_want, lo, nat.total_params, tol_l2=1e-4, elementwise=False)
+    # How many decisions the fp64-accumulating restatement takes differently from the fp32 device (values within rounding
+    # of each other / of zero): a handful per million, reported and bounded.
+    print("decisions taken differently by the oracle: %s" % {k: "%d of %d" % v for k, v in differing.items()})
+    for kind, (nd, nt) in differing.items():
+        assert nd <= max(4, 2e-5 * nt), (kind, nd, nt)
     assert_close(nat.bn_running.cpu().numpy(), bn_o, 1e-5, "bn running")
     import torch
     nat.bn_running.copy_(torch.from_numpy(bn0))
@@ -239,15 +239,32 @@ def _amplified_weights(nat, w, ncls, cls_gain=30.0):
     return w
 
 
+def _iou_border_pairs(boxes, thr, eps=1e-5):
+    """number of box pairs whose nms.lua IoU (the +1 convention of nms.lua:35,88-94) lies within eps of thr"""
+    b = boxes.astype(np.float64)
+    area = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    n = 0
+    for lo in range(0, len(b), 512):
+        c = b[lo:lo + 512]
+        w = np.maximum(0, np.minimum(c[:, None, 2], b[None, :, 2]) - np.maximum(c[:, None, 0], b[None, :, 0]) + 1)
+        h = np.maximum(0, np.minimum(c[:, None, 3], b[None, :, 3]) - np.maximum(c[:, None, 1], b[None, :, 1]) + 1)
+        inter = w * h
+        iou = inter / (area[lo:lo + 512, None] + area[None, :] - inter)
+        n += int((np.abs(iou - thr) < eps).sum())
+    return n
+
+
 def check_detect(F, O, model, om, w, img_seeds, H, W):
-    """Detector:detect against the oracle, every stage, on the first frame of `img_seeds` whose match list and NMS
-    pick list agree (an anchor within fp32 rounding of the 0.95 threshold, or a pair of boxes within rounding of the
-    NMS threshold, may legitimately differ between fp32-MFMA and fp64-accumulated activations; the border rule is
-    checked on every frame, and the test FAILS if no frame agrees -- nothing below is conditional)."""
+    """Detector:detect against the oracle on EVERY frame of `img_seeds`, every stage.  A stage's lists may differ between
+    the fp32 device and the fp64-accumulating restatement only where a BORDER CASE is shown to exist -- an anchor whose
+    probability lies within 1e-4 of the 0.95 threshold (Detector.lua:54), a pair of boxes whose IoU lies within 1e-5 of the
+    NMS threshold (:81) -- and the test asserts that: without such a case the lists must be identical, and once they are,
+    everything downstream (decoded rects, cnet outputs, winners with their boxes) is compared, unconditionally.  NMS ids on
+    identical boxes are always bit-exact.  At least one frame must go all the way."""
     nat = model["native"]
     d = F.Detector(model)
     bn = nat.bn_running.cpu().numpy()
-    chosen = None
+    deep = []
     for seed in img_seeds:
         img = F.synthetic_image(H, W, seed)
         winners = d.detect(img)
@@ -263,28 +280,47 @@ def check_detect(F, O, model, om, w, img_seeds, H, W):
         assert key(gidx[~border_got]) - key(ref["match_idx"]) == set()
         assert key(ref["match_idx"][~border_ref]) - key(gidx) == set()
         assert len(gidx) > 10, "test image produced too few matches to be meaningful"
+        same_matches = len(gidx) == len(ref["match_idx"]) and np.array_equal(gidx, ref["match_idx"])
+        if not (border_ref.any() or border_got.any()):
+            assert same_matches, "frame %d: match lists differ although no anchor is near the threshold" % seed
         # NMS ids: bit-exact when the oracle NMS is fed the boxes the GPU produced
         boxes = m["box"].numpy()
         assert d.last_pick.tolist() == O.nms(boxes, 0.25).tolist()
-        if (len(gidx) == len(ref["match_idx"]) and np.array_equal(gidx, ref["match_idx"])
-                and d.last_pick.tolist() == ref["cand_ids"].tolist()):
-            chosen = (seed, winners, ref, gp, grect)
-            break
-    assert chosen is not None, "no frame of %r gave identical match and candidate lists" % (list(img_seeds),)
-    seed, winners, ref, gp, grect = chosen
-    assert_close(gp, ref["match_p"], 1e-4, "match log-prob")
-    assert_close(grect, ref["match_rect"], 1e-3, "decoded rects")
-    assert len(ref["cand_ids"]) > 0
-    assert_close(d.last_cnet["bbox"], ref["cand_bbox"], 1e-3, "cnet bbox (eval)")
-    assert_close(d.last_cnet["cls"], ref["cand_cls"], 1e-3, "cnet log-probs (eval)")
-    # winners: {class, confidence, r2} per class in NMS pick order (classes ascending on both sides)
-    assert len(winners) == len(ref["winners"]), (len(winners), len(ref["winners"]))
-    assert [x["class"] for x in winners] == [int(r[0]) for r in ref["winners"]]
-    if len(winners):
-        assert_close([x["confidence"] for x in winners], ref["winners"][:, 1], 1e-3, "winner confidence")
-        assert_close([[x["r2"].minX, x["r2"].minY, x["r2"].maxX, x["r2"].maxY] for x in winners], ref["winners"][:, 2:6],
-                     1e-3, "winner rects (Detector.lua:107)")
-    return dict(seed=seed, matches=len(gp), candidates=len(ref["cand_ids"]), winners=len(winners), ref=ref, got=winners)
+        if not same_matches:
+            print("frame %d: %d / %d border anchors, match lists differ by them only" % (seed, border_got.sum(), border_ref.sum()))
+            continue
+        assert_close(gp, ref["match_p"], 1e-4, "match log-prob")
+        assert_close(grect, ref["match_rect"], 1e-3, "decoded rects")
+        same_picks = d.last_pick.tolist() == ref["cand_ids"].tolist()
+        if not same_picks:
+            nb = _iou_border_pairs(boxes, 0.25)
+            assert nb > 0, "frame %d: NMS candidates differ although no box pair is near the overlap threshold" % seed
+            print("frame %d: %d box pairs within 1e-5 of the NMS threshold, candidate lists differ" % (seed, nb))
+            continue
+        assert len(ref["cand_ids"]) > 0
+        assert_close(d.last_cnet["bbox"], ref["cand_bbox"], 1e-3, "cnet bbox (eval)")
+        assert_close(d.last_cnet["cls"], ref["cand_cls"], 1e-3, "cnet log-probs (eval)")
+        # winners: {class, confidence, r2} per class in NMS pick order (classes ascending on both sides).  Border cases of
+        # this stage: a candidate whose top two class log-probabilities agree to 1e-4, or whose confidence lies within 1e-4
+        # of 0.2 (Detector.lua:110-115)
+        cls_sorted = np.sort(ref["cand_cls"].astype(np.float64), axis=1)
+        cls_border = int(((cls_sorted[:, -1] - cls_sorted[:, -2]) < 1e-4).sum() + (np.abs(np.exp(cls_sorted[:, -1]) - 0.2) < 1e-4).sum())
+        got_cls = [x["class"] for x in winners]; want_cls = [int(r[0]) for r in ref["winners"]]
+        if got_cls != want_cls:
+            wb = np.array([[x["r2"].minX, x["r2"].minY, x["r2"].maxX, x["r2"].maxY] for x in winners], dtype=np.float32)
+            assert cls_border > 0 or _iou_border_pairs(wb, 0.1) > 0, "frame %d: winners differ without a border case" % seed
+            print("frame %d: winners differ by border cases" % seed)
+            continue
+        if len(winners):
+            assert_close([x["confidence"] for x in winners], ref["winners"][:, 1], 1e-3, "winner confidence")
+            assert_close([[x["r2"].minX, x["r2"].minY, x["r2"].maxX, x["r2"].maxY] for x in winners], ref["winners"][:, 2:6],
+                         1e-3, "winner rects (Detector.lua:107)")
+        deep.append(dict(seed=seed, matches=len(gp), candidates=len(ref["cand_ids"]), winners=len(winners), ref=ref, got=winners))
+    assert deep, "no frame of %r went through every stage" % (list(img_seeds),)
+    print("detect: %d of %d frames compared through every stage" % (len(deep), len(list(img_seeds))))
+    best = max(deep, key=lambda r: r["winners"])
+    best["frames_compared"] = len(deep)
+    return best
 
 
 def test_detect(F, O, setup):
