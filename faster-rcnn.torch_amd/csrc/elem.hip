@@ -34,6 +34,27 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return r;
 }
 
+// the same in fp64 (the PReLU slope gradient is ONE number summed over a whole layer with cancellation: its partial sums are
+// carried in double so that the result is good to fp32 rounding whatever the layer size)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < 64) {
+    r = threadIdx.x < (blockDim.x >> 6) ? sh[threadIdx.x] : 0.0;
+    r = wave_sum_d(r);
+  }
+  __syncthreads();
+  return r;
+}
+
 // ---------------------------------------------------------------- flat buffer ops
 int fill_zero(void* p, size_t bytes, hipStream_t s) {
   if (prof_enabled(KC_ELEMWISE)) prof_before(KC_ELEMWISE, s);
@@ -163,6 +184,7 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
                                     const float* slope, const float* scale, float* __restrict__ gx,
                                     float* gbias, float* gslope, int chunks, float* part_b, float* part_a) {
   __shared__ float sh[16];
+  __shared__ double shd[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long hw = (long)H * W;
   long per = cdivl(hw, chunks);
@@ -171,7 +193,8 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
   const float a = slope ? *slope : 1.f;
   const float sc = scale ? scale[c] : 1.f;
   const bool has_slope = slope != nullptr;
-  float sb = 0.f, sa = 0.f;
+  float sb = 0.f;
+  double sa = 0.0;
   if (VEC) {
     // 4 consecutive elements of one row per thread and load: 16-byte loads/stores (W % 4 == 0, Wo even).
     // Two such groups are in flight per thread (all loads issued before the first use) and the indices are
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
         float gj = g[j];
         if (scale) gj *= sc;
         r[j] = gj;
-        if (has_slope && !(xv[j] > 0.f)) { r[j] = a * gj; sa += xv[j] * gj; }
+        if (has_slope && !(xv[j] > 0.f)) { r[j] = a * gj; sa += (double)xv[j] * (double)gj; }
         sb += r[j];
       }
       *reinterpret_cast<float4*>(oc + i) = make_float4(r[0], r[1], r[2], r[3]);
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
       float xv = x[(size_t)c * hw + i];
       float r = g;
       if (has_slope) {
-        if (!(xv > 0.f)) { r = a * g; sa += xv * g; }
+        if (!(xv > 0.f)) { r = a * g; sa += (double)xv * (double)g; }
       }
       gx[(size_t)c * hw + i] = r;
       sb += r;
@@ -246,13 +269,13 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
   float tb = block_sum(sb, sh);
   if (part_b) {   // deterministic mode: partials to scratch, folded in index order by fold_partials_kernel
     if (threadIdx.x == 0) part_b[blockIdx.x] = tb;
-    float ta = (slope && gslope) ? block_sum(sa, sh) : 0.f;
+    float ta = (slope && gslope) ? (float)block_sum_d(sa, shd) : 0.f;
     if (threadIdx.x == 0) part_a[blockIdx.x] = ta;
     return;
   }
   if (threadIdx.x == 0 && gbias) unsafeAtomicAdd(gbias + c, tb);
   if (slope && gslope) {
-    float ta = block_sum(sa, sh);
+    float ta = (float)block_sum_d(sa, shd);
     if (threadIdx.x == 0) unsafeAtomicAdd(gslope, ta);
   }
 }
@@ -350,6 +373,7 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
 
 __global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks, float* part_b) {
   __shared__ float sh[16];
+  __shared__ double shd[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long per = cdivl(hw, chunks);
   const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;

@@ -183,13 +183,16 @@ void orc_cnet_backward(const orc_model *, const float *weights, const orc_cnet_s
  *   conv_pos[i]   uint8  [O][Ho][Wo]  1 where backbone conv i's pre-activation takes the x > 0 branch
  *   head_pos[h]   uint8  [n][Ho][Wo]  the same for anchor net h's k x k convolution
  *   cnet_pos[l]   uint8  [R][n]       the same for classification layer l (PReLU input = BN output / Linear output)
- *   roi_idx       int32  [R][planes*kh*kw] flat y*W+x into the last pooled map's plane (orc_train_image only) */
+ *   roi_idx       int32  [R][planes*kh*kw] flat y*W+x into the last pooled map's plane (orc_train_image only)
+ *   slope_abs     double [48]         (record only) see below */
 typedef struct {
   const int32_t *pool_idx[8];
   const uint8_t *conv_pos[32];
   const uint8_t *head_pos[8];
   const uint8_t *cnet_pos[8];
   const int32_t *roi_idx;
+  double *slope_abs;  /* record only, 48 doubles, ADDED to: sum |x * gy| over the entries each PReLU slope gradient sums --
+                         [0..31] backbone convolutions, [32..39] anchor nets, [40..47] classification layers */
 } orc_decisions;
 void orc_set_decisions(const orc_decisions *inject, orc_decisions *record);
 

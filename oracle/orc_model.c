@@ -103,18 +103,22 @@ static void prelu_fwd_d(const float *x, long n, float a, const uint8_t *pos, uin
     y[i] = p ? x[i] : a * x[i];
   }
 }
-static double prelu_bwd_d(const float *x, const float *gy, long n, float a, const uint8_t *pos, float *gx) {
-  if (!pos) return orc_prelu_bwd(x, gy, n, a, gx);
-  double ga = 0;
-#pragma omp parallel for reduction(+ : ga)
+/* slope_abs (optional): receives sum |x * gy| over the same entries -- the size of the terms the slope gradient is the
+ * (cancelling) sum of, i.e. the scale its achievable accuracy has to be measured against */
+static double prelu_bwd_d(const float *x, const float *gy, long n, float a, const uint8_t *pos, float *gx, double *slope_abs) {
+  double ga = 0, gabs = 0;
+#pragma omp parallel for reduction(+ : ga, gabs)
   for (long i = 0; i < n; ++i) {
-    if (pos[i]) {
+    int p = pos ? pos[i] != 0 : x[i] > 0.0f;
+    if (p) {
       gx[i] = gy[i];
     } else {
       gx[i] = a * gy[i];
       ga += (double)x[i] * (double)gy[i];
+      gabs += fabs((double)x[i] * (double)gy[i]);
     }
   }
+  if (slope_abs) *slope_abs += gabs;
   return ga;
 }
 
@@ -283,7 +287,7 @@ void orc_pnet_backward(const orc_model *m, const float *w, const orc_pnet_state 
     tens ghy = tnew(n, hy->H, hy->W);
     orc_conv2d_bwd_input(delta[h], HEAD_OUT, hy->H, hy->W, w + off1, n, 1, 1, 0, hy->H, hy->W, ghy.d);
     tens ghx = tnew(n, hy->H, hy->W);
-    double ga = prelu_bwd_d(hx->d, ghy.d, tnum(hx), w[off + wsz + n], s->hpos[h], ghx.d);
+    double ga = prelu_bwd_d(hx->d, ghy.d, tnum(hx), w[off + wsz + n], s->hpos[h], ghx.d, g_record && g_record->slope_abs ? g_record->slope_abs + 32 + h : NULL);
     grad[off + wsz + n] = (float)((double)grad[off + wsz + n] + ga);
     orc_conv2d_bwd_weight(in->d, in->C, in->H, in->W, ghx.d, n, k, k, 0, grad + off, grad + off + wsz);
     tens gin = tnew(in->C, in->H, in->W);
@@ -310,7 +314,7 @@ void orc_pnet_backward(const orc_model *m, const float *w, const orc_pnet_state 
             for (long t = 0; t < hw; ++t) g.d[c * hw + t] *= s->cmask[nc][c];
       }
       tens gx = tnew(O, x->H, x->W);
-      double ga = prelu_bwd_d(x->d, g.d, tnum(x), w[off + wsz + O], s->cpos[nc], gx.d);
+      double ga = prelu_bwd_d(x->d, g.d, tnum(x), w[off + wsz + O], s->cpos[nc], gx.d, g_record && g_record->slope_abs ? g_record->slope_abs + nc : NULL);
       grad[off + wsz + O] = (float)((double)grad[off + wsz + O] + ga);
       orc_conv2d_bwd_weight(in->d, in->C, in->H, in->W, gx.d, O, k, k, p, grad + off,
                             grad + off + wsz);
@@ -497,7 +501,7 @@ void orc_cnet_backward(const orc_model *m, const float *weights, const orc_cnet_
       for (long i = 0; i < (long)R * n; ++i) g[i] = g[i] * (s->mask[l][i] * inv);
     }
     float *gpre = (float *)malloc(sizeof(float) * (size_t)R * n);
-    double ga = prelu_bwd_d(s->pre[l], g, (long)R * n, w[o_pr], s->pos[l], gpre);
+    double ga = prelu_bwd_d(s->pre[l], g, (long)R * n, w[o_pr], s->pos[l], gpre, g_record && g_record->slope_abs ? g_record->slope_abs + 40 + l : NULL);
     grad[o_pr] = (float)((double)grad[o_pr] + ga);
     free(g);
     float *glin = gpre;

@@ -392,7 +392,7 @@ def train_image(m, weights, grad, img, pos_idx, pos_rect, rois, roi_class, neg_i
 
 class _Decisions(C.Structure):
     _fields_ = [("pool_idx", C.c_void_p * 8), ("conv_pos", C.c_void_p * 32), ("head_pos", C.c_void_p * 8),
-                ("cnet_pos", C.c_void_p * 8), ("roi_idx", C.c_void_p)]
+                ("cnet_pos", C.c_void_p * 8), ("roi_idx", C.c_void_p), ("slope_abs", C.c_void_p)]
 
 
 def _decisions_struct(d):
@@ -411,6 +411,11 @@ def _decisions_struct(d):
         assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
         keep.append(a)
         st.roi_idx = a.ctypes.data
+    a = d.get("slope_abs")
+    if a is not None:
+        assert a.dtype == np.float64 and a.size == 48 and a.flags["C_CONTIGUOUS"]
+        keep.append(a)
+        st.slope_abs = a.ctypes.data
     return st, keep
 
 

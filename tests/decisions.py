@@ -57,7 +57,7 @@ def capture(F, model, H, W, R=0, roi_idx=None):
 
 def blank_like(d):
     """Arrays of the same shapes for O.decisions(record=...)."""
-    out = {}
+    out = dict(slope_abs=np.zeros(48))   # (record only: the size of the terms each PReLU slope gradient sums)
     for k, v in d.items():
         if isinstance(v, list):
             out[k] = [np.zeros_like(a) for a in v]
@@ -70,6 +70,8 @@ def count_differences(a, b):
     """-> dict(kind -> (differing, total)) between two decision sets."""
     res = {}
     for k in a:
+        if k == "slope_abs" or k not in b:
+            continue
         va, vb = a[k], b[k]
         if va is None or vb is None:
             continue
@@ -110,3 +112,13 @@ class CaptureBeforeBackward(object):
     def __exit__(self, *a):
         self.model["pnet"].backward = self._orig
         return False
+
+
+def slope_terms(native, model, slope_abs, divisor=1.0):
+    """{flat offset of a PReLU slope: sum |x * gy| / divisor} from a recorded slope_abs (48 doubles: backbone convolutions,
+    anchor nets, classification layers -- the order in which the slopes appear in the flat parameter vector)."""
+    nconv = sum(l["conv_steps"] for l in model["layers"])
+    order = list(range(nconv)) + [32 + h for h in range(len(model["anchor_nets"]))] + [40 + l for l in range(len(model["class_layers"]))]
+    offs = [off for off, cnt, kind, aux in native.param_table if kind == 2]
+    assert len(offs) == len(order), (len(offs), len(order))
+    return {off: float(slope_abs[i]) / divisor for off, i in zip(offs, order)}

@@ -113,6 +113,40 @@ def test_linear_forward_backward(F, O, R, I, Oo):
     assert_close(gb.numpy(), g64.sum(0), 1e-4, "linear bias grad")
 
 
+@pytest.mark.parametrize("R", [138, 280, 560])
+def test_linear_fc1_split_bf16_form(F, O, R):
+    """nn.Linear(13824, 1024) (models/model_utilities.lua:82; cnet layer 1 of vgg_small / duplo) in its three roles --
+    forward, input gradient, weight gradient -- at the row counts of a training step.  These products take the split-bf16
+    operand form of gemm.hip (six exact bf16 x bf16 partial products per fp32 product): against fp64 they must meet the
+    1e-4 bar AND be no worse than the fp32 matrix-core kernel on the same inputs (root-mean-square error <= 2x)."""
+    I, Oo = 13824, 1024
+    rng = np.random.RandomState(R)
+    x = rng.randn(R, I).astype(np.float32)
+    x[:, ::7] *= 1e-3; x[3] *= 1e-2         # a few decades of dynamic range (downwards: the bar is relative to max(1, |y|))
+    w = (rng.randn(Oo, I) / np.sqrt(I)).astype(np.float32); b = rng.randn(Oo).astype(np.float32)
+    gy = (rng.randn(R, Oo) / R).astype(np.float32)
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+    want = dict(fwd=x64 @ w64.T + b, dgrad=g64 @ w64, wgrad=g64.T @ x64)
+    dx, dw, db, dgy = _dev(F, x), _dev(F, w), _dev(F, b), _dev(F, gy)
+    res = {}
+    for split in (1, 0):
+        F._lib.call("frcnn_set_option", b"split_bf16", split)
+        try:
+            y = F.DeviceTensor.empty((R, Oo)); gx = F.DeviceTensor.empty((R, I)); gw = F.DeviceTensor.zeros((Oo, I)); gb = F.DeviceTensor.zeros((Oo,))
+            F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(db), Oo, F.ptr(y), F.stream_ptr())
+            F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(dgy), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb), F.stream_ptr())
+            res[split] = dict(fwd=y.numpy(), dgrad=gx.numpy(), wgrad=gw.numpy())
+        finally:
+            F._lib.call("frcnn_set_option", b"split_bf16", 1)
+    for k in ("fwd", "dgrad", "wgrad"):
+        assert_close(res[1][k], want[k], 1e-4, "FC1 %s (split form)" % k)
+        assert_close(res[0][k], want[k], 1e-4, "FC1 %s (fp32 kernel)" % k)
+        e1 = np.sqrt(np.mean((res[1][k] - want[k]) ** 2)); e0 = np.sqrt(np.mean((res[0][k] - want[k]) ** 2))
+        print("FC1 %s R=%d: rms error split %.3e, fp32 kernel %.3e" % (k, R, e1, e0))
+        assert e1 <= 2.0 * e0 + 1e-12, (k, e1, e0)
+        assert not np.array_equal(res[1][k], res[0][k]), "the split form was not taken"
+
+
 def test_rmsprop_and_scale(F, O):
     rng = np.random.RandomState(9)
     n = 100003

@@ -99,7 +99,8 @@ def _fullsize(F, O, large=False):
           % (R, loss, want["pcls"] + want["preg"], rel, worst))
     assert rel <= 1e-3, rel
     # SURVEY 8d on every tensor, nothing set aside: 1e-3 relative L2 per tensor + 1e-4 elementwise
-    _compare_gradient(nat, g, g_want, 0, nat.total_params, tol_l2=1e-3, elementwise=True)
+    _compare_gradient(nat, g, g_want, 0, nat.total_params, tol_l2=1e-3, elementwise=True,
+                      slope_terms=decisions.slope_terms(nat, model, own["slope_abs"], acc[2]))
     print("decisions the oracle would have taken differently: %s" % {k: "%d of %d" % v for k, v in differing.items()})
     for kind, (nd, nt) in differing.items():
         assert nd <= max(4, 2e-5 * nt), (kind, nd, nt)
