@@ -332,6 +332,18 @@ static int gemm_workspace(size_t need, float** out, int slot) {
   return FRCNN_OK;
 }
 
+// (shared with gemmx.hip: the split-K workspaces and the slab fold)
+int gemm_workspace_get(size_t need, float** out, int slot) { return gemm_workspace(need, out, slot); }
+int gemm_reduce_slabs(const float* slab, int nSplit, int M, int N, const float* bias, float* C, long ldc, bool accumulate,
+                      hipStream_t s) {
+  const long total = (long)M * N;
+  const int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
+  FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (nSplit + 1), s, gemm_reduce_kernel, dim3(rgrid), dim3(256), 0, slab, nSplit, M, N, bias,
+            C, ldc, accumulate ? 1 : 0);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
              long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot) {
   if (M <= 0 || N <= 0) return FRCNN_OK;

@@ -1,0 +1,390 @@
+// gemmx.hip -- the large nn.Linear of the classification network, Linear(kh*kw*planes, 1024) (models/model_utilities.lua:82,
+// reached through objective.lua:164,179 and Detector.lua:101), in its three roles -- forward, input gradient, weight
+// gradient -- in the SPLIT-bf16 operand form of convx.hip: fp32 tensors in and out, fp32 accumulation, every fp32 product
+// formed from six exact bf16 x bf16 partial products of three-way split operands on v_mfma_f32_32x32x16_bf16 (arithmetic and
+// accuracy: convx.hip; tests/test_gpu_elem.py::test_linear_fc1_split_bf16_form measures it against fp64 and against the
+// fp32 matrix-core kernel of gemm.hip).
+//
+// Who splits what.  The ACTIVATION operands (the pooled ROI features X [R][I], the gradient gY [R][O]) are small (R is a
+// few hundred rows) and each is used by two products in two orientations: one pass (`split_planes_kernel`) writes their
+// three bf16 planes once, row-major and transposed, and the GEMMs bring them to LDS by DMA with no VALU work at all.  The
+// WEIGHTS (14.2 M values that change every optimiser step) are never split in HBM: a wave splits the 32 x 16 weight
+// fragment it needs in registers (44 VALU instructions) and re-uses it for every row tile of the block (24 MFMAs with 128
+// rows), so the split rides under the matrix pipe.
+//   forward : Y[R][O]   = X[R][I]  W[O][I]^T + b     A = planes(X),    B = W fp32, k contiguous   (split K over I)
+//   dgrad   : gX[R][I]  = gY[R][O] W[O][I]           A = planes(gY),   B = W fp32, n contiguous
+//   wgrad   : gW[O][I] += gY^T X                     A = planes(gY^T), B = planes(X^T)            (k = r)
+// Kernel geometry: see gemm_planes_kernel.
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace frcnn {
+
+typedef float xf32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((aligned(16))) unsigned g_xzero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ unsigned x_cvt2(float a, float b) {
+  xf32x2 v = {a, b};
+  xbf16x2 r = __builtin_convertvector(v, xbf16x2);   // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+// x = h + m + l exactly (three bf16 numbers each)
+__device__ __forceinline__ void x_split8(const float* v, uint4& H, uint4& Mi, uint4& L) {
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    hh[j] = x_cvt2(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hh[j] << 16), r1 = x1 - __builtin_bit_cast(float, hh[j] & 0xFFFF0000u);
+    mm[j] = x_cvt2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mm[j] << 16), s1 = r1 - __builtin_bit_cast(float, mm[j] & 0xFFFF0000u);
+    ll[j] = x_cvt2(s0, s1);
+  }
+  H = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  Mi = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+  L = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+// ------------------------------------------------------------------------------------------ activation planes
+// src [R][C] fp32  ->  P  [3][C/8][R][8] bf16   (the matrix as the k-contiguous operand with rows = R, k = C)
+//                  and PT [3][Rp/8][C][8] bf16  (its transpose: rows = C, k = R, rows R..Rp-1 of k zero).
+// K-GROUP-MAJOR: the 8 values of one row and one k group are one 16-byte entry, and the entries of consecutive ROWS are
+// contiguous -- so the GEMM's LDS-DMA, which wants one entry per lane for 64 consecutive rows of a k group, reads 1 KB of
+// consecutive memory per wave instruction (whole 128-byte lines; row-major planes made every lane touch a line of its own
+// and the kernel ran at the rate of the texture addresser, 4x below this).  Either destination may be null.  One block =
+// a 64 x 64 tile through LDS: coalesced reads, 16-byte coalesced writes both ways.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int C, int Rp,
+                                                           unsigned short* __restrict__ P, unsigned short* __restrict__ PT) {
+  __shared__ float tile[64 * 65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    tile[r * 65 + c] = (r0 + r < R && c0 + c < C) ? src[(size_t)(r0 + r) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const size_t plane = (size_t)R * C, planeT = (size_t)C * Rp;
+  for (int it = tid; it < 512; it += 256) {
+    if (P) {   // 8 consecutive columns (one k group) of one row; consecutive threads take consecutive rows
+      const int r = it & 63, c8 = (it >> 6) * 8;
+      if (r0 + r < R && c0 + c8 < C) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[r * 65 + c8 + j];
+        uint4 H, Mi, L;
+        x_split8(v, H, Mi, L);
+        unsigned short* d = P + ((size_t)((c0 + c8) >> 3) * R + r0 + r) * 8;
+        *reinterpret_cast<uint4*>(d) = H;
+        *reinterpret_cast<uint4*>(d + plane) = Mi;
+        *reinterpret_cast<uint4*>(d + 2 * plane) = L;
+      }
+    }
+    if (PT) {  // 8 consecutive rows (one k group of the transpose) of one column; consecutive threads, consecutive columns
+      const int c = it & 63, r8 = (it >> 6) * 8;
+      if (c0 + c < C && r0 + r8 < Rp) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[(r8 + j) * 65 + c];
+        uint4 H, Mi, L;
+        x_split8(v, H, Mi, L);
+        unsigned short* d = PT + ((size_t)((r0 + r8) >> 3) * C + c0 + c) * 8;
+        *reinterpret_cast<uint4*>(d) = H;
+        *reinterpret_cast<uint4*>(d + planeT) = Mi;
+        *reinterpret_cast<uint4*>(d + 2 * planeT) = L;
+      }
+    }
+  }
+}
+
+int linear_x_rows_padded(int R) { return (R + 15) & ~15; }
+
+int split_planes(const float* src, int R, int C, void* P, void* PT, hipStream_t s) {
+  FR_CHECK(C % 8 == 0, "split_planes: %d columns (a multiple of 8 is needed for 16-byte plane entries)", C);
+  const int Rp = linear_x_rows_padded(R);
+  dim3 grid(cdiv(C, 64), cdiv(Rp, 64));
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * C * (4.0 + (P ? 6.0 : 0.0) + (PT ? 6.0 : 0.0)), s, split_planes_kernel, grid, dim3(256), 0,
+            src, R, C, Rp, (unsigned short*)P, (unsigned short*)PT);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ the product
+struct GxArgs {
+  const unsigned short* Ap;   // planes of A, k-group-major: element (plane, row, k) at plane * aPlane + ((k / 8) * aLd + row) * 8 + k % 8
+  long aPlane, aLd;           //   (aLd = rows of the whole operand)
+  const void* B;              // BMODE 0: planes like A (rows = n, bLd = rows of the whole operand); 1: fp32 [n][k] (k contiguous,
+  long bPlane, bLd;           //       row stride bLd); 2: fp32 [k][n] (n contiguous, k stride bLd)
+  float* C; long ldc;
+  const float* bias;
+  int M, N, K, kPerSplit, out_mode;   // 0 store, 1 add, 3 split-K slab [split][M][N]
+  int tm, tn;                         // row / column tiles (the grid is one-dimensional: tm * tn * splits blocks)
+};
+
+// Block = TM (64 | 128) rows x 256 columns, EIGHT waves side by side along the columns (wave = all TM rows x 32 columns: one
+// weight fragment, split once in registers, serves TM / 32 accumulators).  Executed MFMA flops per operand byte brought to
+// LDS: 2 TM 256 6 / (6 TM + 4 256) = 219 with 128 rows -- the tile is this large because the product is otherwise bound by
+// L2 -> LDS delivery, not by the matrix pipe.  K step = 16 = one MFMA per accumulator and plane pair; a RING of three LDS
+// stages filled by LDS-DMA two steps ahead (operands stream from HBM / L2 with ~2 us of latency under load: one step ahead
+// left every step waiting for its tile), counted vmcnt, one barrier per step.  84 - 108 KB of LDS: one block per CU.
+#define GX_TN 256
+#define GX_RING 3
+template <int TM, int BMODE>
+__global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
+  constexpr int MT = TM / 32;
+  constexpr int SA = 96 * TM;                           // bytes of one A stage: [plane 3][half 2][TM rows][8 bf16]
+  constexpr int SB = BMODE == 0 ? 96 * GX_TN : 64 * GX_TN;   // B stage: planes | [256 n][4 chunks of 4 k] | [16 k][256 n] fp32
+  constexpr int NA = SA / 1024, NB = SB / 1024;         // wave instructions (1 KB each) per stage
+  constexpr int IA = (NA + 7) / 8, IB = NB / 8;         // ... per wave (A: the last ones may repeat a slot -- same bytes twice)
+  static_assert(NB % 8 == 0, "B stage must deal evenly to the eight waves");
+  constexpr int SS = SA + SB;
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the virtual index gives
+  // every XCD a CONTIGUOUS range, inside which the row tiles of one (column tile, K split) follow each other: the blocks
+  // that read the same B tile -- the big operand: weights or X^T planes -- run together on one XCD and fetch it from HBM
+  // once; the A tiles (activation planes, a few MB in all) stay L2-resident anyway.
+  int v;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    v = xcd * q + min(xcd, r) + idx;
+  }
+  const int mt_id = v % p.tm;
+  v /= p.tm;
+  const int nt_id = v % p.tn, split = v / p.tn;
+  const int m0 = mt_id * TM, n0 = nt_id * GX_TN;
+  const int kbeg = split * p.kPerSplit;
+  const int kend = min(kbeg + p.kPerSplit, p.K);   // (kend - kbeg is a multiple of 16: every stage is whole)
+  const int nsteps = (kend - kbeg) >> 4;
+
+  xf32x16 acc[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // ---- this lane's DMA sources at k = kbeg (one per wave instruction it issues) and what a K step adds to them
+  const char* srcA[IA];
+  const char* srcB[IB];
+  int dstA[IA];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int q = (wave + 8 * i) % NA;     // (NA not a multiple of 8: the surplus instructions repeat a slot)
+    const int s = q * 64 + lane;
+    const int pl = s / (2 * TM), hh = (s / TM) & 1, row = s % TM;
+    const int rr = min(m0 + row, p.M - 1);
+    srcA[i] = reinterpret_cast<const char*>(p.Ap + (size_t)pl * p.aPlane + ((size_t)((kbeg >> 3) + hh) * p.aLd + rr) * 8);
+    dstA[i] = q * 1024;
+  }
+  long stepB;
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int q = wave + 8 * i;
+    const int s = q * 64 + lane;
+    if (BMODE == 0) {
+      const unsigned short* Bp = reinterpret_cast<const unsigned short*>(p.B);
+      const int pl = s / (2 * GX_TN), hh = (s / GX_TN) & 1, row = s % GX_TN;
+      const int rr = min(n0 + row, p.N - 1);
+      srcB[i] = reinterpret_cast<const char*>(Bp + (size_t)pl * p.bPlane + ((size_t)((kbeg >> 3) + hh) * p.bLd + rr) * 8);
+    } else if (BMODE == 1) {
+      const float* Bf = reinterpret_cast<const float*>(p.B);
+      const int row = s >> 2, cphys = s & 3;
+      const int rr = min(n0 + row, p.N - 1);
+      srcB[i] = reinterpret_cast<const char*>(Bf + (size_t)rr * p.bLd + kbeg + ((cphys ^ ((row >> 2) & 3)) << 2));
+    } else {
+      const float* Bf = reinterpret_cast<const float*>(p.B);
+      const int kr = s >> 6, n4 = (s & 63) * 4;
+      const int nn = min(n0 + n4, p.N - 4);
+      srcB[i] = reinterpret_cast<const char*>(Bf + (size_t)(kbeg + kr) * p.bLd + nn);
+    }
+  }
+  stepB = BMODE == 0 ? 32 * (long)p.bLd : BMODE == 1 ? 64 : 64 * (long)p.bLd;   // bytes per K step of 16
+  const long stepA = 32 * (long)p.aLd;                                             // (two k groups of all rows)
+  auto issue = [&](int step) {
+    char* base = xsm + (step % GX_RING) * SS;
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)step * stepA),
+                                       (__attribute__((address_space(3))) void*)(base + dstA[i]), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (long)step * stepB),
+                                       (__attribute__((address_space(3))) void*)(base + SA + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+
+  issue(0);
+  if (nsteps > 1) issue(1);
+  const int brow = wave * 32 + li;   // this lane's column inside the block tile
+  for (int step = 0; step < nsteps; ++step) {
+    // stage `step` has landed in this wave's part (DMA retires in order: at most the next stage's instructions in flight)
+    if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // ... in every wave's part, and every wave is done with stage step - 1, whose slot is refilled now
+    if (step + 2 < nsteps) issue(step + 2);
+    const char* A_ = xsm + (step % GX_RING) * SS;
+    const char* B_ = A_ + SA;
+    xbf16x8 bp[3];
+    if (BMODE == 0) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        bp[pl] = *reinterpret_cast<const xbf16x8*>(B_ + ((pl * 2 + h) * GX_TN + brow) * 16);
+    } else {
+      float vv[8];
+      if (BMODE == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float4 q = *reinterpret_cast<const float4*>(B_ + (brow * 4 + ((2 * h + c) ^ ((brow >> 2) & 3))) * 16);
+          vv[4 * c] = q.x; vv[4 * c + 1] = q.y; vv[4 * c + 2] = q.z; vv[4 * c + 3] = q.w;
+        }
+      } else {
+        const float* Bf = reinterpret_cast<const float*>(B_);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = Bf[(8 * h + j) * GX_TN + brow];
+      }
+      uint4 H, Mi, L;
+      x_split8(vv, H, Mi, L);
+      bp[0] = __builtin_bit_cast(xbf16x8, H);
+      bp[1] = __builtin_bit_cast(xbf16x8, Mi);
+      bp[2] = __builtin_bit_cast(xbf16x8, L);
+    }
+    xbf16x8 ap[MT][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        ap[mt][pl] = *reinterpret_cast<const xbf16x8*>(A_ + ((pl * 2 + h) * TM + mt * 32 + li) * 16);
+    // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mt][PA[t]], bp[PB[t]], acc[mt], 0, 0, 0);
+  }
+
+  // ---- epilogue: D layout col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
+  const int n = n0 + brow;
+  if (n < p.N) {
+    const float bv = (p.bias && split == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M) {
+          const float val = acc[mt][r] + bv;
+          if (p.out_mode == 3) {
+            p.C[((long)split * p.M + m) * p.N + n] = val;
+          } else {
+            float* dst = p.C + (long)m * p.ldc + n;
+            if (p.out_mode == 0) *dst = val; else *dst += val;
+          }
+        }
+      }
+    }
+  }
+}
+
+bool linear_x_eligible(int R, int I, int O) {
+  static const bool on = !(getenv("FRCNN_GEMM_X") && atoi(getenv("FRCNN_GEMM_X")) == 0);
+  return on && get_split_bf16() && I % 16 == 0 && O % 16 == 0 && R >= 32 && (double)R * I * O >= 1.0e9;
+}
+
+template <int TM, int BMODE>
+static int launch_gx(GxArgs& a, dim3 grid, double flops, double bytes, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<TM, BMODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const size_t lds = GX_RING * (size_t)(96 * TM + (BMODE == 0 ? 96 * GX_TN : 64 * GX_TN));
+  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_planes_kernel<TM, BMODE>), grid, dim3(512), lds, a);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// Tile height and K split by a round model: one block per CU (256 slots); a block's time ~ steps x (cost of a K step, which
+// grows with the row tiles it multiplies) + a fixed prologue / epilogue; the launch takes ceil(blocks / 256) rounds.
+static void gx_plan(int M, int N, int K, int splitK_max, int* TM, int* splitK) {
+  double best = 1e300;
+  for (int tmv : {128, 64}) {
+    if (const char* e = getenv("FRCNN_GX_TM")) if (atoi(e) != tmv) continue;
+    const long tiles = (long)cdiv(M, tmv) * cdiv(N, GX_TN);
+    for (int sk = 1; sk <= splitK_max; ++sk) {
+      const int kper = cdiv(cdiv(K, sk), 16) * 16;
+      if (sk > 1 && kper < 256) break;
+      const int sk_eff = cdiv(K, kper);
+      const long rounds = cdivl(tiles * sk_eff, 256);
+      const double step_cost = tmv == 128 ? 1.0 : 0.62;   // 24 vs 12 MFMAs behind the same fragment split and barrier
+      double cost = rounds * ((kper / 16) * step_cost + 40.0) + (sk_eff > 1 ? 8.0 * sk_eff : 0.0);   // + slab traffic
+      if (cost < best) { best = cost; *TM = tmv; *splitK = sk_eff; }
+    }
+  }
+  if (const char* e = getenv("FRCNN_GX_SPLITK")) *splitK = std::max(1, atoi(e));
+}
+
+static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const float* bias, int out_mode, hipStream_t s, int ws_slot) {
+  FR_CHECK(a.K % 16 == 0, "gemm_planes: K = %d must be a multiple of 16", a.K);
+  int TM = 128, splitK = 1;
+  gx_plan(a.M, a.N, a.K, splitK_max, &TM, &splitK);
+  const int tm = cdiv(a.M, TM), tn = cdiv(a.N, GX_TN);
+  a.kPerSplit = cdiv(cdiv(a.K, splitK), 16) * 16;
+  splitK = cdiv(a.K, a.kPerSplit);
+  a.C = user_C; a.bias = bias; a.out_mode = out_mode;
+  if (splitK > 1) {
+    float* ws = nullptr;
+    FR_TRY(gemm_workspace_get((size_t)splitK * a.M * a.N * 4, &ws, ws_slot & 7));
+    a.C = ws; a.bias = nullptr; a.out_mode = 3;
+  }
+  a.tm = tm; a.tn = tn;
+  dim3 grid(tn * tm * splitK);
+  const double flops = 2.0 * a.M * a.N * (double)a.K;
+  const double bytes = 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
+  int rc;
+  if (TM == 128) rc = bmode == 0 ? launch_gx<128, 0>(a, grid, flops, bytes, s) : bmode == 1 ? launch_gx<128, 1>(a, grid, flops, bytes, s)
+                                                                                             : launch_gx<128, 2>(a, grid, flops, bytes, s);
+  else rc = bmode == 0 ? launch_gx<64, 0>(a, grid, flops, bytes, s) : bmode == 1 ? launch_gx<64, 1>(a, grid, flops, bytes, s)
+                                                                                 : launch_gx<64, 2>(a, grid, flops, bytes, s);
+  FR_TRY(rc);
+  if (splitK > 1) FR_TRY(gemm_reduce_slabs(a.C, splitK, a.M, a.N, bias, user_C, a.ldc, out_mode == OUT_ADD, s));
+  return FRCNN_OK;
+}
+
+// Y[R][O] = X W^T + b ; Xp = planes of X, [3][I/8][R][8]
+int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot) {
+  FR_CHECK(((uintptr_t)W & 3) == 0 && I % 16 == 0, "linear_x_forward: operand alignment");
+  GxArgs a;
+  a.Ap = (const unsigned short*)Xp; a.aPlane = (long)R * I; a.aLd = R;
+  a.B = W; a.bPlane = 0; a.bLd = I;
+  a.ldc = O; a.M = R; a.N = O; a.K = I;
+  return gx_run(a, 1, 24, y, bias, OUT_STORE, s, ws_slot);
+}
+
+// gX[R][I] (= | +=) gY W ; Gp = planes of gY, [3][O/8][R][8]
+int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot) {
+  FR_CHECK(((uintptr_t)W & 3) == 0 && I % 4 == 0 && O % 16 == 0, "linear_x_dgrad: operand alignment");
+  GxArgs a;
+  a.Ap = (const unsigned short*)Gp; a.aPlane = (long)R * O; a.aLd = R;
+  a.B = W; a.bPlane = 0; a.bLd = I;
+  a.ldc = I; a.M = R; a.N = I; a.K = O;
+  return gx_run(a, 2, 4, gx, nullptr, out_mode, s, ws_slot);
+}
+
+// gW[O][I] += gY^T X ; GpT = planes of gY^T [3][Rp/8][O][8], XpT = planes of X^T [3][Rp/8][I][8] (k = r; r >= R zero)
+int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot) {
+  const int Rp = linear_x_rows_padded(R);
+  GxArgs a;
+  a.Ap = (const unsigned short*)GpT; a.aPlane = (long)O * Rp; a.aLd = O;
+  a.B = XpT; a.bPlane = (long)I * Rp; a.bLd = I;
+  a.ldc = I; a.M = O; a.N = I; a.K = Rp;
+  return gx_run(a, 0, 1, gw, nullptr, OUT_ADD, s, ws_slot);
+}
+
+}  // namespace frcnn

@@ -111,6 +111,19 @@ int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, fl
 // C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
              long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot = 0);
+int gemm_workspace_get(size_t need, float** out, int slot);
+int gemm_reduce_slabs(const float* slab, int nSplit, int M, int N, const float* bias, float* C, long ldc, bool accumulate,
+                      hipStream_t s);
+// ---- split-bf16 operand form of the large Linear (gemmx.hip): activation operands as three bf16 planes written once
+// (split_planes), weights split in registers; fp32 results of fp32 accuracy (see convx.hip)
+bool linear_x_eligible(int R, int I, int O);
+int linear_x_rows_padded(int R);                       // rows of the transposed planes (R rounded up to 16, zero filled)
+int split_planes(const float* src, int R, int C, void* P /* [3][C/8][R][8] bf16 or null */, void* PT /* [3][Rp/8][C][8] or null */,
+                 hipStream_t s);
+int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot = 0);
+int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot = 0);
+int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot = 0);
+
 
 // ---------------------------------------------------------------- roi (roi.hip)
 int roi_pool_forward(const float* fmap, int C, int H, int W, const int* wins, int R, int kh, int kw,

@@ -79,6 +79,8 @@ struct ClsLayer {
   float p_drop;
   long w_off, b_off, bnw_off, bnb_off, a_off;
   DevBuf lin, pre, post, xhat, invstd, mask, g;
+  DevBuf xp, xpT, gp, gpT;    // split-bf16 planes of the layer's input and of its output gradient (gemmx.hip), when it takes that form
+  bool x_form = false;        // set per call: this layer's products run in the split-bf16 operand form
 };
 
 }  // namespace frcnn
@@ -366,7 +368,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   }
   for (auto& l : m->cls) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
-    l.mask.release(); l.g.release();
+    l.mask.release(); l.g.release(); l.xp.release(); l.xpT.release(); l.gp.release(); l.gpT.release();
   }
   m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
@@ -954,6 +956,12 @@ static int ensure_cnet(frcnn_model* m, int R) {
     FR_TRY(L.post.ensure(n));
     FR_TRY(L.g.ensure(n));
     if (L.p_drop > 0.f) FR_TRY(L.mask.ensure(n));
+    L.x_form = linear_x_eligible(R, L.in, L.n);
+    if (L.x_form) {
+      const size_t Rp = (size_t)linear_x_rows_padded(R);
+      FR_TRY(L.xp.ensure((size_t)3 * R * L.in * 2)); FR_TRY(L.xpT.ensure((size_t)3 * L.in * Rp * 2));
+      FR_TRY(L.gp.ensure((size_t)3 * R * L.n * 2)); FR_TRY(L.gpT.ensure((size_t)3 * L.n * Rp * 2));
+    }
   }
   int nc = m->d.class_count + 1;
   int nf = m->cls.empty() ? m->D : m->cls.back().n;
@@ -976,7 +984,12 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
   float* bnr = bn_running;
   for (size_t l = 0; l < m->cls.size(); ++l) {
     ClsLayer& L = m->cls[l];
-    FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s));
+    if (L.x_form) {   // split-bf16 operand form: the input's planes once (transposed too when a backward pass follows)
+      FR_TRY(split_planes(cur, R, L.in, L.xp.p, training ? L.xpT.p : nullptr, s));
+      FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s));
+    } else {
+      FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s));
+    }
     const float* pre = L.lin.f();
     if (L.bn) {
       FR_CHECK(training || bnr, "cnet_forward: evaluate mode needs bn_running");
@@ -1042,7 +1055,13 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
                          grad + L.bnw_off, grad + L.bnb_off, s));
     const float* in = l == 0 ? m->cnet_x : m->cls[l - 1].post.f();
     float* gin = l == 0 ? gx : m->cls[l - 1].post.f();  // post[l-1] is dead after this point: reuse as gradient
-    if (l > 0) {
+    if (L.x_form) {
+      if (!m->training) FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, s));   // (an evaluate-mode forward does not write them)
+      FR_TRY(split_planes(L.g.f(), R, L.n, gin ? L.gp.p : nullptr, L.gpT.p, s));
+      FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, s));
+      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
+      if (gin) FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
+    } else if (l > 0) {
       // gradient wrt post[l-1] must not overwrite `in` before the weight gradient used it
       FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
       FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));

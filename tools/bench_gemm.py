@@ -21,7 +21,9 @@ def run(R, I, O, reps=5):
         F._lib.call("frcnn_prof_enable", 0)
         F._lib.call("frcnn_prof_collect", la, ms, fl, by)
         t = sum(ms) / reps
-        print("R=%d I=%d O=%d %-6s %8.1f us  %6.2f TFLOP/s  weight stream %.2f TB/s" % (R, I, O, name, t * 1e3, 2.0 * R * I * O / t / 1e9, (O * I * 4.0 * (2 if name == "wgrad" else 1)) / t / 1e9), flush=True)
+        kg = F._lib.KC_NAMES.index("gemm"); ke = F._lib.KC_NAMES.index("elemwise")
+        print("R=%d I=%d O=%d %-6s %8.1f us  %6.2f TFLOP/s  (product kernel %.1f us x %d, split planes / slab fold %.1f us x %d)"
+              % (R, I, O, name, t * 1e3, 2.0 * R * I * O / t / 1e9, ms[kg] / reps * 1e3, la[kg] // reps, ms[ke] / reps * 1e3, la[ke] // reps), flush=True)
 
 if __name__ == "__main__":
     for R in (138, 320, 560):
