@@ -5,7 +5,7 @@ OUT=../libfrcnn_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed"
 mkdir -p ../build
 pids=(); names=()
-for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip image.hip convx.hip wgradx.hip gemmx.hip api.cpp net.cpp anchors.cpp comm.cpp; do
+for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip image.hip convx.hip wgradx.hip gemmx.hip detect.hip api.cpp net.cpp anchors.cpp comm.cpp; do
   o=../build/${f%.*}.o
   if [ "$FORCE" = "1" ] || [ ! -f $o ] || [ $f -nt $o ] || [ kernels.h -nt $o ] || [ common.h -nt $o ] || [ ../../include/frcnn_hip.h -nt $o ]; then
     case $f in *.cpp) X="-x hip";; *) X="";; esac

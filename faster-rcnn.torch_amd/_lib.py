@@ -56,6 +56,10 @@ _SIGS = {
     "frcnn_nms_workspace_bytes": ([C.c_int], C.c_size_t),
     "frcnn_nms_device": ([vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp], C.c_int),
     "frcnn_nms_device_classes": ([vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "frcnn_nms_device_n": ([vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, C.c_size_t, vp], C.c_int),
+    "frcnn_roi_windows": ([vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
+    "frcnn_detect_post": ([vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp], C.c_int),
+    "frcnn_detect_gather": ([vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "frcnn_nms_host": ([vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp], C.c_int),
     "frcnn_conv2d_forward": ([vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
     "frcnn_conv2d_backward_input": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),

@@ -154,6 +154,25 @@ int frcnn_nms_device_classes(const float* boxes, int n, int ncols, float overlap
                              long long* pick, int* count, void* ws, size_t ws_bytes, void* stream) {
   return nms_device(boxes, n, ncols, overlap, key_mode, key_col, pick, count, ws, ws_bytes, S(stream), cls);
 }
+int frcnn_nms_device_n(const float* boxes, int n_cap, const int* n_dev, int ncols, float overlap, int key_mode, int key_col,
+                       const int* cls, long long* pick, int* count, void* ws, size_t ws_bytes, void* stream) {
+  FR_CHECK(n_dev, "frcnn_nms_device_n: NULL device count");
+  return nms_device(boxes, n_cap, ncols, overlap, key_mode, key_col, pick, count, ws, ws_bytes, S(stream), cls, n_dev);
+}
+int frcnn_roi_windows(const double* rect, const long long* pick, int k, const int* layers_host, int nlayers, int fmH, int fmW,
+                      int* wins, void* stream) {
+  FR_CHECK(rect && wins && (layers_host || nlayers == 0), "frcnn_roi_windows: NULL argument");
+  return roi_windows(rect, pick, k, layers_host, nlayers, fmH, fmW, wins, S(stream));
+}
+int frcnn_detect_post(const int* cls, const float* conf, const float* bbox, const double* rect, const long long* pick, int R,
+                      int bgclass, double min_conf, float* bb, int* kc, int* keep_row, double* r2, int* K_dev, void* stream) {
+  return detect_post(cls, conf, bbox, rect, pick, R, bgclass, min_conf, bb, kc, keep_row, r2, K_dev, S(stream));
+}
+int frcnn_detect_gather(const long long* wpick, const int* nwin_dev, int cap, const int* keep_row, const int* kc, const float* bb,
+                        const double* r2, const long long* pick, const float* match_p, const double* match_rect,
+                        const int* match_idx, double* rec, void* stream) {
+  return detect_gather(wpick, nwin_dev, cap, keep_row, kc, bb, r2, pick, match_p, match_rect, match_idx, rec, S(stream));
+}
 int frcnn_nms_host(const float* boxes_host, int n, int ncols, float overlap, int key_mode, int key_col,
                    long long* pick_host, int* count_host) {
   if (n <= 0) { *count_host = 0; return FRCNN_OK; }

@@ -151,7 +151,16 @@ int loss_accumulate(const double* ex_loss, int E, double* acc, hipStream_t s);
 size_t nms_workspace_bytes(int n);
 // cls (optional, int[n]): rows only suppress rows of the same class (Detector.lua:125-136 in one pass)
 int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
-               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls = nullptr);
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls = nullptr,
+               const int* n_dev = nullptr);   // n_dev: the row count is read from device memory (<= n)
+// ---- Detector:detect glue that stays on the device (detect.hip)
+int roi_windows(const double* rect, const long long* pick, int k, const int* layers, int nlayers, int fmH, int fmW, int* wins,
+                hipStream_t s);
+int detect_post(const int* cls, const float* conf, const float* bbox, const double* rect, const long long* pick, int R,
+                int bgclass, double min_conf, float* bb, int* kc, int* keep_row, double* r2, int* K_dev, hipStream_t s);
+int detect_gather(const long long* wpick, const int* nwin_dev, int cap, const int* keep_row, const int* kc, const float* bb,
+                  const double* r2, const long long* pick, const float* mp, const double* rect, const int* midx, double* rec,
+                  hipStream_t s);
 
 // ---------------------------------------------------------------- cnet small ops (cnet.hip)
 int bn_forward(const float* x, int R, int n, const float* gamma, const float* beta, float* running,

@@ -17,8 +17,12 @@
 
 namespace frcnn {
 
-__global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, int ncols, int key_mode,
+// n_dev (optional, every kernel): the row count lives in device memory (the match count a scan just produced, the
+// number of candidates that passed the class test): n = min(*n_dev, n) -- the launch is sized for the host-side bound
+// and the pipeline that feeds it never waits for a read-back (Detector.lua:39-85 without a host round trip).
+__global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, const int* __restrict__ n_dev, int ncols, int key_mode,
                                 int key_col, float* __restrict__ area, float* __restrict__ key) {
+  if (n_dev) n = min(*n_dev, n);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* b = boxes + (size_t)i * ncols;
@@ -35,8 +39,10 @@ __global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, int ncol
 // 2-D grid: block (x, y) counts, for its 256 keys i, the keys j of slice y; partial counts meet in an integer
 // atomic (exact, order-independent), then nms_scatter_kernel writes the permutation.
 #define NMS_RANK_SLICE 1024
-__global__ void nms_rank_kernel(const float* __restrict__ key, int n, int* __restrict__ rank) {
+__global__ void nms_rank_kernel(const float* __restrict__ key, int n, const int* __restrict__ n_dev, int* __restrict__ rank) {
   __shared__ float sk[256];
+  if (n_dev) n = min(*n_dev, n);
+  if ((int)(blockIdx.x * blockDim.x) >= n || (int)(blockIdx.y * NMS_RANK_SLICE) >= n) return;   // (uniform per block)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float ki = i < n ? key[i] : 0.f;
   const int jbeg = blockIdx.y * NMS_RANK_SLICE, jend = min(jbeg + NMS_RANK_SLICE, n);
@@ -54,7 +60,8 @@ __global__ void nms_rank_kernel(const float* __restrict__ key, int n, int* __res
   }
   if (i < n && r) atomicAdd(rank + i, r);
 }
-__global__ void nms_scatter_kernel(const int* __restrict__ rank, int n, int* __restrict__ sorted) {
+__global__ void nms_scatter_kernel(const int* __restrict__ rank, int n, const int* __restrict__ n_dev, int* __restrict__ sorted) {
+  if (n_dev) n = min(*n_dev, n);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sorted[n - 1 - rank[i]] = i;
 }
@@ -62,10 +69,12 @@ __global__ void nms_scatter_kernel(const int* __restrict__ rank, int n, int* __r
 // mask[a][w] bit b: box at sorted position a suppresses box at sorted position w*64+b (b > a)
 // cls (optional): rows only suppress rows of the same class -- the per-class NMS problems of Detector.lua:125-136 in one pass
 __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, const float* __restrict__ area,
-                                const int* __restrict__ sorted, int n, int nw, float thr, const int* __restrict__ cls,
-                                unsigned long long* __restrict__ mask) {
+                                const int* __restrict__ sorted, int n, const int* __restrict__ n_dev, int nw, float thr,
+                                const int* __restrict__ cls, unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;
+  if (n_dev) n = min(*n_dev, n);
+  if (cb * 64 >= n) return;   // (rows of the device-side count only; nw stays the pitch of the host-side bound)
   __shared__ float cx1[64], cy1[64], cx2[64], cy2[64], car[64];
   __shared__ int ccl[64];
   const int t = threadIdx.x;  // 64 threads = one wave
@@ -112,23 +121,26 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
 // round-robin, so the global loads of one step are independent and coalesced along the words.
 #define NMS_RED_THREADS 1024
 __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
-                                                                     const int* __restrict__ sorted, int n, int nw,
+                                                                     const int* __restrict__ sorted, int n,
+                                                                     const int* __restrict__ n_dev, int nwp,
                                                                      long long* __restrict__ pick, int* __restrict__ count) {
   extern __shared__ unsigned long long removed[];  // [nw]
+  if (n_dev) n = min(*n_dev, n);
+  const int nw = (n + 63) >> 6;   // words of this run; nwp = pitch of the mask rows (the host-side bound)
   __shared__ int kept_list[64];
   __shared__ int nkept;
   __shared__ int cnt;
   for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
   if (threadIdx.x == 0) cnt = 0;
   unsigned long long diag_next = 0ull;
-  if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * nw];
+  if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * nwp];
   __syncthreads();
   for (int g = 0; g < nw; ++g) {
     if (threadIdx.x < 64) {  // wave 0 resolves the diagonal block sequentially
       const int row = g * 64 + threadIdx.x;
       const unsigned long long diag = diag_next;
       const int nrow = row + 64;
-      if (g + 1 < nw) diag_next = nrow < n ? mask[(size_t)nrow * nw + g + 1] : 0ull;
+      if (g + 1 < nw) diag_next = nrow < n ? mask[(size_t)nrow * nwp + g + 1] : 0ull;
       // wave-uniform bit sets in scalar registers; one step per KEPT box (first clear bit), not per box
       const unsigned long long w0 = removed[g];
       unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsig
     const int items = nk * W;
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
       const int q = it / W, w = g + 1 + (it - q * W);
-      const unsigned long long v = mask[(size_t)kept_list[q] * nw + w];
+      const unsigned long long v = mask[(size_t)kept_list[q] * nwp + w];
       if (v) atomicOr(&removed[w], v);
     }
     __syncthreads();
@@ -179,7 +191,7 @@ size_t nms_workspace_bytes(int n) {
 }
 
 int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode, int key_col,
-               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls) {
+               long long* pick, int* count, void* ws, size_t ws_bytes, hipStream_t s, const int* cls, const int* n_dev) {
   if (n <= 0) {  // nms.lua:26-28
     FR_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
     return FRCNN_OK;
@@ -199,15 +211,15 @@ int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode
   size_t off = ((size_t)n * 16 + 255) / 256 * 256;
   unsigned long long* mask = (unsigned long long*)(base + off);
   double pair_bytes = 20.0 * n;
-  FR_LAUNCH(KC_NMS, 0, pair_bytes, s, nms_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, boxes, n, ncols,
+  FR_LAUNCH(KC_NMS, 0, pair_bytes, s, nms_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, boxes, n, n_dev, ncols,
             key_mode, key_col, area, key);
   FR_HIP(hipMemsetAsync(rank, 0, (size_t)n * 4, s));
-  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256), cdiv(n, NMS_RANK_SLICE)), dim3(256), 0, key, n, rank);
-  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (const int*)rank, n, sorted);
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_rank_kernel, dim3(cdiv(n, 256), cdiv(n, NMS_RANK_SLICE)), dim3(256), 0, key, n, n_dev, rank);
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (const int*)rank, n, n_dev, sorted);
   FR_LAUNCH(KC_NMS, 3.5 * n * (double)n, 8.0 * n * nw / 2, s, nms_mask_kernel, dim3(nw, nw), dim3(64), 0,
-            boxes, ncols, area, sorted, n, nw, overlap, cls, mask);
+            boxes, ncols, area, sorted, n, n_dev, nw, overlap, cls, mask);
   FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(NMS_RED_THREADS), (size_t)nw * 8, mask,
-            sorted, n, nw, pick, count);
+            sorted, n, n_dev, nw, pick, count);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -35,7 +35,7 @@ __global__ void roi_pool_forward_kernel(const float* __restrict__ fmap, int C, i
         if (v > best) { best = v; bi = (r0 + y) * W + (c0 + x); }
       }
     out[t] = best;
-    idx[t] = bi;
+    if (idx) idx[t] = bi;   // (inference has no backward pass: Detector.lua:96-98 drops the indices)
   }
 }
 

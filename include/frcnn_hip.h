@@ -114,6 +114,31 @@ int frcnn_nms_device(const float *boxes, int n, int ncols, float overlap, int ke
 int frcnn_nms_device_classes(const float *boxes, int n, int ncols, float overlap, int key_mode, int key_col,
                              const int *cls, long long *pick, int *count, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* The same with the row count in DEVICE memory: n = min(*n_dev, n_cap); launches and workspace are sized for n_cap
+ * (frcnn_nms_workspace_bytes(n_cap)).  Lets Detector.lua:39-85 run scan -> NMS, and :115-136 class test -> per-class NMS,
+ * without a host round trip for the count in between.  cls may be NULL. */
+int frcnn_nms_device_n(const float *boxes, int n_cap, const int *n_dev, int ncols, float overlap, int key_mode, int key_col,
+                       const int *cls, long long *pick, int *count, void *workspace, size_t workspace_bytes, void *stream);
+/* ---- Detector:detect glue kept on the device (Detector.lua:88-136; csrc/detect.hip) ------------------------------
+ * frcnn_roi_windows: extract_roi_pooling_input (objective.lua:5-13) for k ROIs at once -- Localizer:inputToFeatureRect
+ * (Localizer.lua:41-67, the reference's double arithmetic incl. its dH/dW mix-ups) over layers_host[nlayers][6] =
+ * {kW,kH,dW,dH,padW,padH} (frcnn_model_localizer_layers), clip to the fmH x fmW map, 1-based inclusive window
+ * wins[k][4] = {row_lo,row_hi,col_lo,col_hi}.  rect: device double[n][4]; pick: optional device int64[k] of 1-based rows of
+ * rect (the NMS candidates), NULL = rows 0..k-1. */
+int frcnn_roi_windows(const double *rect, const long long *pick, int k, const int *layers_host, int nlayers, int fmH, int fmW,
+                      int *wins, void *stream);
+/* frcnn_detect_post: Detector.lua:106-122 for the R candidates (cls / conf from frcnn_cnet_decode, bbox = cnet's R x 4
+ * output, rect / pick as above): candidate r survives iff cls[r] != bgclass and exp(conf[r]) > min_conf; survivors, in
+ * candidate order, get r2 = Anchors.anchorToInput(anchor rect, bbox row) in double (r2[K][4]), bb[K][5] = {float(r2), conf},
+ * kc[K] = class, keep_row[K] = r (0-based); *K_dev = their number (device).  All outputs need room for R rows. */
+int frcnn_detect_post(const int *cls, const float *conf, const float *bbox, const double *rect, const long long *pick, int R,
+                      int bgclass, double min_conf, float *bb, int *kc, int *keep_row, double *r2, int *K_dev, void *stream);
+/* frcnn_detect_gather: one record of 16 doubles per winner q < min(*nwin_dev, cap), in the pick order wpick of the
+ * per-class NMS over bb/kc: {class, candidate row (1-based), confidence (log-prob), p (anchor log-prob), anchor rect x4,
+ * r2 x4, anchor index {layer,aspect,y,x}} -- everything Detector.lua:116-122 puts into a detection's table. */
+int frcnn_detect_gather(const long long *wpick, const int *nwin_dev, int cap, const int *keep_row, const int *kc,
+                        const float *bb, const double *r2, const long long *pick, const float *match_p,
+                        const double *match_rect, const int *match_idx, double *rec, void *stream);
 /* Host-pointer variant (the reference's nms runs on CPU FloatTensors): uploads, runs the same
  * kernels, downloads, synchronises. */
 int frcnn_nms_host(const float *boxes_host, int n, int ncols, float overlap, int key_mode,
