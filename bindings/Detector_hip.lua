@@ -61,120 +61,84 @@ function Detector:detect(input)                                         -- Detec
   local mi = ffi.cast('int*', scratch('match_idx', 16 * cap).ptr)
   local mr = ffi.cast('double*', scratch('match_rect', 32 * cap).ptr)
   local mb = ffi.cast('float*', scratch('match_box', 16 * cap).ptr)
-  local cnt = ffi.cast('int*', scratch('count', 16).ptr)
+  -- counts (device int[4]): matches, NMS candidates, candidates that pass the class test, winners
+  local cnt = ffi.cast('int*', scratch('counts', 16).ptr)
   check(C.frcnn_rpn_scan(maps, Hs, Ws, self.aw.ptr, self.ah.ptr, input_size[3], input_size[2], 0.95, cap, mp, mi, mr, mb,
                          cnt, ws.ptr, wsb, nil))
-  local count = ffi.new('int[1]')
-  check(C.frcnn_memcpy_d2h(count, cnt, 4, nil))
+  -- NON-MAXIMUM SUPPRESSION (:74-85) on the device, the match count read from DEVICE memory (no round trip between scan
+  -- and NMS); the score tensor is ignored by nms.lua -> key = max-y
+  local nwsb = tonumber(C.frcnn_nms_workspace_bytes(cap))
+  local nws = scratch('nms_ws', nwsb)
+  local dpick = ffi.cast('long long*', scratch('pick', 8 * cap).ptr)
+  check(C.frcnn_nms_device_n(mb, cap, cnt, 4, 0.25, 0, 0, nil, dpick, cnt + 1, nws.ptr, nwsb, nil))
+  local count = ffi.new('int[2]')
+  check(C.frcnn_memcpy_d2h(count, cnt, 8, nil))                          -- ---- read-back 1 of 2: two counts
   check(C.frcnn_stream_sync(nil))
   if count[0] > cap then
     error(string.format('Detector: %d anchors pass p > 0.95, more than the %d the maps hold', count[0], cap))
   end
-  local nm = count[0]
+  local nm, R = count[0], count[1]
 
   local winners = {}
   if nm > 0 then                                                        -- :71
-    -- NON-MAXIMUM SUPPRESSION (:74-85) on the device; the score tensor is ignored by nms.lua -> key = max-y
-    local nwsb = tonumber(C.frcnn_nms_workspace_bytes(nm))
-    local nws = scratch('nms_ws', nwsb)
-    local dpick = ffi.cast('long long*', scratch('pick', 8 * nm).ptr)
-    check(C.frcnn_nms_device(mb, nm, 4, 0.25, 0, 0, dpick, cnt, nws.ptr, nwsb, nil))
-    local h_p, h_idx, h_rect = ffi.new('float[?]', nm), ffi.new('int[?]', 4 * nm), ffi.new('double[?]', 4 * nm)
-    local h_pick = ffi.new('long long[?]', nm)
-    check(C.frcnn_memcpy_d2h(count, cnt, 4, nil))
-    check(C.frcnn_memcpy_d2h(h_pick, dpick, 8 * nm, nil))
-    check(C.frcnn_memcpy_d2h(h_p, mp, 4 * nm, nil))
-    check(C.frcnn_memcpy_d2h(h_idx, mi, 16 * nm, nil))
-    check(C.frcnn_memcpy_d2h(h_rect, mr, 32 * nm, nil))
-    check(C.frcnn_stream_sync(nil))
-    local R = count[0]
-    local candidates = {}
-    for k = 0, R - 1 do
-      local m = tonumber(h_pick[k]) - 1                                 -- 1-based match id -> 0-based row
-      local l, a, y, x = h_idx[4 * m], h_idx[4 * m + 1], h_idx[4 * m + 2], h_idx[4 * m + 3]
-      candidates[k + 1] = { p = h_p[m], a = self.anchors:get(l, a, y, x), l = l,
-                            r = Rect.new(h_rect[4 * m], h_rect[4 * m + 1], h_rect[4 * m + 2], h_rect[4 * m + 3]) }
-    end
-    print(string.format('candidates: %d', #candidates))                 -- :87
-
-    -- REGION CLASSIFICATION (:90-101): every candidate's window, one pooling launch, one cnet pass
+    print(string.format('candidates: %d', R))                           -- :87
+    -- REGION CLASSIFICATION (:90-101): every candidate's window (objective.lua:5-13 for all of them in one kernel), one
+    -- pooling launch (no indices: there is no backward pass), one cnet pass
     cnet:evaluate()
     local fm = outputs[self.nheads + 1]
     local fs = fm:size()
-    local wins = ffi.new('int[?]', 4 * R)
-    for i, v in ipairs(candidates) do
-      local _, idx = extract_roi_pooling_input(v.r, self.localizer, fm)
-      local o = 4 * (i - 1)
-      wins[o], wins[o + 1], wins[o + 2], wins[o + 3] = idx[2][1], idx[2][2], idx[3][1], idx[3][2]
+    local nl = #self.localizer.layers
+    local layers = ffi.new('int[?]', 6 * nl)
+    for i, l in ipairs(self.localizer.layers) do
+      local o = 6 * (i - 1)
+      layers[o], layers[o + 1], layers[o + 2], layers[o + 3], layers[o + 4], layers[o + 5] = l.kW, l.kH, l.dW, l.dH, l.padW, l.padH
     end
     local dwins = ffi.cast('int*', scratch('wins', 16 * R).ptr)
-    check(C.frcnn_memcpy_h2d(dwins, wins, 16 * R, nil))
+    check(C.frcnn_roi_windows(mr, dpick, R, layers, nl, fs[2], fs[3], dwins, nil))
     local cinput = hip.view(scratch('cinput', 4 * R * D).ptr, { R, D })
-    local pidx = ffi.cast('int*', scratch('pidx', 4 * R * D).ptr)
-    check(C.frcnn_roi_pool_forward(fm.ptr, fs[1], fs[2], fs[3], dwins, R, kh, kw, cinput.ptr, pidx, nil))
+    check(C.frcnn_roi_pool_forward(fm.ptr, fs[1], fs[2], fs[3], dwins, R, kh, kw, cinput.ptr, nil, nil))
     local coutputs = cnet:forward(cinput)                               -- :101
     local bbox_out, cls_out = coutputs[1], coutputs[2]
     local dcls = ffi.cast('int*', scratch('cls', 4 * R).ptr)
     local dconf = ffi.cast('float*', scratch('conf', 4 * R).ptr)
     check(C.frcnn_cnet_decode(cls_out.ptr, R, ncls, dcls, dconf, nil))  -- :110-113 (arg-max of the log-probs)
-    local h_bbox, h_cls, h_conf = ffi.new('float[?]', 4 * R), ffi.new('int[?]', R), ffi.new('float[?]', R)
-    check(C.frcnn_memcpy_d2h(h_bbox, bbox_out.ptr, 16 * R, nil))
-    check(C.frcnn_memcpy_d2h(h_cls, dcls, 4 * R, nil))
-    check(C.frcnn_memcpy_d2h(h_conf, dconf, 4 * R, nil))
+    -- :106-122 on the device: class test, r2 = Anchors.anchorToInput(r, bbox) in double, survivors compacted in order
+    local dbb = ffi.cast('float*', scratch('bb5', 20 * R).ptr)
+    local dkc = ffi.cast('int*', scratch('bbcls', 4 * R).ptr)
+    local dkeep = ffi.cast('int*', scratch('keep_row', 4 * R).ptr)
+    local dr2 = ffi.cast('double*', scratch('r2', 32 * R).ptr)
+    check(C.frcnn_detect_post(dcls, dconf, bbox_out.ptr, mr, dpick, R, bgclass, 0.2, dbb, dkc, dkeep, dr2, cnt + 2, nil))
+    -- per-class NMS (:125-136), every class in ONE device pass: rows only suppress rows of their own class; a stable
+    -- partition of the picks by class is, per class, exactly nms(bb, 0.1, bb[{{}, 5}]) -- the score tensor is ignored by
+    -- nms.lua:42, the key is max-y.  The survivor count is read from device memory.
+    local cwsb = tonumber(C.frcnn_nms_workspace_bytes(R))
+    local cws = scratch('nms_ws2', cwsb)
+    local cpick = ffi.cast('long long*', scratch('wpick', 8 * R).ptr)
+    check(C.frcnn_nms_device_n(dbb, R, cnt + 2, 5, 0.1, 0, 0, dkc, cpick, cnt + 3, cws.ptr, cwsb, nil))
+    -- one record of 16 doubles per winner behind a 128-byte header that carries the four counts
+    local out = ffi.cast('double*', scratch('winners', 128 * (R + 1)).ptr)
+    check(C.frcnn_memcpy_d2d(out, cnt, 16, nil))
+    check(C.frcnn_detect_gather(cpick, cnt + 3, R, dkeep, dkc, dbb, dr2, dpick, mp, mr, mi, out + 16, nil))
+    local h = ffi.new('double[?]', 16 * (R + 1))
+    check(C.frcnn_memcpy_d2h(h, out, 128 * (R + 1), nil))                -- ---- read-back 2 of 2: the winner table
     check(C.frcnn_stream_sync(nil))
-
-    local kept = {}
-    for i, x in ipairs(candidates) do                                   -- :106-122
-      local t = torch.FloatTensor(4)
-      for k = 1, 4 do t[k] = h_bbox[4 * (i - 1) + k - 1] end
-      x.r2 = Anchors.anchorToInput(x.r, t)                              -- :107
-      x.class = h_cls[i - 1]
-      x.confidence = h_conf[i - 1]
-      if x.class ~= bgclass and math.exp(x.confidence) > 0.2 then       -- :115
-        table.insert(kept, x)
+    local nwin = ffi.cast('int*', h)[3]
+    -- classes in ascending order (the reference iterates with pairs(): unspecified), pick order within a class
+    local byclass, classes = {}, {}
+    for q = 1, nwin do
+      local v = h + 16 * q
+      local l, a, y, x = tonumber(v[12]), tonumber(v[13]), tonumber(v[14]), tonumber(v[15])
+      local det = { p = v[3], a = self.anchors:get(l, a, y, x), l = l, r = Rect.new(v[4], v[5], v[6], v[7]),
+                    r2 = Rect.new(v[8], v[9], v[10], v[11]), class = tonumber(v[0]), confidence = v[2] }
+      if not byclass[det.class] then
+        byclass[det.class] = {}
+        classes[#classes + 1] = det.class
       end
+      table.insert(byclass[det.class], det)
     end
-
-    -- per-class NMS (:125-136), every class in ONE device pass (frcnn_nms_device_classes): rows only suppress rows of
-    -- their own class; a stable partition of the picks by class is, per class, exactly nms(bb, 0.1, bb[{{}, 5}]) -- the
-    -- score tensor is ignored by nms.lua:42, the key is max-y.  One launch sequence and one read-back instead of one per
-    -- class (up to 200 with config/imagenet.lua).
-    local K = #kept
-    if K > 0 then
-      local bb = ffi.new('float[?]', 5 * K)
-      local kc = ffi.new('int[?]', K)
-      for j, r in ipairs(kept) do
-        local tt = r.r2:totensor()
-        for k = 1, 4 do bb[5 * (j - 1) + k - 1] = tt[k] end
-        bb[5 * (j - 1) + 4] = r.confidence
-        kc[j - 1] = r.class
-      end
-      local dbb = ffi.cast('float*', scratch('bb5', 20 * K).ptr)
-      local dkc = ffi.cast('int*', scratch('bbcls', 4 * K).ptr)
-      check(C.frcnn_memcpy_h2d(dbb, bb, 20 * K, nil))
-      check(C.frcnn_memcpy_h2d(dkc, kc, 4 * K, nil))
-      local cwsb = tonumber(C.frcnn_nms_workspace_bytes(K))
-      local cws = scratch('nms_ws', cwsb)
-      local cpick = ffi.cast('long long*', scratch('pick', 8 * K).ptr)
-      check(C.frcnn_nms_device_classes(dbb, K, 5, 0.1, 0, 0, dkc, cpick, cnt, cws.ptr, cwsb, nil))
-      local h_cp = ffi.new('long long[?]', K)
-      check(C.frcnn_memcpy_d2h(count, cnt, 4, nil))
-      check(C.frcnn_memcpy_d2h(h_cp, cpick, 8 * K, nil))
-      check(C.frcnn_stream_sync(nil))
-      -- classes in ascending order (the reference iterates with pairs(): unspecified), pick order within a class
-      local byclass, classes = {}, {}
-      for q = 0, count[0] - 1 do
-        local x = kept[tonumber(h_cp[q])]
-        if not byclass[x.class] then
-          byclass[x.class] = {}
-          classes[#classes + 1] = x.class
-        end
-        table.insert(byclass[x.class], x)
-      end
-      table.sort(classes)
-      for _, ci in ipairs(classes) do
-        for _, x in ipairs(byclass[ci]) do table.insert(winners, x) end
-      end
+    table.sort(classes)
+    for _, ci in ipairs(classes) do
+      for _, x in ipairs(byclass[ci]) do table.insert(winners, x) end
     end
   end
 

@@ -124,7 +124,8 @@ def test_lua_drop_in_files_are_consistent_with_the_abi():
     # the batched entry points of the training step and of detect, and the exchange step, are all reached from Lua
     for name in ("frcnn_pnet_forward_async_heads", "frcnn_pnet_anchor_loss_begin", "frcnn_pnet_anchor_loss_wait",
                  "frcnn_pnet_set_sparse_deltas", "frcnn_roi_pool_forward", "frcnn_roi_pool_backward", "frcnn_cnet_losses",
-                 "frcnn_cnet_forward", "frcnn_cnet_backward", "frcnn_pnet_backward", "frcnn_rpn_scan", "frcnn_nms_device",
+                 "frcnn_cnet_forward", "frcnn_cnet_backward", "frcnn_pnet_backward", "frcnn_rpn_scan", "frcnn_nms_device_n",
+                 "frcnn_roi_windows", "frcnn_detect_post", "frcnn_detect_gather",
                  "frcnn_cnet_decode", "frcnn_allreduce_f32", "frcnn_allreduce_f64", "frcnn_comm_init_rank_file",
                  "frcnn_broadcast_f32", "frcnn_rmsprop", "frcnn_add"):
         assert name in used_all, name
