@@ -74,6 +74,16 @@ class _U8Frame(object):
         self.dev, self.event, self.slot, self.recycle = dev, event, slot, recycle
         self.shape = (3, H, W)
 
+    def __del__(self):
+        # a frame that never reached processImage (an exception, a caller that dropped it) still hands its device buffer
+        # back to the pool instead of leaving it to the allocator
+        r, self.recycle = getattr(self, "recycle", None), None
+        if r is not None:   # (processImage clears `recycle` when it has handed the buffer back itself)
+            try:
+                r()
+            except Exception:
+                pass
+
 
 class _DecodeAhead(object):
     """Worker threads decode upcoming files (Pillow releases the GIL while it decodes) and upload the 8-bit frames
@@ -112,6 +122,21 @@ class _DecodeAhead(object):
     def request(self, fn, base=""):
         if (fn, base) not in self.jobs:
             self.jobs[(fn, base)] = self.pool.submit(self._work, fn, base)
+
+    def forget(self, fn=None, base=""):
+        """Drop prefetched decodes nobody will ask for: one file that was loaded another way (materialize / a custom path),
+        or -- fn None -- everything, when the epoch's order is redrawn.  Their pinned buffers go back to the pool."""
+        keys = [k for k in self.jobs if fn is None or k == (fn, base)]
+        for k in keys:
+            fut = self.jobs.pop(k)
+            if not fut.cancel():
+                def give(f, self=self):
+                    try:
+                        pin, pb, _ = f.result()
+                        self.pin_pool.give(pin, pb)
+                    except Exception:
+                        pass
+                fut.add_done_callback(give)
 
     def get(self, fn, base=""):
         """consumer thread: wait for the decode, queue the upload on the copy stream, hand out the frame + its event"""
@@ -348,6 +373,8 @@ class BatchIterator(object):
 
     # ---- BatchIterator.lua:7-25
     def _randomize_order(self, *sets):
+        if getattr(self, "ahead", None) is not None:
+            self.ahead.forget()    # decodes requested for the old order are not waited for any more
         for x in sets:
             if x["list"]:
                 x["order"] = self.rng.randperm(len(x["list"]))
@@ -379,6 +406,8 @@ class BatchIterator(object):
             if cs not in ("yuv", "rgb"):
                 raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
             return self.ahead.get(fn, base)
+        if self.ahead is not None:
+            self.ahead.forget(fn, base)   # loaded here instead: its prefetched decode (if any) is not kept around
         img = to_device(self.load_image_fn(fn) if self._custom_loader else self.load_image_fn(fn, base))
         if len(img.shape) != 3 or img.shape[0] != 3:
             return img   # the caller reports the unexpected channel count (:185-188)

@@ -203,7 +203,7 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
   float* wf = nullptr;
   if (conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
     FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
-    int rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream));
+    int rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream), H + 2 * pad - k + 1, W + 2 * pad - k + 1);
     if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wf);
@@ -221,7 +221,7 @@ int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const 
   float* wd = nullptr;
   if (conv_x3_eligible(O, C, k)) {
     FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C, k)));
-    int rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream));
+    int rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream), Ho + 2 * (k - 1 - pad) - k + 1, Wo + 2 * (k - 1 - pad) - k + 1);
     if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wd);

@@ -62,11 +62,22 @@ bool conv_x3_eligible(int Cin, int M, int k) {
   return get_split_bf16() && (k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && Cin >= CX_CH && M % (k == 3 ? 64 : 128) == 0;
 }
 
+static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW);
 // filters per block: 128 (2 x 2 waves of 64 x 64), or 64 (1 x 4 waves of 64 filters x 32 pixels) when 128 does not divide M
-int conv_x3_bm(int M) {
+// -- or when 128-filter blocks would need a K split to fill the chip while 64-filter blocks fill it whole (the 113 x 200
+// layers of vgg_small: 354 -> 708 blocks): the smaller block multiplies 6 % slower, but the partial-sum slabs and the fold
+// launch behind them (42 us each, on the dependent chain) go away -- 96 vs 114 us and 171 vs 182 us for the two layers.
+// The weight pack depends on the choice, so the launch and the pack job both ask this function with the same shape.
+int conv_x3_bm(int M, int Ho, int Wo, int k) {
   static const int force = getenv("FRCNN_X3_BM") ? atoi(getenv("FRCNN_X3_BM")) : 0;
   if (force == 64) return 64;
-  return M % 128 == 0 ? 128 : 64;
+  if (M % 128 != 0) return 64;
+  if (force == 128 || k != 3 || Ho <= 0) return 128;
+  int TH, TW;
+  x3_choose_tile(Ho, Wo, k, &TH, &TW);
+  const long tiles = (long)cdiv(Ho, TH) * cdiv(Wo, TW);
+  const long b128 = tiles * (M / 128), b64 = tiles * (M / 64);
+  return (b128 < 512 && b64 >= 512 && b64 <= 256 * CX_OCC) ? 64 : 128;
 }
 size_t conv_x3_pack_bytes(int Kchan, int M, int k) { return (size_t)M * (Kchan / CX_CH) * k * k * 96; }   // 6 x 16 bytes per filter, chunk and tap
 
@@ -164,10 +175,11 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
   pack_x3_job(weights, j, blockIdx.x, gridDim.x, tile);
 }
 
-PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst) {
+// Ho x Wo: the OUTPUT map of the launch the pack feeds (the input map of the layer for mode 1, the input-gradient pass)
+PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, int Ho, int Wo) {
   PackXJob j;
   j.w_off = w_off; j.O = O; j.C = C; j.k = k; j.mode = mode; j.dst = dst;
-  j.bm = conv_x3_bm(mode == 0 ? O : C);
+  j.bm = conv_x3_bm(mode == 0 ? O : C, Ho, Wo, k);
   j.total = (long)O * C * k * k;
   j.blk_begin = 0; j.nblk = 1;
   return j;
@@ -192,8 +204,8 @@ int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs
 }
 
 // one pack by itself (op-level entry points and tests)
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s) {
-  PackXJob j = conv_x3_pack_job(0, O, C, k, mode, dst);
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo) {
+  PackXJob j = conv_x3_pack_job(0, O, C, k, mode, dst, Ho, Wo);
   int grid = conv_x3_pack_assign_blocks(&j, 1);
   FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_kernel, dim3(grid), dim3(256), 0, w, j);
   FR_LAUNCH_CHECK();
@@ -541,7 +553,7 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
   x3_choose_tile(a.Ho, a.Wo, k, &a.TH, &a.TW);
   a.tilesX = cdiv(a.Wo, a.TW); a.tilesY = cdiv(a.Ho, a.TH);
-  const int bm = conv_x3_bm(M);
+  const int bm = conv_x3_bm(M, a.Ho, a.Wo, k);
   a.mTiles = M / bm;
   a.nChunks = Cin / CX_CH;
   const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;

@@ -42,10 +42,10 @@ int get_split_bf16();
 bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)
 size_t conv_x3_pack_bytes(int Kchan, int M, int k);
 struct PackXJob { long w_off; long total; void* dst; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
-PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst);
+PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, int Ho, int Wo);   // Ho x Wo: output map of the launch it feeds
 int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s);
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo);
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0);
 

@@ -315,8 +315,8 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
   {  // split-bf16 pack jobs
     std::vector<PackXJob> all, fwd;
     auto add = [&](Conv& c) {
-      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p)); fwd.push_back(all.back()); }
-      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p));
+      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p, c.Ho, c.Wo)); fwd.push_back(all.back()); }
+      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p, c.H, c.W));
     };
     for (auto& c : m->convs) add(c);
     for (auto& hd : m->heads) add(hd.c3);
@@ -783,6 +783,12 @@ static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
   FR_HIP(hipEventRecord(m->chain_ev, m->side));
   std::vector<char> own(m->heads.size(), 0);   // (the hint is consumed by backward_head: decide before calling it)
   for (size_t i = 0; i < m->heads.size(); ++i) own[i] = m->heads[i].stream && head_is_sparse(m->heads[i]);
+  // A dense-fallback net adds into the pooled-map gradient with plain read-modify-writes and uses the shared weight-gradient
+  // workspace, while the sparse nets add into the same map with atomics from their own streams: nothing orders the two
+  // groups, so as soon as ONE net is dense every net runs on the side stream, one after the other.
+  bool any_dense = false;
+  for (size_t i = 0; i < m->heads.size(); ++i) any_dense = any_dense || !head_is_sparse(m->heads[i]);
+  if (any_dense) std::fill(own.begin(), own.end(), 0);
   for (size_t i = 0; i < m->heads.size(); ++i) {
     Head& h = m->heads[i];
     if (!own[i]) continue;

@@ -254,7 +254,9 @@ static void wgradx_plan(WgradXArgs& a) {
   a.tilesX = cdiv(a.Wo, WX_TW); a.tilesY = cdiv(a.Ho, WX_TH);
   a.oTiles = a.O / 64; a.cTiles = a.Cin / 64;
   const long base = (long)a.oTiles * a.cTiles, npix = (long)a.tilesX * a.tilesY;
-  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (512 + base / 2) / base));   // two blocks per CU: ~512 blocks
+  static const int per_cu = getenv("FRCNN_WGX_PER_CU") ? atoi(getenv("FRCNN_WGX_PER_CU")) : 2;
+  const long target = per_cu == 1 ? 256 : 512;
+  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (target + base / 2) / base));   // two blocks per CU: ~512 blocks
   if (const char* e = getenv("FRCNN_WGX_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }
 
@@ -276,7 +278,9 @@ static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) 
   const int grid = a.oTiles * a.cTiles * a.nSplit;
   const double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
   if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
-  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), WX_LDS, s, a);
+  static const int per_cu = getenv("FRCNN_WGX_PER_CU") ? atoi(getenv("FRCNN_WGX_PER_CU")) : 2;
+  const size_t lds = per_cu == 1 ? std::max<size_t>(WX_LDS, 84 * 1024) : (size_t)WX_LDS;   // > 80 KB: one block per CU
+  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), lds, s, a);
   FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
   if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
   FR_LAUNCH_CHECK();

@@ -38,7 +38,7 @@ def run(kind, name, reps=5):
         else:
             F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O, Ho, Wo, F.ptr(w), Cin, k, pad, F.ptr(gin), 0, s)
     once()
-    conv = [i for i, n in enumerate(F._lib.KC_NAMES) if n.startswith("conv_")]
+    conv = [i for i, n in enumerate(F._lib.KC_NAMES) if n.startswith("conv_") or (n == "elemwise" and os.environ.get("WITH_FOLD"))]
     F._lib.call("frcnn_prof_enable", sum(1 << i for i in conv))
     for _ in range(reps):
         once()

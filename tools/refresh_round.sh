@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): every measurement that profiles/ holds for one round, from the current tree, into
-# gpurun_out/<tag>/ (copy what should be judged into profiles/).  usage: bash tools/refresh_round.sh r02
-TAG=${1:-r02}
+# gpurun_out/<tag>/ (copy what should be judged into profiles/).  usage: bash tools/refresh_round.sh r03
+TAG=${1:-r03}
 R=/root/repo; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-upload-leg"
 # 1. PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1
@@ -27,7 +27,7 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 PY
 # 2. kernel stats of the bench command (rocprofv3 --kernel-trace --stats) and the step timeline of the same trace
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-upload-leg > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
 cd $R
 cp $O/stats/*/*kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
 python tools/timeline.py $O/stats 12 > $O/${TAG}_step_timeline.txt 2>&1
@@ -42,20 +42,26 @@ python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
   python tools/bench_conv.py fwd 2>/dev/null; python tools/bench_conv.py dgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null; python tools/bench_conv.py wgrad 2>/dev/null
   echo "# the same with the fp32 matrix-core kernels only -- FRCNN_SPLIT_BF16=0 python tools/bench_conv.py fwd|dgrad|wgrad"
   FRCNN_SPLIT_BF16=0 python tools/bench_conv.py fwd 2>/dev/null; FRCNN_SPLIT_BF16=0 python tools/bench_conv.py dgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null; FRCNN_SPLIT_BF16=0 python tools/bench_conv.py wgrad 2>/dev/null
-  echo "# ... and with the Winograd F(2x2,3x3) form of the eligible 3x3 layers (fp32) -- FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd|dgrad"
-  FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py fwd b2c1 b2c2 b3c1 b3c2 2>/dev/null; FRCNN_SPLIT_BF16=0 FRCNN_WINO=1 python tools/bench_conv.py dgrad b2c1 b2c2 b3c2 2>/dev/null
   echo "# sustained v_mfma_f32_32x32x16_bf16 rate (no memory traffic) -- tools/bin/mfma_peak_bf16"
   [ -x tools/bin/mfma_peak_bf16 ] || { mkdir -p tools/bin; hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_bf16.hip -o tools/bin/mfma_peak_bf16 >/dev/null 2>&1; }
   tools/bin/mfma_peak_bf16 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
-  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_SPLIT_BF16=0 FRCNN_WINO=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
+  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_GEMM_X=0" "FRCNN_WGX_PER_CU=1" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
     echo -n "$e: "; env $e python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
   done
   echo "# config 5 shapes on one GPU -- python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline"
   for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0"; do
     echo -n "$e: "; env $e python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'images/s', d['ms_per_step'], 'ms/step; conv_igemm 3x3', r['achieved'], 'TFLOP/s live,', r['isolated']['achieved'], 'alone')"
   done
+  echo "# the cnet's Linear(13824,1024) in its three roles, split-bf16 form and (FRCNN_GEMM_X=0) fp32 matrix-core kernels -- python tools/bench_gemm.py"
+  python tools/bench_gemm.py 2>/dev/null | grep "I=13824"; FRCNN_GEMM_X=0 python tools/bench_gemm.py 2>/dev/null | grep "I=13824"
   echo "# config 2 -- python tools/bench_detect.py 30   (Detector:detect on 3x450x800 frames; CLASSES=200: config/imagenet.lua class count)"
   python tools/bench_detect.py 30 2>/dev/null; CLASSES=200 CLS_GAIN=2000 python tools/bench_detect.py 30 2>/dev/null
 } > $O/${TAG}_other_configs.txt 2>&1
+# 5. Detector:detect under rocprofv3: kernel stats of the inference leg (BASELINE config 2)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/detect -- python $R/tools/bench_detect.py 30 > $O/detect.log 2>&1
+cd $R
+cp $O/detect/*/*kernel_stats.csv $O/${TAG}_detect_kernel_stats.csv 2>/dev/null
+rm -rf $O/fetch $O/write $O/mfma $O/stats $O/detect
 ls -la $O | head -40
