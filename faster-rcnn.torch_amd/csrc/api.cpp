@@ -313,7 +313,7 @@ int frcnn_loss_accumulate(const double* ex_loss, int E, double* acc, void* strea
 int frcnn_linear_forward(const float* x, int R, int I, const float* weight, const float* bias, int O, float* y,
                          void* stream) {
   // Y[R][O] = X[R][I] * W[O][I]^T + b
-  if (linear_x_eligible(R, I, O)) {   // split-bf16 operand form (gemmx.hip); the model runtime keeps the planes resident
+  if (linear_x_eligible(1, R, I, O)) {   // split-bf16 operand form (gemmx.hip); the model runtime keeps the planes resident
     void* xp = nullptr;
     FR_HIP(hipMalloc(&xp, (size_t)3 * R * I * 2));
     int rc = split_planes(x, R, I, xp, nullptr, S(stream));
@@ -326,19 +326,22 @@ int frcnn_linear_forward(const float* x, int R, int I, const float* weight, cons
 }
 int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const float* weight, int O, float* gx,
                           float* gweight, float* gbias, void* stream) {
-  if (linear_x_eligible(R, I, O)) {
+  const bool xd = gx && linear_x_eligible(2, R, I, O), xw = gweight && linear_x_eligible(4, R, I, O);
+  if (xd || xw) {
     const size_t Rp = (size_t)linear_x_rows_padded(R);
     void *gp = nullptr, *gpT = nullptr, *xpT = nullptr;
     int rc = FRCNN_OK;
-    if (gx) FR_HIP(hipMalloc(&gp, (size_t)3 * R * O * 2));
-    if (gweight) { FR_HIP(hipMalloc(&gpT, (size_t)3 * O * Rp * 2)); FR_HIP(hipMalloc(&xpT, (size_t)3 * I * Rp * 2)); }
+    if (xd) FR_HIP(hipMalloc(&gp, (size_t)3 * R * O * 2));
+    if (xw) { FR_HIP(hipMalloc(&gpT, (size_t)3 * O * Rp * 2)); FR_HIP(hipMalloc(&xpT, (size_t)3 * I * Rp * 2)); }
     rc = split_planes(gy, R, O, gp, gpT, S(stream));
-    if (rc == FRCNN_OK && gweight) rc = split_planes(x, R, I, nullptr, xpT, S(stream));
-    if (rc == FRCNN_OK && gx) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream));
-    if (rc == FRCNN_OK && gweight) rc = linear_x_wgrad(gpT, xpT, R, O, I, gweight, S(stream));
+    if (rc == FRCNN_OK && xw) rc = split_planes(x, R, I, nullptr, xpT, S(stream));
+    if (rc == FRCNN_OK && xd) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream));
+    if (rc == FRCNN_OK && xw) rc = linear_x_wgrad(gpT, xpT, R, O, I, gweight, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(gp); (void)hipFree(gpT); (void)hipFree(xpT);
     FR_TRY(rc);
+    if (gx && !xd) FR_TRY(gemm_f32(gy, O, 1, weight, I, 1, gx, I, R, I, O, OUT_STORE, nullptr, S(stream)));
+    if (gweight && !xw) FR_TRY(gemm_f32(gy, 1, O, x, I, 1, gweight, I, O, I, R, OUT_ADD, nullptr, S(stream)));
     if (gbias) FR_TRY(channel_sum_cols(gy, R, O, gbias, S(stream)));
     return FRCNN_OK;
   }

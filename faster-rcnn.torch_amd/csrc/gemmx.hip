@@ -291,9 +291,23 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
   }
 }
 
-bool linear_x_eligible(int R, int I, int O) {
-  static const bool on = !(getenv("FRCNN_GEMM_X") && atoi(getenv("FRCNN_GEMM_X")) == 0);
-  return on && get_split_bf16() && I % 16 == 0 && O % 16 == 0 && R >= 32 && (double)R * I * O >= 1.0e9;
+// role: 1 forward, 2 input gradient, 4 weight gradient.  Measured on Linear(13824, 1024) against the fp32 matrix-core
+// kernel of gemm.hip (profiles/r03_other_configs.txt): the input gradient wins at every row count (R = 320: 101 vs 119 us,
+// 560: 113 vs 182 us -- its big operand arrives in whole 1 KB rows); forward and weight gradient only break even from
+// R ~ 560 on (181 vs 178, 180 vs 192 us) and lose below (their LDS-DMA gathers 64-byte pieces / the output is read-modify-
+// written; inference with R = 1398 candidates: Detector:detect 2.23 vs 2.22 ms), so by default they keep the fp32 kernel.
+// FRCNN_GEMM_X / option "gemm_x_roles" = bit mask of the roles that take the split form (0 none, 7 all).
+static int g_gemm_x_roles = -2;   // -2: not decided yet (environment FRCNN_GEMM_X, default -1 = the rule below)
+void set_gemm_x_roles(int mask) { g_gemm_x_roles = mask; }
+int get_gemm_x_roles() {
+  if (g_gemm_x_roles == -2) g_gemm_x_roles = getenv("FRCNN_GEMM_X") ? atoi(getenv("FRCNN_GEMM_X")) : -1;
+  return g_gemm_x_roles;
+}
+bool linear_x_eligible(int role, int R, int I, int O) {
+  const int mask = get_gemm_x_roles();
+  if (!get_split_bf16() || I % 16 != 0 || O % 16 != 0 || R < 32 || (double)R * I * O < 1.0e9) return false;
+  if (mask >= 0) return (mask & role) != 0;
+  return role == 2;
 }
 
 template <int TM, int BMODE>

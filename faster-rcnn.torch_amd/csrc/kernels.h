@@ -116,7 +116,9 @@ int gemm_reduce_slabs(const float* slab, int nSplit, int M, int N, const float* 
                       hipStream_t s);
 // ---- split-bf16 operand form of the large Linear (gemmx.hip): activation operands as three bf16 planes written once
 // (split_planes), weights split in registers; fp32 results of fp32 accuracy (see convx.hip)
-bool linear_x_eligible(int R, int I, int O);
+void set_gemm_x_roles(int mask);   // option "gemm_x_roles": -1 the built-in rule, else bit mask of roles in the split form
+int get_gemm_x_roles();
+bool linear_x_eligible(int role, int R, int I, int O);   // role: 1 forward, 2 input gradient, 4 weight gradient
 int linear_x_rows_padded(int R);                       // rows of the transposed planes (R rounded up to 16, zero filled)
 int split_planes(const float* src, int R, int C, void* P /* [3][C/8][R][8] bf16 or null */, void* PT /* [3][Rp/8][C][8] or null */,
                  hipStream_t s);

@@ -80,7 +80,8 @@ struct ClsLayer {
   long w_off, b_off, bnw_off, bnb_off, a_off;
   DevBuf lin, pre, post, xhat, invstd, mask, g;
   DevBuf xp, xpT, gp, gpT;    // split-bf16 planes of the layer's input and of its output gradient (gemmx.hip), when it takes that form
-  bool x_form = false;        // set per call: this layer's products run in the split-bf16 operand form
+  int x_form = 0;             // set per call: which of this layer's products run in the split-bf16 operand form
+                              // (bit 1 forward, 2 input gradient, 4 weight gradient: linear_x_eligible)
 };
 
 }  // namespace frcnn
@@ -432,7 +433,9 @@ static bool side_enabled() {
 int frcnn_get_option(const char* name, int* value) {
   FR_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
+  if (strcmp(name, "gemm_x_roles") == 0) { *value = get_gemm_x_roles(); return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
+  if (strcmp(name, "gemm_x_roles") == 0) { *value = get_gemm_x_roles(); return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
@@ -442,6 +445,7 @@ int frcnn_set_option(const char* name, int value) {
   FR_CHECK(name != nullptr, "set_option: null name");
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
+  if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   FR_CHECK(false, "set_option: unknown option '%s'", name);
   return FRCNN_OK;
@@ -962,12 +966,12 @@ static int ensure_cnet(frcnn_model* m, int R) {
     FR_TRY(L.post.ensure(n));
     FR_TRY(L.g.ensure(n));
     if (L.p_drop > 0.f) FR_TRY(L.mask.ensure(n));
-    L.x_form = linear_x_eligible(R, L.in, L.n);
-    if (L.x_form) {
-      const size_t Rp = (size_t)linear_x_rows_padded(R);
-      FR_TRY(L.xp.ensure((size_t)3 * R * L.in * 2)); FR_TRY(L.xpT.ensure((size_t)3 * L.in * Rp * 2));
-      FR_TRY(L.gp.ensure((size_t)3 * R * L.n * 2)); FR_TRY(L.gpT.ensure((size_t)3 * L.n * Rp * 2));
-    }
+    L.x_form = 0;
+    for (int role : {1, 2, 4}) if (linear_x_eligible(role, R, L.in, L.n)) L.x_form |= role;
+    const size_t Rp = (size_t)linear_x_rows_padded(R);
+    if (L.x_form & 1) FR_TRY(L.xp.ensure((size_t)3 * R * L.in * 2));
+    if (L.x_form & 2) FR_TRY(L.gp.ensure((size_t)3 * R * L.n * 2));
+    if (L.x_form & 4) { FR_TRY(L.xpT.ensure((size_t)3 * L.in * Rp * 2)); FR_TRY(L.gpT.ensure((size_t)3 * L.n * Rp * 2)); }
   }
   int nc = m->d.class_count + 1;
   int nf = m->cls.empty() ? m->D : m->cls.back().n;
@@ -990,8 +994,8 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
   float* bnr = bn_running;
   for (size_t l = 0; l < m->cls.size(); ++l) {
     ClsLayer& L = m->cls[l];
-    if (L.x_form) {   // split-bf16 operand form: the input's planes once (transposed too when a backward pass follows)
-      FR_TRY(split_planes(cur, R, L.in, L.xp.p, training ? L.xpT.p : nullptr, s));
+    if (L.x_form & 1) {   // split-bf16 operand form: the input's planes once
+      FR_TRY(split_planes(cur, R, L.in, L.xp.p, nullptr, s));
       FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s));
     } else {
       FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s));
@@ -1061,12 +1065,18 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
                          grad + L.bnw_off, grad + L.bnb_off, s));
     const float* in = l == 0 ? m->cnet_x : m->cls[l - 1].post.f();
     float* gin = l == 0 ? gx : m->cls[l - 1].post.f();  // post[l-1] is dead after this point: reuse as gradient
-    if (L.x_form) {
-      if (!m->training) FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, s));   // (an evaluate-mode forward does not write them)
-      FR_TRY(split_planes(L.g.f(), R, L.n, gin ? L.gp.p : nullptr, L.gpT.p, s));
-      FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, s));
+    if (L.x_form & 6) {   // the gradient's planes once, in the orientations the split-form products of this layer read
+      const bool xw = (L.x_form & 4) != 0, xd = (L.x_form & 2) != 0 && gin;
+      if (xw || xd) FR_TRY(split_planes(L.g.f(), R, L.n, xd ? L.gp.p : nullptr, xw ? L.gpT.p : nullptr, s));
+      if (xw) {
+        FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, s));
+        FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, s));
+      } else {
+        FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
+      }
       FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
-      if (gin) FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
+      if (xd) FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
+      else if (gin) FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
     } else if (l > 0) {
       // gradient wrt post[l-1] must not overwrite `in` before the weight gradient used it
       FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));

@@ -53,7 +53,10 @@ int frcnn_device_name(char *buf_host, int len);
  * form: fp32 tensors in and out, fp32 accumulation, every fp32 product formed from six exact bf16 x bf16 partial products of
  * three-way split operands on the bf16 matrix cores (24 significand bits per operand; against an fp64 reference the error
  * equals that of the fp32 matrix-core kernels, tests/test_gpu_convx.py).  0 = fp32 matrix-core kernels only.  Applies to the
- * operator-level entry points at once and to a model from its next (re)shaping on. */
+ * operator-level entry points at once and to a model from its next (re)shaping on.
+ * "gemm_x_roles" (default -1; environment FRCNN_GEMM_X): which products of a large nn.Linear (the cnet's Linear(13824, 1024))
+ * take the split-bf16 operand form of csrc/gemmx.hip -- bit 1 forward, 2 input gradient, 4 weight gradient; -1 = the
+ * measured rule (the input gradient only: the other two break even at best), 0 = fp32 matrix-core kernels for all three. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 

@@ -130,14 +130,14 @@ def test_linear_fc1_split_bf16_form(F, O, R):
     dx, dw, db, dgy = _dev(F, x), _dev(F, w), _dev(F, b), _dev(F, gy)
     res = {}
     for split in (1, 0):
-        F._lib.call("frcnn_set_option", b"split_bf16", split)
+        F._lib.call("frcnn_set_option", b"gemm_x_roles", 7 if split else 0)    # all three roles in the split form / none
         try:
             y = F.DeviceTensor.empty((R, Oo)); gx = F.DeviceTensor.empty((R, I)); gw = F.DeviceTensor.zeros((Oo, I)); gb = F.DeviceTensor.zeros((Oo,))
             F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(db), Oo, F.ptr(y), F.stream_ptr())
             F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(dgy), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb), F.stream_ptr())
             res[split] = dict(fwd=y.numpy(), dgrad=gx.numpy(), wgrad=gw.numpy())
         finally:
-            F._lib.call("frcnn_set_option", b"split_bf16", 1)
+            F._lib.call("frcnn_set_option", b"gemm_x_roles", -1)
     for k in ("fwd", "dgrad", "wgrad"):
         assert_close(res[1][k], want[k], 1e-4, "FC1 %s (split form)" % k)
         assert_close(res[0][k], want[k], 1e-4, "FC1 %s (fp32 kernel)" % k)
