@@ -95,7 +95,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
   const int wo = wave >> 1, wc = wave & 1;
   const int h = lane >> 5, li = lane & 31;
 
-  int bid = blockIdx.x;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (own L2 each); the virtual index gives every XCD a
+  // contiguous range, in which the (o tile, c tile) blocks of one pixel split follow each other -- they walk the same
+  // pixel tiles at the same time and now share them through ONE L2 instead of fetching them once per XCD
+  int bid;
+  {
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = xcd * q + min(xcd, r) + idx;
+  }
   const int ot = bid % p.oTiles; bid /= p.oTiles;
   const int ct = bid % p.cTiles;
   const int split = bid / p.cTiles;
