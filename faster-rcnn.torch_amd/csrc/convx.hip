@@ -18,8 +18,7 @@
 // GEMM view: D[m = filter][n = pixel] = sum_{tap, c} W[m][c][tap] * X[c][pixel + tap];  block = 128 filters x (TH x TW <=
 // 128) pixels, 2 x 2 waves of 64 x 64 (four 32x32 accumulators), K step = 16 channels of one tap (lane half h takes
 // channels 8h..8h+7), stage = one tap of a 16-channel chunk: A ring of two 12 KB stages (LDS-DMA one stage ahead), one patch
-// buffer per block.  44 KB of LDS, <= 168 registers -> three blocks per CU (CX_OCC; -DCX_OCC=2 builds the first layout: ring
-// of three, double-buffered patch, 79 KB).
+// buffer per block.  44 KB of LDS, <= 168 registers -> three blocks per CU.
 #include <cstdlib>
 
 #include "kernels.h"
@@ -34,18 +33,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define CX_BM 128                       // filters per block
 #define CX_CH 16                        // channels per chunk (one MFMA K step per tap)
-#ifndef CX_OCC
-#define CX_OCC 3                        // blocks per CU the kernel is laid out for (2: A ring of 3 + double-buffered patch)
-#endif
-#if CX_OCC == 3
+#define CX_OCC 3                        // blocks per CU the kernel is laid out for
 #define CX_PP 204                       // patch positions per (plane, half) in LDS (pitch); patch plane <= CX_PP
 #define CX_NA 2                         // A ring slots
 #define CX_NB 1                         // patch buffers
-#else
-#define CX_PP 228
-#define CX_NA 3
-#define CX_NB 2
-#endif
 #define CX_NTMAX 128                    // pixels per block
 #define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage of a 128-filter block: [plane 3][half 2][128 filters][8 bf16]
 #define CX_BBUF (6 * CX_PP * 16)        // bytes of one B buffer: [plane 3][half 2][CX_PP positions][8 bf16]
@@ -233,7 +224,6 @@ template <int KS, int WM, bool SLOPE, bool SCALE>
 __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   constexpr int KK = KS * KS;
   constexpr int BMK = 64 * WM, NTW = WM, AST = 6 * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
-  static_assert(CX_OCC == 3 || WM == 2, "the two-blocks-per-CU layout exists for 128-filter blocks only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,7 +375,6 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
   };
 
-#if CX_OCC == 3
   // Three blocks per CU (44 KB of LDS, <= 168 registers): A ring of two stages -- stage s+1 is requested right after the
   // barrier of stage s, into the slot stage s-1 was read from -- and ONE patch buffer: at a chunk boundary every wave
   // has passed the barrier of the new chunk's first stage before the new patch (in registers since the old chunk's first
@@ -417,39 +406,6 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
       compute(As + ((tap + par) & 1) * AST, Bs, (ky * PW + kx) * 16);
     }
   }
-#else
-  // ---- prologue: patch of the first chunk, A stages 0 and 1
-  load_patch(cbeg);
-  dma_stage(0, 0);
-  dma_stage(1, 1);
-  store_patch(Bs);
-  bool more = false;
-
-  int stage = 0;
-  for (int chunk = cbeg; chunk < cend; ++chunk) {
-    const char* Bcur = Bs + ((chunk - cbeg) & 1) * CX_BBUF;
-    char* Bnext = Bs + (((chunk - cbeg) & 1) ^ 1) * CX_BBUF;
-    const int rot = KK % 3 == 0 ? 0 : ((chunk - cbeg) * KK) % 3;   // A ring slot of the chunk's first tap
-#pragma unroll
-    for (int tap = 0; tap < KK; ++tap, ++stage) {
-      // stage's A image has landed in every wave's part (DMA retires in order: at most the next stage's three
-      // instructions -- and, right after a chunk's first tap, the patch loads issued behind them -- may be in flight)
-      if (stage + 1 >= nStages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      __syncthreads();
-      if (stage + 2 < nStages) dma_stage(stage + 2, (tap + 2 + rot) % 3);
-      if (tap == 0) {   // the next chunk's patch: requested now, split and written to the other buffer at tap 4
-        more = chunk + 1 < cend;
-        if (more) load_patch(chunk + 1);
-      }
-      const int ky = tap / KS, kx = tap - ky * KS;
-      compute(As + ((tap + rot) % 3) * AST, Bcur, (ky * PW + kx) * 16);
-      if (tap == 4 && more) store_patch(Bnext);
-    }
-  }
-
-#endif
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
   const long HoWo = (long)p.Ho * p.Wo;
@@ -577,12 +533,8 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     rc = act == 3 ? launch_x3<3, 2, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 2, true, false>(a, algo_flops, s)
        : act == 1 ? launch_x3<3, 2, false, true>(a, algo_flops, s) : launch_x3<3, 2, false, false>(a, algo_flops, s);
   } else if (k == 3) {
-#if CX_OCC == 3
     rc = act == 3 ? launch_x3<3, 1, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 1, true, false>(a, algo_flops, s)
        : act == 1 ? launch_x3<3, 1, false, true>(a, algo_flops, s) : launch_x3<3, 1, false, false>(a, algo_flops, s);
-#else
-    FR_CHECK(false, "conv_x3: 64-filter blocks need the three-blocks-per-CU layout");
-#endif
   } else {   // anchor nets: their input is a pooled map (activation already applied by the pooling kernel)
     FR_CHECK(act == 0 && bm == 128, "conv_x3: a %dx%d launch takes no fused input activation and 128-filter blocks", k, k);
     rc = k == 5 ? launch_x3<5, 2, false, false>(a, algo_flops, s) : launch_x3<7, 2, false, false>(a, algo_flops, s);

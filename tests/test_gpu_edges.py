@@ -153,3 +153,42 @@ def test_wait_block_gradients_contract(F, setup):
     with pytest.raises(F.FrcnnError):
         F._lib.call("frcnn_pnet_wait_block_gradients", model["native"].h, 9, F.stream_ptr())
     assert pnet.block_param_range(0)[0] == 0 and pnet.block_param_range(3)[1] == pnet.heads_param_range()[0]
+
+
+def test_uploading_iterator_equals_resident_frames(F, setup):
+    """SyntheticBatchIterator(upload=True) -- frames in page-locked host memory, uploaded every step on a copy stream into a
+    ring of device buffers, the consumer's stream waiting for the copy's event (objective.lua:66 `x.img:cuda()`) -- feeds the
+    training step the same bytes as the resident frames: identical gradients and weights over several steps."""
+    import torch
+    s = setup
+    model = s["model"]
+    res = {}
+    for mode in ("resident", "upload"):
+        s["weights"].copy_(torch.from_numpy(s["w"]))
+        it = F.SyntheticBatchIterator(model, H=128, W=176, images_per_batch=1, pool=3, upload=(mode == "upload"))
+        rng = np.random.RandomState(1)
+        model["pnet"].drop_masks = _masks(rng, model)
+        stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
+        cnet = model["cnet"]
+        orig = cnet.forward
+
+        def fwd(x, orig=orig):   # deterministic cnet dropout masks sized for whatever batch arrives
+            R = x.shape[0]
+            r2 = np.random.RandomState(R)
+            cnet.drop_masks = [(r2.rand(R, 1024) > 0.5).astype(np.float32), (r2.rand(R, 512) > 0.5).astype(np.float32)]
+            return orig(x)
+        cnet.forward = fwd
+        try:
+            f = F.create_objective(model, s["weights"], s["gradient"], it, stats)
+            state = dict(learningRate=1e-4, alpha=0.9)
+            for _ in range(5):
+                F.rmsprop(f, s["weights"], state)
+            torch.cuda.synchronize()
+        finally:
+            cnet.forward = orig
+            cnet.drop_masks = None
+            model["pnet"].drop_masks = None
+        res[mode] = (s["weights"].cpu().numpy().copy(), s["gradient"].cpu().numpy().copy(), list(stats["pcls"]))
+    s["weights"].copy_(torch.from_numpy(s["w"]))
+    assert res["resident"][2] == res["upload"][2]
+    assert np.array_equal(res["resident"][1], res["upload"][1]) and np.array_equal(res["resident"][0], res["upload"][0])

@@ -161,6 +161,28 @@ def test_rmsprop_and_scale(F, O):
     assert_close(tg.cpu().numpy(), g * np.float32(1.0 / 37.0), 1e-6, "scale")
 
 
+def test_scale_rmsprop_with_the_divisor_on_the_device(F):
+    """frcnn_scale_rmsprop_dev (the data-parallel tail: gradient:div(n) with n = the all-reduced count in device memory) ==
+    frcnn_scale_rmsprop with 1 / n computed on the host, bit for bit; a count of 0 leaves the gradient unscaled."""
+    import torch
+    rng = np.random.RandomState(11)
+    n = 100003
+    x = rng.randn(n).astype(np.float32); g = rng.randn(n).astype(np.float32); m = rng.rand(n).astype(np.float32)
+    for count in (560.0, 3.0, 0.0):
+        a = [torch.from_numpy(v.copy()).cuda() for v in (x, g, m)]
+        b = [torch.from_numpy(v.copy()).cuda() for v in (x, g, m)]
+        cnt = torch.tensor([1.5, count, 7.0], dtype=torch.float64, device="cuda")
+        F._lib.call("frcnn_scale_rmsprop_dev", F.ptr(a[0]), F.ptr(a[1]), C.c_void_p(cnt.data_ptr() + 8), F.ptr(a[2]), n, 1e-4, 0.9, 1e-8,
+                    F.stream_ptr())
+        F._lib.call("frcnn_scale_rmsprop", F.ptr(b[0]), F.ptr(b[1]), (1.0 / count) if count > 0 else 1.0, F.ptr(b[2]), n, 1e-4, 0.9, 1e-8,
+                    F.stream_ptr())
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), count
+    with pytest.raises(F.FrcnnError):
+        F._lib.call("frcnn_scale_rmsprop_dev", F.ptr(a[0]), F.ptr(a[1]), None, F.ptr(a[2]), n, 1e-4, 0.9, 1e-8, F.stream_ptr())
+
+
 def test_scale_rmsprop_equals_the_two_calls(F):
     """frcnn_scale_rmsprop == frcnn_scale followed by frcnn_rmsprop, bit for bit (x, m and the scaled g)."""
     import torch
