@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfrcnn_hip.so")
+SO_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(_HERE, "libfrcnn_hip.so")   # (FRCNN_LIB_PATH: A/B builds of the library)
 
 KC_NAMES = ["conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "gemm", "elemwise",
             "roi", "rpn", "nms", "optim", "image", "conv_x3", "conv_wgradx"]
