@@ -350,7 +350,8 @@ def spawn_ranks(args):
     import torch
     n = args.gpus
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    shared = os.environ.get("FRCNN_DIST_BACKEND", "nccl") != "nccl"   # (debug: gloo lets the ranks share devices, see main)
+    if have < n and not (shared and have >= 1):
         _fail("--gpus %d needs %d HIP devices on this node, found %d (no oversubscription, no CPU fallback)" % (n, n, have))
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     env = dict(os.environ)
@@ -422,6 +423,11 @@ def main():
     torch.cuda.set_device(local_rank)
     native_comm = None
     exchange_info = None
+    # RCCL (and gloo) print banners while a communicator comes up -- on stdout, which must carry ONE JSON line: file
+    # descriptor 1 points at stderr until the communicator exists
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 and args.comm == "native":
         import frcnn_amd as F0
         F0._lib.call("frcnn_set_device", local_rank)
@@ -447,6 +453,14 @@ def main():
     import frcnn_amd as F
     L = F._lib.load()
     F._lib.call("frcnn_set_device", local_rank)
+    if world > 1:    # first collective (communicators may finish their set-up lazily), still with stdout parked
+        if native_comm is not None:
+            native_comm.barrier()
+        else:
+            dist.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     cfg = dict(F.duplo_cfg if args.model == "vgg_small" else F.imgnet_cfg)
     model = (F.vgg_small if args.model == "vgg_small" else F.vgg_large)(cfg)
     weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)  # same seed on every rank
@@ -611,7 +625,8 @@ def main():
         )
         out["config"]["exchange"] = dict(
             backend=("frcnn_comm (RCCL through the C ABI: frcnn_comm_init_rank_file / frcnn_allreduce_f32 / _f64)" if native_comm is not None
-                     else "torch.distributed nccl (RCCL)" if world > 1 else "none (single process)"),
+                     else ("torch.distributed nccl (RCCL)" if backend == "nccl" else "torch.distributed %s (debug: ranks may share a device)" % backend)
+                     if world > 1 else "none (single process)"),
             ranks=world, **(exchange_info or {}))
         ok = True
         full = args.model == "vgg_small" and (H, W) == (FULL_H, FULL_W)
