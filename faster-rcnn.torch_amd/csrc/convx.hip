@@ -407,10 +407,19 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     }
   }
 
-  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter)
+  // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter).  Every filter row of the
+  // block exists (M is a multiple of the block's filter count), so only the pixel is predicated.  The 32 bias values of the
+  // lane's rows are loaded in one batch before the stores, and the accumulate mode reads the 16 old values of a tile in one
+  // batch (pixel clamped, not branched around): with a test, a bias load and an old-value load PER ELEMENT the compiler
+  // emitted load - wait - add - store 64 times in a row -- 64 serialized memory round trips at the end of every block.
   const long HoWo = (long)p.Ho * p.Wo;
   const bool add_bias = p.bias != nullptr && split == 0;
   const int mrow0 = m0 + wm * 64 + 4 * h;
+  float bv[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[mt][r] = add_bias ? p.bias[mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
   auto store_tile = [&](auto mode_c) {
     constexpr int OM = decltype(mode_c)::value;
 #pragma unroll
@@ -418,19 +427,21 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
       const int q = wn * (32 * NTW) + nt * 32 + li;
       const int ty = q / p.TW, tx = q - ty * p.TW;
       const int oy = ty0 + ty, ox = tx0 + tx;
-      if (q < NT && oy < p.Ho && ox < p.Wo) {
-        float* col = p.out + (OM == 3 ? (size_t)split * p.M * HoWo : (size_t)0) + (size_t)oy * p.Wo + ox;
+      const bool ok = q < NT && oy < p.Ho && ox < p.Wo;
+      float* const col = p.out + (OM == 3 ? (size_t)split * p.M * HoWo : (size_t)0) + (ok ? (size_t)oy * p.Wo + ox : (size_t)0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < 2; ++mt) {
+        float* const row = col + (size_t)(mrow0 + mt * 32) * HoWo;
+        float old[16];
+        if (OM == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = row[(size_t)((r & 3) + 8 * (r >> 2)) * HoWo];
+        }
+        if (ok) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-            if (m < p.M) {
-              float val = acc[mt][nt][r];
-              if (add_bias) val += p.bias[m];
-              float* dst = col + (size_t)m * HoWo;
-              if (OM == 1) *dst += val; else *dst = val;
-            }
+            const float val = acc[mt][nt][r] + bv[mt][r];
+            row[(size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = OM == 1 ? old[r] + val : val;
           }
         }
       }

@@ -124,26 +124,43 @@ struct GxArgs {
   int tm, tn;                         // row / column tiles (the grid is one-dimensional: tm * tn * splits blocks)
 };
 
-// Block = TM (64 | 128) rows x 256 columns, EIGHT waves side by side along the columns (wave = all TM rows x 32 columns: one
-// weight fragment, split once in registers, serves TM / 32 accumulators).  Executed MFMA flops per operand byte brought to
-// LDS: 2 TM 256 6 / (6 TM + 4 256) = 219 with 128 rows -- the tile is this large because the product is otherwise bound by
-// L2 -> LDS delivery, not by the matrix pipe.  K step = 16 = one MFMA per accumulator and plane pair; a RING of three LDS
-// stages filled by LDS-DMA two steps ahead (operands stream from HBM / L2 with ~2 us of latency under load: one step ahead
-// left every step waiting for its tile), counted vmcnt, one barrier per step.  84 - 108 KB of LDS: one block per CU.
+// Block = TM (64 | 128 | 192 | 256) rows x 256 columns, EIGHT waves as 2 (rows) x 4 (columns): a wave owns TM / 2 rows x 64
+// columns = TM / 64 x 2 accumulators of 32 x 32, i.e. with 256 rows 48 MFMAs per K step behind 12 A and 6 B fragment reads
+// (0.375 KB of LDS reads per MFMA; the 128 x 32 wave tile of the first version read 0.625 KB, and with the eight waves
+// released by the same barrier its LDS phase and its MFMA phase did not overlap).  What the shape buys, per K step of 16 and
+// CU: 3072 matrix-pipe cycles per SIMD behind ONE barrier, 48 KB (planes x planes) or 40 KB (planes x fp32 weights) of
+// LDS-DMA = 13 - 16 B/clk -- the first version (128 x 256 with 1536 cycles per barrier, or 64 x 256 with 768) asked for
+// 19 - 29 B/clk, and its stripped variants showed both halves too slow on their own (Linear(13824,1024), 560 rows, forward:
+// 156 us whole, 111 us with the DMA removed, 104 us with the MFMAs removed, 65 us DMA alone).  A weight fragment (fp32 in
+// LDS) is split in registers by the two waves that need it.  K step = 16; a ring of 3 - 4 LDS stages filled by LDS-DMA
+// ring - 1 steps ahead, counted vmcnt, one barrier per step; one block per CU.
 #define GX_TN 256
-#define GX_RING 3
-template <int TM, int BMODE>
-__global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
-  constexpr int MT = TM / 32;
+#define GX_LDS_MAX (160 * 1024)
+constexpr int gx_stage_bytes(int TM, int BMODE) { return 96 * TM + (BMODE == 0 ? 96 * GX_TN : 64 * GX_TN); }
+// Tiles of up to 128 rows are laid out for TWO blocks per CU (<= 80 KB of LDS, <= 128 registers): two independent blocks
+// fill each other's barrier and fragment-latency bubbles (Linear(13824,1024) input gradient, 64-row tiles: 99 us with a
+// ring of three = 66 KB, 121 us with a ring of four = 88 KB and one block per CU); taller tiles own the CU.
+constexpr int gx_blocks_per_cu(int TM) { return TM <= 128 ? 2 : 1; }
+constexpr int gx_ring(int TM, int BMODE) {
+  const int room = GX_LDS_MAX / gx_blocks_per_cu(TM) / gx_stage_bytes(TM, BMODE);
+  return room < 2 ? 2 : room > 4 ? 4 : room;
+}
+template <int N> __device__ __forceinline__ void gx_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int WM, int BMODE>
+__global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_kernel(GxArgs p) {
+  constexpr int RW = TM / WM, MTW = RW / 32, NTW = WM;  // rows of one wave, its 32-row tiles and its 32-column tiles
   constexpr int SA = 96 * TM;                           // bytes of one A stage: [plane 3][half 2][TM rows][8 bf16]
   constexpr int SB = BMODE == 0 ? 96 * GX_TN : 64 * GX_TN;   // B stage: planes | [256 n][4 chunks of 4 k] | [16 k][256 n] fp32
   constexpr int NA = SA / 1024, NB = SB / 1024;         // wave instructions (1 KB each) per stage
   constexpr int IA = (NA + 7) / 8, IB = NB / 8;         // ... per wave (A: the last ones may repeat a slot -- same bytes twice)
   static_assert(NB % 8 == 0, "B stage must deal evenly to the eight waves");
   constexpr int SS = SA + SB;
+  constexpr int RING = gx_ring(TM, BMODE);
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WM == 2 ? wave >> 2 : 0, wn = WM == 2 ? wave & 3 : wave;
   const int h = lane >> 5, li = lane & 31;
   // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the virtual index gives
   // every XCD a CONTIGUOUS range, inside which the row tiles of one (column tile, K split) follow each other: the blocks
@@ -163,11 +180,13 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
   const int kend = min(kbeg + p.kPerSplit, p.K);   // (kend - kbeg is a multiple of 16: every stage is whole)
   const int nsteps = (kend - kbeg) >> 4;
 
-  xf32x16 acc[MT];
+  xf32x16 acc[MTW][NTW];
 #pragma unroll
-  for (int a = 0; a < MT; ++a)
+  for (int a = 0; a < MTW; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    for (int b = 0; b < NTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // ---- this lane's DMA sources at k = kbeg (one per wave instruction it issues) and what a K step adds to them
   const char* srcA[IA];
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
   stepB = BMODE == 0 ? 32 * (long)p.bLd : BMODE == 1 ? 64 : 64 * (long)p.bLd;   // bytes per K step of 16
   const long stepA = 32 * (long)p.aLd;                                             // (two k groups of all rows)
   auto issue = [&](int step) {
-    char* base = xsm + (step % GX_RING) * SS;
+    char* base = xsm + (step % RING) * SS;
 #pragma unroll
     for (int i = 0; i < IA; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (long)step * stepA),
@@ -218,73 +237,109 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
                                        (__attribute__((address_space(3))) void*)(base + SA + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
-  issue(0);
-  if (nsteps > 1) issue(1);
-  const int brow = wave * 32 + li;   // this lane's column inside the block tile
+  for (int i = 0; i < RING - 1 && i < nsteps; ++i) issue(i);
+  constexpr int PER = IA + IB;                  // DMA instructions of one stage, per wave
+  const int arow = wm * RW + li;                // this lane's row (of the wave's first row tile) and column (of its first
+  const int bcol = wn * 32 * NTW + li;          // column tile) inside the block tile
   for (int step = 0; step < nsteps; ++step) {
-    // stage `step` has landed in this wave's part (DMA retires in order: at most the next stage's instructions in flight)
-    if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // ... in every wave's part, and every wave is done with stage step - 1, whose slot is refilled now
-    if (step + 2 < nsteps) issue(step + 2);
-    const char* A_ = xsm + (step % GX_RING) * SS;
-    const char* B_ = A_ + SA;
-    xbf16x8 bp[3];
-    if (BMODE == 0) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        bp[pl] = *reinterpret_cast<const xbf16x8*>(B_ + ((pl * 2 + h) * GX_TN + brow) * 16);
-    } else {
-      float vv[8];
-      if (BMODE == 1) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const float4 q = *reinterpret_cast<const float4*>(B_ + (brow * 4 + ((2 * h + c) ^ ((brow >> 2) & 3))) * 16);
-          vv[4 * c] = q.x; vv[4 * c + 1] = q.y; vv[4 * c + 2] = q.z; vv[4 * c + 3] = q.w;
-        }
-      } else {
-        const float* Bf = reinterpret_cast<const float*>(B_);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vv[j] = Bf[(8 * h + j) * GX_TN + brow];
-      }
-      uint4 H, Mi, L;
-      x_split8(vv, H, Mi, L);
-      bp[0] = __builtin_bit_cast(xbf16x8, H);
-      bp[1] = __builtin_bit_cast(xbf16x8, Mi);
-      bp[2] = __builtin_bit_cast(xbf16x8, L);
+    // stage `step` has landed in this wave's part (DMA retires in order: at most the RING - 2 younger stages in flight)
+    switch (min(nsteps - 1 - step, RING - 2)) {
+      case 0: gx_wait_vmcnt<0>(); break;
+      case 1: gx_wait_vmcnt<PER>(); break;
+      default: gx_wait_vmcnt<2 * PER>(); break;
     }
-    xbf16x8 ap[MT][3];
+    // ... in every wave's part, and every wave is done with stage step - 1, whose slot is refilled now.  A bare s_barrier:
+    // __syncthreads() is fence + barrier, and the fence makes the compiler drain EVERY LDS-DMA in flight (s_waitcnt
+    // vmcnt(0) before each barrier) -- the ring would prefetch nothing.  No wave writes LDS except by DMA, whose arrival the
+    // counted wait above has established, so the barrier alone orders everything this loop needs.
+    asm volatile("s_barrier" ::: "memory");
+    if (step + RING - 1 < nsteps) issue(step + RING - 1);
+    const char* A_ = xsm + (step % RING) * SS;
+    const char* B_ = A_ + SA;
+    // a block that owns its CU issues every fragment read of the step before the first MFMA (left alone the scheduler sinks
+    // each group of reads to just before its use and waits lgkmcnt(0) five times a step); the two-per-CU tiles leave the
+    // order to the compiler -- all fragments live at once would not fit their 128 registers
+    xbf16x8 bp[NTW][3], ap[MTW][3];
+    auto load_a = [&](int pl) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int mt = 0; mt < MTW; ++mt)
+        ap[mt][pl] = *reinterpret_cast<const xbf16x8*>(A_ + ((pl * 2 + h) * TM + arow + mt * 32) * 16);
+    };
+    if (BMODE == 0) {
+      auto load_b = [&](int pl) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        ap[mt][pl] = *reinterpret_cast<const xbf16x8*>(A_ + ((pl * 2 + h) * TM + mt * 32 + li) * 16);
+        for (int nt = 0; nt < NTW; ++nt)
+          bp[nt][pl] = *reinterpret_cast<const xbf16x8*>(B_ + ((pl * 2 + h) * GX_TN + bcol + nt * 32) * 16);
+      };
+      load_a(2); load_b(0); load_a(0); load_b(2); load_a(1); load_b(1);
+    } else {
+      float vv[NTW][8];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = bcol + nt * 32;
+        if (BMODE == 1) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float4 q = *reinterpret_cast<const float4*>(B_ + (col * 4 + ((2 * h + c) ^ ((col >> 2) & 3))) * 16);
+            vv[nt][4 * c] = q.x; vv[nt][4 * c + 1] = q.y; vv[nt][4 * c + 2] = q.z; vv[nt][4 * c + 3] = q.w;
+          }
+        } else {
+          const float* Bf = reinterpret_cast<const float*>(B_);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[nt][j] = Bf[(8 * h + j) * GX_TN + col];
+        }
+      }
+      load_a(2); load_a(0); load_a(1);
+      if constexpr (gx_blocks_per_cu(TM) == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {   // the weight fragments are split while the A fragments are on their way
+        uint4 H, Mi, L;
+        x_split8(vv[nt], H, Mi, L);
+        bp[nt][0] = __builtin_bit_cast(xbf16x8, H);
+        bp[nt][1] = __builtin_bit_cast(xbf16x8, Mi);
+        bp[nt][2] = __builtin_bit_cast(xbf16x8, L);
+      }
+    }
+    if constexpr (gx_blocks_per_cu(TM) == 1) __builtin_amdgcn_sched_barrier(0);
     // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mt][PA[t]], bp[PB[t]], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mt][PA[t]], bp[nt][PB[t]], acc[mt][nt], 0, 0, 0);
   }
 
-  // ---- epilogue: D layout col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
-  const int n = n0 + brow;
-  if (n < p.N) {
-    const float bv = (p.bias && split == 0) ? p.bias[n] : 0.f;
+  // ---- epilogue: D layout col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m).  The accumulate mode reads the
+  // 16 old values of an accumulator tile in one batch (row clamped instead of branched around: a branch per element made
+  // the compiler emit load - wait - add - store 128 times in a row, ~80 us of serialized round trips per launch).
+  float* const cbase = p.out_mode == 3 ? p.C + (long)split * p.M * p.N : p.C;
+  const long rstride = p.out_mode == 3 ? (long)p.N : p.ldc;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int n = n0 + bcol + nt * 32;
+    const bool nok = n < p.N;
+    float* const col = cbase + min(n, p.N - 1);
+    const float bv = (p.bias && split == 0 && nok) ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M) {
-          const float val = acc[mt][r] + bv;
-          if (p.out_mode == 3) {
-            p.C[((long)split * p.M + m) * p.N + n] = val;
-          } else {
-            float* dst = p.C + (long)m * p.ldc + n;
-            if (p.out_mode == 0) *dst = val; else *dst += val;
-          }
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int mb = m0 + wm * RW + mt * 32 + 4 * h;
+      if (p.out_mode == 1) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = col[(long)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * rstride];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (nok && m < p.M) col[(long)m * rstride] = old[r] + acc[mt][nt][r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (nok && m < p.M) col[(long)m * rstride] = acc[mt][nt][r] + bv;
         }
       }
     }
@@ -292,11 +347,11 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(GxArgs p) {
 }
 
 // role: 1 forward, 2 input gradient, 4 weight gradient.  Measured on Linear(13824, 1024) against the fp32 matrix-core
-// kernel of gemm.hip (profiles/r03_other_configs.txt): the input gradient wins at every row count (R = 320: 101 vs 119 us,
-// 560: 113 vs 182 us -- its big operand arrives in whole 1 KB rows); forward and weight gradient only break even from
-// R ~ 560 on (181 vs 178, 180 vs 192 us) and lose below (their LDS-DMA gathers 64-byte pieces / the output is read-modify-
-// written; inference with R = 1398 candidates: Detector:detect 2.23 vs 2.22 ms), so by default they keep the fp32 kernel.
-// FRCNN_GEMM_X / option "gemm_x_roles" = bit mask of the roles that take the split form (0 none, 7 all).
+// kernel of gemm.hip (profiles/r03_other_configs.txt; product + plane split + slab fold): 560 rows 137 / 113 / 132 us against
+// 179 / 184 / 196; 320 rows 92 / 95 / 92 against 105 / 120 / 110; 138 rows 72 / 63 / 63 against 70 / 71 / 65 -- the input
+// gradient wins at every row count, forward and weight gradient from ~200 rows on (below, their plane passes and the K
+// split's slabs cost what the faster product saves).
+// FRCNN_GEMM_X / option "gemm_x_roles" = bit mask of the roles that take the split form (0 none, 7 all; -1 this rule).
 static int g_gemm_x_roles = -2;   // -2: not decided yet (environment FRCNN_GEMM_X, default -1 = the rule below)
 void set_gemm_x_roles(int mask) { g_gemm_x_roles = mask; }
 int get_gemm_x_roles() {
@@ -307,47 +362,75 @@ bool linear_x_eligible(int role, int R, int I, int O) {
   const int mask = get_gemm_x_roles();
   if (!get_split_bf16() || I % 16 != 0 || O % 16 != 0 || R < 32 || (double)R * I * O < 1.0e9) return false;
   if (mask >= 0) return (mask & role) != 0;
-  return role == 2;
+  return role == 2 || R >= 192;
 }
 
-template <int TM, int BMODE>
+template <int TM, int WM, int BMODE>
 static int launch_gx(GxArgs& a, dim3 grid, double flops, double bytes, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<TM, BMODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<TM, WM, BMODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS_MAX));
     attr_set = true;
   }
-  const size_t lds = GX_RING * (size_t)(96 * TM + (BMODE == 0 ? 96 * GX_TN : 64 * GX_TN));
-  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_planes_kernel<TM, BMODE>), grid, dim3(512), lds, a);
+  const size_t lds = (size_t)gx_ring(TM, BMODE) * gx_stage_bytes(TM, BMODE);
+  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_planes_kernel<TM, WM, BMODE>), grid, dim3(512), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
-// Tile height and K split by a round model: one block per CU (256 slots); a block's time ~ steps x (cost of a K step, which
-// grows with the row tiles it multiplies) + a fixed prologue / epilogue; the launch takes ceil(blocks / 256) rounds.
-static void gx_plan(int M, int N, int K, int splitK_max, int* TM, int* splitK) {
+// Tile height and K split by a load model, in matrix-pipe cycles.  The busiest CU holds b = ceil(blocks / 256) blocks; a K
+// step costs a block that is alone on its CU 768 cycles per 64 rows (12 MFMAs of 32 cycles on each of two waves per SIMD)
+// at ~80 % plus ~300 for the barrier, the fragment latency and the DMA issue; two co-resident blocks (tiles of <= 128 rows)
+// share the pipe at ~92 % and hide each other's fixed part; a block pays ~8000 cycles of prologue (first stages from HBM)
+// and epilogue; split-K slabs are written and folded at ~1500 B/clk.
+static void gx_plan(int M, int N, int K, int bmode, int splitK_max, int* TM, int* splitK) {
   double best = 1e300;
-  for (int tmv : {128, 64}) {
+  for (int tmv : {256, 192, 128, 64}) {
+    if (tmv == 256 && bmode != 0) continue;
     if (const char* e = getenv("FRCNN_GX_TM")) if (atoi(e) != tmv) continue;
     const long tiles = (long)cdiv(M, tmv) * cdiv(N, GX_TN);
+    const int bpc = gx_blocks_per_cu(tmv);
     for (int sk = 1; sk <= splitK_max; ++sk) {
       const int kper = cdiv(cdiv(K, sk), 16) * 16;
       if (sk > 1 && kper < 256) break;
       const int sk_eff = cdiv(K, kper);
-      const long rounds = cdivl(tiles * sk_eff, 256);
-      const double step_cost = tmv == 128 ? 1.0 : 0.62;   // 24 vs 12 MFMAs behind the same fragment split and barrier
-      double cost = rounds * ((kper / 16) * step_cost + 40.0) + (sk_eff > 1 ? 8.0 * sk_eff : 0.0);   // + slab traffic
+      const long b = cdivl(tiles * sk_eff, 256);
+      const double mf = (tmv / 64) * 768.0, steps = kper / 16, fixed = 8000.0 + 12.0 * tmv;
+      const double alone = steps * (mf / 0.80 + 300.0) + fixed, paired = steps * (2.0 * mf / 0.92 + 150.0) + fixed;
+      double cost = bpc == 2 ? (b / 2) * paired + (b % 2) * alone : b * alone;
+      if (sk_eff > 1) cost += 8.0 * sk_eff * (double)M * N / 1500.0 / 8.0 + 6000.0;   // slabs out and back in
       if (cost < best) { best = cost; *TM = tmv; *splitK = sk_eff; }
     }
   }
   if (const char* e = getenv("FRCNN_GX_SPLITK")) *splitK = std::max(1, atoi(e));
 }
 
+// wave layout by operand form: planes x planes -> 2 x 4 waves of TM / 2 rows x 64 columns (fewest fragment reads per MFMA);
+// fp32 weights -> 1 x 8 waves of TM rows x 32 columns (each weight fragment is split by exactly one wave: 44 VALU
+// instructions behind TM / 32 x 6 MFMAs)
+template <int BMODE>
+static int launch_gx_tm(int TM, GxArgs& a, dim3 grid, double flops, double bytes, hipStream_t s) {
+  if constexpr (BMODE == 0) {
+    switch (TM) {
+      case 256: return launch_gx<256, 2, 0>(a, grid, flops, bytes, s);
+      case 192: return launch_gx<192, 2, 0>(a, grid, flops, bytes, s);
+      case 128: return launch_gx<128, 2, 0>(a, grid, flops, bytes, s);
+      default: return launch_gx<64, 2, 0>(a, grid, flops, bytes, s);
+    }
+  } else {
+    switch (TM) {
+      case 192: return launch_gx<192, 1, BMODE>(a, grid, flops, bytes, s);
+      case 128: return launch_gx<128, 1, BMODE>(a, grid, flops, bytes, s);
+      default: return launch_gx<64, 1, BMODE>(a, grid, flops, bytes, s);
+    }
+  }
+}
+
 static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const float* bias, int out_mode, hipStream_t s, int ws_slot) {
   FR_CHECK(a.K % 16 == 0, "gemm_planes: K = %d must be a multiple of 16", a.K);
   int TM = 128, splitK = 1;
-  gx_plan(a.M, a.N, a.K, splitK_max, &TM, &splitK);
+  gx_plan(a.M, a.N, a.K, bmode, splitK_max, &TM, &splitK);
   const int tm = cdiv(a.M, TM), tn = cdiv(a.N, GX_TN);
   a.kPerSplit = cdiv(cdiv(a.K, splitK), 16) * 16;
   splitK = cdiv(a.K, a.kPerSplit);
@@ -361,11 +444,8 @@ static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const flo
   dim3 grid(tn * tm * splitK);
   const double flops = 2.0 * a.M * a.N * (double)a.K;
   const double bytes = 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
-  int rc;
-  if (TM == 128) rc = bmode == 0 ? launch_gx<128, 0>(a, grid, flops, bytes, s) : bmode == 1 ? launch_gx<128, 1>(a, grid, flops, bytes, s)
-                                                                                             : launch_gx<128, 2>(a, grid, flops, bytes, s);
-  else rc = bmode == 0 ? launch_gx<64, 0>(a, grid, flops, bytes, s) : bmode == 1 ? launch_gx<64, 1>(a, grid, flops, bytes, s)
-                                                                                 : launch_gx<64, 2>(a, grid, flops, bytes, s);
+  const int rc = bmode == 0 ? launch_gx_tm<0>(TM, a, grid, flops, bytes, s) : bmode == 1 ? launch_gx_tm<1>(TM, a, grid, flops, bytes, s)
+                                                                                         : launch_gx_tm<2>(TM, a, grid, flops, bytes, s);
   FR_TRY(rc);
   if (splitK > 1) FR_TRY(gemm_reduce_slabs(a.C, splitK, a.M, a.N, bias, user_C, a.ldc, out_mode == OUT_ADD, s));
   return FRCNN_OK;
@@ -378,7 +458,7 @@ int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* 
   a.Ap = (const unsigned short*)Xp; a.aPlane = (long)R * I; a.aLd = R;
   a.B = W; a.bPlane = 0; a.bLd = I;
   a.ldc = O; a.M = R; a.N = O; a.K = I;
-  return gx_run(a, 1, 24, y, bias, OUT_STORE, s, ws_slot);
+  return gx_run(a, 1, 32, y, bias, OUT_STORE, s, ws_slot);
 }
 
 // gX[R][I] (= | +=) gY W ; Gp = planes of gY, [3][O/8][R][8]

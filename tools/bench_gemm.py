@@ -26,6 +26,9 @@ def run(R, I, O, reps=5):
               % (R, I, O, name, t * 1e3, 2.0 * R * I * O / t / 1e9, ms[kg] / reps * 1e3, la[kg] // reps, ms[ke] / reps * 1e3, la[ke] // reps), flush=True)
 
 if __name__ == "__main__":
+    if os.environ.get("ONLY_R"):
+        run(int(os.environ["ONLY_R"]), 13824, 1024, reps=3)
+        sys.exit(0)
     for R in (138, 320, 560):
         run(R, 13824, 1024)
     run(560, 1024, 512)
