@@ -26,6 +26,34 @@ struct GemmArgs {
   int M, N, K, kPerSplit, out_mode;  // 0 store, 1 add, 3 split-K slab
 };
 
+// One 32 x 32 accumulator tile to memory: rows m = mb + (r & 3) + 8 (r >> 2) (mb includes the lane half's 4 h), column n.
+// The bias and -- in the accumulate mode -- the 16 old values are read in one batch with clamped addresses; a test, a bias
+// load and an old-value load per element made the compiler emit load - wait - add - store sixteen times per tile.
+__device__ __forceinline__ void gemm_store_tile(const f32x16& a, const GemmArgs& p, int mb, int n, int split) {
+  const bool nok = n < p.N;
+  const int nc = min(n, p.N - 1);
+  const float bv = (p.bias && split == 0) ? p.bias[nc] : 0.f;
+  float* const col = (p.out_mode == 3 ? p.C + (long)split * p.M * p.N : p.C) + nc;   // 3: split-K slab [split][M][N]
+  const long rs = p.out_mode == 3 ? (long)p.N : p.ldc;
+  if (p.out_mode == 1) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = col[(long)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * rs];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (nok && m < p.M) col[(long)m * rs] = old[r] + (a[r] + bv);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (nok && m < p.M) col[(long)m * rs] = a[r] + bv;
+    }
+  }
+}
+
+
 // Operand tile loader: ROWS (m or n) x GBK (k) floats -> LDS image T[k][row] (pitch ROWS+1).
 // KC: the operand is contiguous along k (else along the row index).  VEC: 16-byte loads are legal
 // (strides multiple of 4 floats, base 16-byte aligned).  All loads of the tile are issued first with
@@ -135,22 +163,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * (TN / 2) + j * 32 + li;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M && n < p.N) {
-          float v = acc[i][j][r];
-          if (p.bias && blockIdx.z == 0) v += p.bias[n];
-          if (p.out_mode == 3) {   // split-K slab [split][M][N]
-            p.C[((long)blockIdx.z * p.M + m) * p.N + n] = v;
-          } else {
-            float* dst = p.C + (long)m * p.ldc + n;
-            if (p.out_mode == 0) *dst = v; else *dst += v;
-          }
-        }
-      }
-    }
+    for (int i = 0; i < MT; ++i)
+      gemm_store_tile(acc[i][j], p, m0 + wm * (TM / 2) + i * 32 + 4 * h, n, (int)blockIdx.z);
   }
 }
 
@@ -285,22 +299,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmArgs p) {
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * (TN / 2) + j * 32 + li;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M && n < p.N) {
-          float v = acc[i][j][r];
-          if (p.bias && blockIdx.z == 0) v += p.bias[n];
-          if (p.out_mode == 3) {
-            p.C[((long)blockIdx.z * p.M + m) * p.N + n] = v;
-          } else {
-            float* dst = p.C + (long)m * p.ldc + n;
-            if (p.out_mode == 0) *dst = v; else *dst += v;
-          }
-        }
-      }
-    }
+    for (int i = 0; i < MT; ++i)
+      gemm_store_tile(acc[i][j], p, m0 + wm * (TM / 2) + i * 32 + 4 * h, n, (int)blockIdx.z);
   }
 }
 

@@ -100,7 +100,7 @@ def _compare_gradient(native, g, g_want, lo, hi, tol_l2=1e-3, elementwise=True, 
         if not err <= tol_l2 * nb + 1e-6 * np.sqrt(cnt) + floor:
             bad.append("tensor @%d kind %d (%d elements): |a-b|=%.3e |b|=%.3e" % (off, kind, cnt, err, nb))
         scale = max(1e-30, np.abs(b).max())
-        if elementwise and not np.abs(a - b).max() <= 1e-4 * max(1.0, scale) + 1e-3 * scale:
+        if elementwise and not np.abs(a - b).max() <= 1e-4 * max(1.0, scale) + 1e-3 * scale + floor:   # (a slope is one element: same bar)
             bad.append("tensor @%d kind %d (%d elements) elementwise: max|a-b|=%.3e max|b|=%.3e" % (off, kind, cnt, np.abs(a - b).max(), scale))
     assert not bad, "\n".join(bad)
 
