@@ -14,9 +14,22 @@
 // map this kernel relies on: result lane i, element j  <-  supplier lane 4j + (i>>2), element i&3).
 //
 // Block = 64 o x 64 c x 9 taps (2 x 2 waves, nine 32x32 accumulators = 144 registers each), walking its share of 4 x 16
-// pixel tiles (K = 64 per tile: 4 K-steps x 9 taps x 6 partial products = 216 MFMAs per wave).  69 KB of LDS -> two blocks
-// per CU, one staging while the other multiplies.  Partial sums go to slabs [split][tap][o][c] and are folded by
-// wgrad_reduce_kernel (conv.hip) exactly as in the fp32 matrix-core kernel.
+// pixel tiles (K = 64 per tile: 216 MFMAs per wave).  ONE block per CU (<= 256 blocks), four waves of ~300 registers:
+//   * the 48 global loads of the NEXT tile are issued right before the products of the current one and stay in flight
+//     under its 216 MFMAs (with two 254-register blocks per CU -- rounds 1 and 2 -- there was no room to hold them: each
+//     tile paid its memory round trip in front of its products, covered only by the CU's other block);
+//   * the products walk the PATCH rows: the fragments of patch row r (three kx shifts x three planes) serve every
+//     (K step ks, tap row ky) with ks + ky = r, so each is read once instead of up to three times -- 132 transposed reads
+//     per wave and tile instead of 240 (ds_read_b64_tr_b16 moves ~50-64 B/clk: at 240 reads the LDS pipe was as busy as
+//     the matrix pipe);
+//   * a wave of this kernel leaves 200 registers per lane of its SIMD free, i.e. room for a wave of the main stream's
+//     convolution kernels beside it: launches alone take what they took (b2c2 167 vs 153 us), the training step is 1.5 %
+//     faster.
+// Tried and measured slower (all parity-green): the same with double-buffered LDS images and the next
+// tile's conversion interleaved into the products (189 us: the scheduler serialises conversion and MFMAs in one wave),
+// twelve waves = quadrants x tap rows or tap columns with three accumulators each and three waves per SIMD (205 / 174 us).
+// Partial sums go to slabs [split][tap][o][c] and are folded by wgrad_reduce_kernel (conv.hip) exactly as in the fp32
+// matrix-core kernel.
 #include <cstdlib>
 
 #include "kernels.h"
@@ -86,7 +99,7 @@ __device__ __forceinline__ bf16x8 wx_frag(const char* p0, const char* p1) {
 }
 
 template <bool SLOPE, bool SCALE>
-__global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
+__global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Gs = smem;                // [plane][og][WX_GP][8]
   char* const Xs = smem + WX_GBYTES;    // [plane][cg][WX_XP][8]
@@ -137,109 +150,120 @@ __global__ __launch_bounds__(256, 2) void conv_wgradx_kernel(WgradXArgs p) {
   const char* const laneB = Xs + ((cl >> 3) * WX_XP + 8 * h + js) * 16 + (cl & 7) * 2;
 
   const int nPix = p.tilesX * p.tilesY;
-  for (int t = split; t < nPix; t += p.nSplit) {
+  // ---- every global load of a tile is issued in one go (one memory round trip, 48 values in flight per thread: gradient
+  // tile 2 items per thread, input patch 4 = 2 channel groups x 2 position slots) -- for the NEXT tile, right before the
+  // products of the current one, so that the round trip runs under 216 MFMAs instead of in front of them; the splits and
+  // LDS writes follow when the products are done.
+  float vg[2][8], vp[2][2][8];
+  bool pok[2], gok = false;
+  auto load_tile = [&](int t) {
     const int oy0 = (t / p.tilesX) * WX_TH, ox0 = (t % p.tilesX) * WX_TW;
-    // ---- every global load of the tile first (one memory round trip, 48 values in flight per thread), then the splits:
-    // gradient tile: 2 items per thread; input patch: 4 items (2 channel groups x 2 position slots)
-    float vg[2][8], vp[2][2][8];
-    bool pok[2];
     const int goy = oy0 + g_ty, gox = ox0 + g_tx;
-    const bool gok = goy < p.Ho && gox < p.Wo;
-    {
-      const unsigned gofs = gok ? (unsigned)(goy * p.Wo + gox) * 4u : 0u;
+    gok = goy < p.Ho && gox < p.Wo;
+    const unsigned gofs = gok ? (unsigned)(goy * p.Wo + gox) * 4u : 0u;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const char* gb = reinterpret_cast<const char*>(p.g) + (size_t)(o0 + 8 * (wave + 4 * it)) * g_bytes;
+    for (int it = 0; it < 2; ++it) {
+      const char* gb = reinterpret_cast<const char*>(p.g) + (size_t)(o0 + 8 * (wave + 4 * it)) * g_bytes;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vg[it][j] = *reinterpret_cast<const float*>(gb + j * g_bytes + gofs);
+      for (int j = 0; j < 8; ++j) vg[it][j] = *reinterpret_cast<const float*>(gb + j * g_bytes + gofs);
+    }
+    unsigned pofs[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int iy = oy0 - p.pad + p_r[m], ix = ox0 - p.pad + p_c[m];
+      pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      pofs[m] = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const char* ib = reinterpret_cast<const char*>(p.in) + (size_t)(c0 + 8 * (2 * wave + gi)) * in_bytes;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vp[gi][m][j] = *reinterpret_cast<const float*>(ib + j * in_bytes + pofs[m]);
+    }
+  };
+  auto stage_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = gok ? vg[it][j] : 0.f;
+      uint4 Hh, Mi, L;
+      wx_split8(x, Hh, Mi, L);
+      char* d = Gs + ((wave + 4 * it) * WX_GP + lane) * 16;
+      *reinterpret_cast<uint4*>(d) = Hh;
+      *reinterpret_cast<uint4*>(d + 8 * WX_GP * 16) = Mi;
+      *reinterpret_cast<uint4*>(d + 16 * WX_GP * 16) = L;
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int cg = 2 * wave + gi;
+      float sc[8];
+      if (SCALE) {
+        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + c0 + 8 * cg);
+        const float4 s0 = sp[0], s1 = sp[1];
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
       }
-      unsigned pofs[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const int iy = oy0 - p.pad + p_r[m], ix = ox0 - p.pad + p_c[m];
-        pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        pofs[m] = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
-      }
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi) {
-        const char* ib = reinterpret_cast<const char*>(p.in) + (size_t)(c0 + 8 * (2 * wave + gi)) * in_bytes;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) vp[gi][m][j] = *reinterpret_cast<const float*>(ib + j * in_bytes + pofs[m]);
-      }
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = gok ? vg[it][j] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          float v = vp[gi][m][j];
+          if (SLOPE) v = v > 0.f ? v : slope * v;
+          if (SCALE) v *= sc[j];
+          x[j] = pok[m] ? v : 0.f;
+        }
         uint4 Hh, Mi, L;
         wx_split8(x, Hh, Mi, L);
-        char* d = Gs + ((wave + 4 * it) * WX_GP + lane) * 16;
-        *reinterpret_cast<uint4*>(d) = Hh;
-        *reinterpret_cast<uint4*>(d + 8 * WX_GP * 16) = Mi;
-        *reinterpret_cast<uint4*>(d + 16 * WX_GP * 16) = L;
-      }
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi) {
-        const int cg = 2 * wave + gi;
-        float sc[8];
-        if (SCALE) {
-          const float4* sp = reinterpret_cast<const float4*>(p.in_scale + c0 + 8 * cg);
-          const float4 s0 = sp[0], s1 = sp[1];
-          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          float x[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v = vp[gi][m][j];
-            if (SLOPE) v = v > 0.f ? v : slope * v;
-            if (SCALE) v *= sc[j];
-            x[j] = pok[m] ? v : 0.f;
-          }
-          uint4 Hh, Mi, L;
-          wx_split8(x, Hh, Mi, L);
-          if (p_in[m]) {
-            char* d = Xs + (cg * WX_XP + lane + 64 * m) * 16;
-            *reinterpret_cast<uint4*>(d) = Hh;
-            *reinterpret_cast<uint4*>(d + 8 * WX_XP * 16) = Mi;
-            *reinterpret_cast<uint4*>(d + 16 * WX_XP * 16) = L;
-          }
+        if (p_in[m]) {
+          char* d = Xs + (cg * WX_XP + lane + 64 * m) * 16;
+          *reinterpret_cast<uint4*>(d) = Hh;
+          *reinterpret_cast<uint4*>(d + 8 * WX_XP * 16) = Mi;
+          *reinterpret_cast<uint4*>(d + 16 * WX_XP * 16) = L;
         }
       }
     }
+  };
+  if (split < nPix) load_tile(split);
+  for (int t = split; t < nPix; t += p.nSplit) {
+    stage_tile();
     __syncthreads();
-    // ---- K = the tile's 64 pixels: K-step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it
+    if (t + p.nSplit < nPix) load_tile(t + p.nSplit);
+    // ---- K = the tile's 64 pixels: K-step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it.  The loop
+    // runs over PATCH rows: the fragments of patch row r (three kx shifts x three planes) serve every (ks, ky) with
+    // ks + ky = r, so each is read from LDS once instead of up to three times -- 132 transposed reads per tile instead of
+    // 240.  (ds_read_b64_tr_b16 moves 64 B/clk: at 240 reads the LDS pipe was busier than the matrix pipe.)  The gradient
+    // fragments of the up to three K steps that meet a row stay in registers (a sliding window).
+    bf16x8 a[WX_TH][3];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest partial products first; plane 0 = h, 1 = m, 2 = l
 #pragma unroll
-    for (int ks = 0; ks < WX_TH; ++ks) {
-      bf16x8 a[3];
+    for (int r = 0; r < WX_TH + 2; ++r) {
+      if (r < WX_TH) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[pl] = wx_frag(laneA + (pl * 8 * WX_GP + 16 * ks) * 16, laneA + (pl * 8 * WX_GP + 16 * ks + 4) * 16);
-      // taps in groups of up to three, the six partial products of a group interleaved: consecutive MFMAs write
+        for (int pl = 0; pl < 3; ++pl)
+          a[r][pl] = wx_frag(laneA + (pl * 8 * WX_GP + 16 * r) * 16, laneA + (pl * 8 * WX_GP + 16 * r + 4) * 16);
+      }
+      bf16x8 b[3][3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[kx][pl] = wx_frag(laneB + (pl * 8 * WX_XP + r * WX_PW + kx) * 16, laneB + (pl * 8 * WX_XP + r * WX_PW + kx + 4) * 16);
+      // the (ks, ky) pairs of this row, their 3 kx taps and 6 partial products interleaved: consecutive MFMAs write
       // different accumulators (a chain on ONE accumulator issues at its dependent latency, not at the pipe rate)
 #pragma unroll
-      for (int t0 = 0; t0 < 9; t0 += WX_TG) {
-        bf16x8 b[WX_TG][3];
+      for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int i = 0; i < WX_TG; ++i) {
-          const int tap = t0 + i < 9 ? t0 + i : 8;
-          const int ky = tap / 3, kx = tap - 3 * ky;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int ks = r - ky;
+          if (ks >= 0 && ks < WX_TH) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            b[i][pl] = wx_frag(laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx) * 16,
-                               laneB + (pl * 8 * WX_XP + (ks + ky) * WX_PW + kx + 4) * 16);
+            for (int kx = 0; kx < 3; ++kx)
+              acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][PA[q]], b[kx][PB[q]], acc[3 * ky + kx], 0, 0, 0);
+          }
         }
-        // smallest partial products first; plane 0 = h, 1 = m, 2 = l
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-          for (int i = 0; i < WX_TG; ++i)
-            if (t0 + i < 9) acc[t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[i][PB[q]], acc[t0 + i], 0, 0, 0);
-      }
     }
     __syncthreads();
   }
@@ -262,9 +286,7 @@ static void wgradx_plan(WgradXArgs& a) {
   a.tilesX = cdiv(a.Wo, WX_TW); a.tilesY = cdiv(a.Ho, WX_TH);
   a.oTiles = a.O / 64; a.cTiles = a.Cin / 64;
   const long base = (long)a.oTiles * a.cTiles, npix = (long)a.tilesX * a.tilesY;
-  static const int per_cu = getenv("FRCNN_WGX_PER_CU") ? atoi(getenv("FRCNN_WGX_PER_CU")) : 2;
-  const long target = per_cu == 1 ? 256 : 512;
-  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, (target + base / 2) / base));   // two blocks per CU: ~512 blocks
+  a.nSplit = (int)std::max<long>(1, std::min<long>(npix, 256 / base));   // one block per CU, one round: <= 256 blocks
   if (const char* e = getenv("FRCNN_WGX_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }
 
@@ -286,8 +308,7 @@ static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) 
   const int grid = a.oTiles * a.cTiles * a.nSplit;
   const double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
   if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
-  static const int per_cu = getenv("FRCNN_WGX_PER_CU") ? atoi(getenv("FRCNN_WGX_PER_CU")) : 2;
-  const size_t lds = per_cu == 1 ? std::max<size_t>(WX_LDS, 84 * 1024) : (size_t)WX_LDS;   // > 80 KB: one block per CU
+  const size_t lds = std::max<size_t>(WX_LDS, 84 * 1024);   // (> 80 KB: one block per CU, whatever the register count)
   hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), lds, s, a);
   FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
   if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
