@@ -226,8 +226,10 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
     FR_HIP(hipMemset(c.wd.p, 0, c.wd.bytes));
   }
   // 3x3 launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time
-  // (the 5x5 / 7x7 anchor nets keep the fp32 kernel: on their 25x46 / 23x44 maps the split form's 8x10-pixel tiles fill 63 %
-  // of an MFMA tile and its 7.2 M weights would have to be split every step -- measured 3.59 ms/step with them against 3.38)
+  // (the 5x5 / 7x7 anchor nets keep the fp32 kernel.  Round 2: on their 25x46 / 23x44 maps the split form's 8x10-pixel tiles fill
+  // 63 % of an MFMA tile and its 7.2 M weights have to be split every step -- 3.59 ms/step with them against 3.38.  Round 3,
+  // with a 240 / 308-position patch buffer so that they get 8x16-pixel tiles, and up to 24 K splits: 18 tiles x 12..24 splits
+  // of 49-tap stages on two blocks per CU -- 3.14 ms/step against 3.11)
   c.x_f = c.k == 3 && conv_x3_eligible(c.Cin, c.Cout, c.k);
   c.x_d = c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
   if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout, c.k)));
