@@ -1112,8 +1112,51 @@ static void wgrad_plan(WgradArgs& a, int k) {
   if (const char* e = getenv("FRCNN_WG_NSPLIT")) a.nSplit = (int)std::max<long>(1, std::min<long>(npix, atoi(e)));
 }
 
+// the same with four consecutive (o, c) pairs of one tap per thread: 16-byte slab loads, four of them in flight (needs 4 | OC)
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, int nSplit, int taps, int OC,
+                                                            float* __restrict__ gw) {
+  __shared__ float4 sh[4][64];
+  const long total = (long)taps * OC;
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (long t0 = (long)blockIdx.x * 256; t0 < total; t0 += (long)gridDim.x * 256) {
+    const long t = t0 + 4 * tx;
+    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    auto add = [](float4& a, const float4 x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; };
+    if (t < total) {
+      int s = g;
+      for (; s + 12 < nSplit; s += 16) {   // (the order of round 2's scalar kernel: the sums are the same numbers)
+        const float4 x0 = *reinterpret_cast<const float4*>(slab + (size_t)s * total + t);
+        const float4 x1 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 4) * total + t);
+        const float4 x2 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 8) * total + t);
+        const float4 x3 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 12) * total + t);
+        add(a0, x0); add(a1, x1); add(a2, x2); add(a3, x3);
+      }
+      for (; s < nSplit; s += 4) add(a0, *reinterpret_cast<const float4*>(slab + (size_t)s * total + t));
+    }
+    sh[g][tx] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                            (a0.w + a1.w) + (a2.w + a3.w));
+    __syncthreads();
+    if (g == 0 && t < total) {
+      const int tap = (int)(t / OC);
+      const int oc = (int)(t - (long)tap * OC);
+      const float4 p0 = sh[0][tx], p1 = sh[1][tx], p2 = sh[2][tx], p3 = sh[3][tx];
+      float* d = gw + (size_t)oc * taps + tap;
+      d[0] += (p0.x + p1.x) + (p2.x + p3.x);
+      d[taps] += (p0.y + p1.y) + (p2.y + p3.y);
+      d[2 * (size_t)taps] += (p0.z + p1.z) + (p2.z + p3.z);
+      d[3 * (size_t)taps] += (p0.w + p1.w) + (p2.w + p3.w);
+    }
+    __syncthreads();
+  }
+}
+
 int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s) {
   const long total = (long)taps * OC;
+  if (OC % 4 == 0 && ((uintptr_t)slab & 15) == 0) {
+    const int rgrid = (int)std::min<long>(cdivl(total, 256), 4096);
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(rgrid), dim3(256), 0, s, slab, nSplit, taps, OC, gw);
+    return FRCNN_OK;
+  }
   const int rgrid = (int)std::min<long>(cdivl(total, 64), 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, slab, nSplit, taps, OC, gw);
   return FRCNN_OK;

@@ -453,13 +453,33 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 }
 
 // out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
-__global__ void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw, const float* __restrict__ bias,
-                                        float* __restrict__ out, int accumulate) {
-  const long total = (long)M * hw;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    float v = bias ? bias[t / hw] : 0.f;
-    for (int s = 0; s < nSplit; ++s) v += slab[(size_t)s * total + t];
-    if (accumulate) out[t] += v; else out[t] = v;
+// Four consecutive pixels of one filter per thread when the map size allows (16-byte loads, the slabs of up to eight splits
+// in flight at once), in split order -- the sum is the same number whatever the vector width.
+template <int VEC>
+__global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int accumulate) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const long total = (long)M * hw, nvec = total / VEC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const long t = i * VEC;
+    const float b = bias ? bias[t / hw] : 0.f;   // (VEC divides hw: the vector stays inside one filter's map)
+    vec_t v = b;
+    int s = 0;
+    for (; s + 8 <= nSplit; s += 8) {
+      vec_t x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const vec_t*>(slab + (size_t)(s + j) * total + t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += x[j];
+    }
+    for (; s + 2 <= nSplit; s += 2) {
+      const vec_t x0 = *reinterpret_cast<const vec_t*>(slab + (size_t)s * total + t);
+      const vec_t x1 = *reinterpret_cast<const vec_t*>(slab + (size_t)(s + 1) * total + t);
+      v += x0; v += x1;
+    }
+    if (s < nSplit) v += *reinterpret_cast<const vec_t*>(slab + (size_t)s * total + t);
+    vec_t* o = reinterpret_cast<vec_t*>(out + t);
+    if (accumulate) *o += v; else *o = v;
   }
 }
 
@@ -553,9 +573,20 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   FR_TRY(rc);
   if (slab) {
     long total = (long)M * a.Ho * a.Wo;
-    int grid = (int)std::min<long>(cdivl(total, 256), 4096);
-    FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel, dim3(grid), dim3(256), 0,
-              (const float*)a.out, a.splitK, M, (long)a.Ho * a.Wo, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    int grid;
+    const long hw = (long)a.Ho * a.Wo;
+    const bool al = ((uintptr_t)out & 15) == 0 && ((uintptr_t)a.out & 15) == 0;
+    const int vec = al && hw % 4 == 0 ? 4 : al && hw % 2 == 0 ? 2 : 1;
+    grid = (int)std::min<long>(cdivl(total / vec, 256), 4096);
+    if (vec == 4)
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<4>, dim3(grid), dim3(256), 0,
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    else if (vec == 2)
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0,
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
+    else
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0,
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
     FR_LAUNCH_CHECK();
   }
   return FRCNN_OK;
