@@ -118,6 +118,7 @@ struct frcnn_model {
   bool block_ev_valid = false;
   bool loss_pending = false;
   DevBuf wg_ws;                // split-K slab workspace of the weight-gradient kernels
+  DevBuf wg_ws_first;          // ... of the first layer's, which runs on the caller's stream beside the side stream's last launches
   DevBuf img;                  // copy of the input image (needed by the first conv's accGradParameters)
   // cnet state
   int R = 0, D = 0;
@@ -284,6 +285,7 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     wsb = std::max(wsb, conv_wgrad_workspace_bytes(hd.c1.Cin, hd.c1.H, hd.c1.W, hd.c1.Cout, 1, 0));
   }
   FR_TRY(m->wg_ws.ensure(wsb));
+  { const Conv& c0 = m->convs[0]; FR_TRY(m->wg_ws_first.ensure(conv_wgrad_workspace_bytes(c0.Cin, c0.H, c0.W, c0.Cout, c0.k, c0.pad))); }
   {  // pack-job table (buffers may have been re-allocated above)
     std::vector<PackJob> jobs;
     for (auto& c : m->convs)
@@ -373,7 +375,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release(); l.xp.release(); l.xpT.release(); l.gp.release(); l.gpT.release();
   }
-  m->img.release(); m->wg_ws.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
+  m->img.release(); m->wg_ws.release(); m->wg_ws_first.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
@@ -928,8 +930,19 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
-      if (use_side) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
-      FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
+      // The first layer's weight gradient ends the pass and the caller's stream has nothing left to do (no input gradient for
+      // the image): it runs THERE, with a slab workspace of its own, beside the side stream's last launches instead of
+      // behind them (the optimiser waited ~80 us for the side stream's tail).
+      const bool on_caller = use_side && b == 0 && st == 0;
+      if (use_side && !on_caller) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
+      if (on_caller) {
+        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws_first.p,
+                          m->wg_ws_first.bytes, s));
+        FR_HIP(hipEventRecord(m->join_ev, ws));          // (block 0's other convolutions, if any, are on the side stream)
+        FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+      } else {
+        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
+      }
       if (st == 0) {   // every gradient of block b's parameters is final once this launch has run (its fork also
                        // covers the bias / slope sums that act_backward accumulates on the caller's stream)
         while (m->block_ev.size() < (size_t)nb) {
@@ -937,7 +950,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
           FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
           m->block_ev.push_back(e);
         }
-        FR_HIP(hipEventRecord(m->block_ev[b], ws));
+        FR_HIP(hipEventRecord(m->block_ev[b], on_caller ? s : ws));
       }
       if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
