@@ -56,7 +56,8 @@ int frcnn_device_name(char *buf_host, int len);
  * operator-level entry points at once and to a model from its next (re)shaping on.
  * "gemm_x_roles" (default -1; environment FRCNN_GEMM_X): which products of a large nn.Linear (the cnet's Linear(13824, 1024))
  * take the split-bf16 operand form of csrc/gemmx.hip -- bit 1 forward, 2 input gradient, 4 weight gradient; -1 = the
- * measured rule (the input gradient only: the other two break even at best), 0 = fp32 matrix-core kernels for all three. */
+ * measured rule (the input gradient always; forward and weight gradient from 192 rows on, where they beat the fp32 kernels),
+ * 0 = fp32 matrix-core kernels for all three. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 
