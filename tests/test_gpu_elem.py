@@ -147,6 +147,35 @@ def test_linear_fc1_split_bf16_form(F, O, R):
         assert not np.array_equal(res[1][k], res[0][k]), "the split form was not taken"
 
 
+@pytest.mark.parametrize("R,tm", [(33, None), (193, None), (561, 64), (561, 128), (561, 192), (561, 256), (1398, None)])
+def test_linear_fc1_split_form_tile_heights_and_ragged_rows(F, O, R, tm, monkeypatch):
+    """The split-form Linear kernels (gemmx.hip) with row counts that are no multiple of any tile (33: less than one tile;
+    193 / 561: one row into a new tile; 1398: the candidate count of an inference frame) and with every tile height forced
+    in turn (FRCNN_GX_TM; 256 rows exist for the planes x planes weight gradient only -- the other roles then keep their
+    own choice): forward, input gradient and weight gradient against fp64 at the 1e-4 bar."""
+    I, Oo = 13824, 1024
+    if tm is not None:
+        monkeypatch.setenv("FRCNN_GX_TM", str(tm))
+    rng = np.random.RandomState(R + (tm or 0))
+    x = rng.randn(R, I).astype(np.float32)
+    w = (rng.randn(Oo, I) / np.sqrt(I)).astype(np.float32); b = rng.randn(Oo).astype(np.float32)
+    gy = (rng.randn(R, Oo) / R).astype(np.float32)
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+    gw0 = rng.randn(Oo, I).astype(np.float32)            # accGradParameters ADDS to what is there
+    dx, dw, db, dgy = _dev(F, x), _dev(F, w), _dev(F, b), _dev(F, gy)
+    F._lib.call("frcnn_set_option", b"gemm_x_roles", 7)
+    try:
+        y = F.DeviceTensor.empty((R, Oo)); gx = F.DeviceTensor.empty((R, I)); gw = _dev(F, gw0); gb = F.DeviceTensor.zeros((Oo,))
+        F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, F.ptr(dw), F.ptr(db), Oo, F.ptr(y), F.stream_ptr())
+        F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(dgy), R, I, F.ptr(dw), Oo, F.ptr(gx), F.ptr(gw), F.ptr(gb), F.stream_ptr())
+        got = dict(fwd=y.numpy(), dgrad=gx.numpy(), wgrad=gw.numpy())
+    finally:
+        F._lib.call("frcnn_set_option", b"gemm_x_roles", -1)
+    assert_close(got["fwd"], x64 @ w64.T + b, 1e-4, "FC1 forward R=%d tm=%s" % (R, tm))
+    assert_close(got["dgrad"], g64 @ w64, 1e-4, "FC1 input gradient R=%d tm=%s" % (R, tm))
+    assert_close(got["wgrad"], gw0.astype(np.float64) + g64.T @ x64, 1e-4, "FC1 weight gradient R=%d tm=%s" % (R, tm))
+
+
 def test_rmsprop_and_scale(F, O):
     rng = np.random.RandomState(9)
     n = 100003
