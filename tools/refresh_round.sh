@@ -45,6 +45,9 @@ python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
   echo "# sustained v_mfma_f32_32x32x16_bf16 rate (no memory traffic) -- tools/bin/mfma_peak_bf16"
   [ -x tools/bin/mfma_peak_bf16 ] || { mkdir -p tools/bin; hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_bf16.hip -o tools/bin/mfma_peak_bf16 >/dev/null 2>&1; }
   tools/bin/mfma_peak_bf16 2>/dev/null
+  echo "# what an LDS-DMA / register load stream delivers per CU (L2-resident, shared, gathered, HBM) -- tools/bin/lds_dma_probe"
+  [ -x tools/bin/lds_dma_probe ] || hipcc --offload-arch=gfx950 -O3 tools/lds_dma_probe.hip -o tools/bin/lds_dma_probe >/dev/null 2>&1
+  timeout 60 tools/bin/lds_dma_probe 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
   for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_GEMM_X=0" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=1"; do
     echo -n "$e: "; env $e python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
