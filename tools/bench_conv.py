@@ -14,6 +14,10 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, pad)
     "b1c1": (3, 450, 800, 64, 3, 1), "b2c1": (64, 225, 400, 128, 3, 1), "b2c2": (128, 225, 400, 128, 3, 1),
     "b3c1": (128, 113, 200, 256, 3, 1), "b3c2": (256, 113, 200, 256, 3, 1), "b4c1": (256, 57, 100, 384, 3, 1),
     "b4c2": (384, 57, 100, 384, 3, 1), "a1": (256, 57, 100, 256, 3, 0), "a2": (384, 29, 50, 256, 3, 0),
+    # vgg_large 1000x600 (models/vgg_large.lua: 64/128/256/512, 2-2-3-3)
+    "L1c2": (64, 600, 1000, 64, 3, 1), "L2c1": (64, 300, 500, 128, 3, 1), "L2c2": (128, 300, 500, 128, 3, 1),
+    "L3c1": (128, 150, 250, 256, 3, 1), "L3c2": (256, 150, 250, 256, 3, 1), "L4c1": (256, 75, 125, 512, 3, 1),
+    "L4c2": (512, 75, 125, 512, 3, 1),
     "bigk": (2048, 57, 100, 384, 3, 1), "a3": (384, 29, 50, 256, 5, 0), "a4": (384, 29, 50, 256, 7, 0), "a1x": (256, 55, 98, 18, 1, 0),
 }
 
@@ -51,6 +55,6 @@ def run(kind, name, reps=5):
 
 if __name__ == "__main__":
     kind = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
-    names = sys.argv[2:] or list(LAYERS)
+    names = sys.argv[2:] or [n for n in LAYERS if not n.startswith("L")]
     for n in names:
         run(kind, n)
