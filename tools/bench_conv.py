@@ -30,6 +30,8 @@ def run(kind, name, reps=5):
     g = F.DeviceTensor.from_numpy(rng.randn(O, Ho, Wo).astype(np.float32))
     w = F.DeviceTensor.from_numpy((rng.randn(O, Cin, k, k) * 0.05).astype(np.float32))
     gw = F.DeviceTensor.zeros((O, Cin, k, k)); out = F.DeviceTensor.empty((O, Ho, Wo)); gin = F.DeviceTensor.empty((Cin, H, W))
+    act = bool(os.environ.get("WITH_ACT"))   # fused PReLU + dropout scale of the producing layer on the input
+    slope = F.DeviceTensor.from_numpy(np.array([0.25], np.float32)); scale = F.DeviceTensor.from_numpy((rng.rand(Cin) > 0.4).astype(np.float32))
     s = F.stream_ptr()
     nk = len(F._lib.KC_NAMES)
     la = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
@@ -38,7 +40,8 @@ def run(kind, name, reps=5):
         if kind == "wgrad":
             F._lib.call("frcnn_conv2d_backward_weight", F.ptr(x), Cin, H, W, None, None, F.ptr(g), O, k, pad, F.ptr(gw), None, s)
         elif kind == "fwd":
-            F._lib.call("frcnn_conv2d_forward", F.ptr(x), Cin, H, W, None, None, F.ptr(w), None, O, k, pad, F.ptr(out), s)
+            F._lib.call("frcnn_conv2d_forward", F.ptr(x), Cin, H, W, F.ptr(slope) if act else None, F.ptr(scale) if act else None,
+                        F.ptr(w), None, O, k, pad, F.ptr(out), s)
         else:
             F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O, Ho, Wo, F.ptr(w), Cin, k, pad, F.ptr(gin), 0, s)
     once()
