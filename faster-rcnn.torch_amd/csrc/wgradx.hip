@@ -45,16 +45,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WX_TH 4
 #define WX_TW 16
-#define WX_PW 18                 // patch width  (TW + 2)
-#define WX_P 108                 // patch positions (6 x 18)
-#define WX_GP 68                 // LDS pitch (positions) of a gradient channel group: 68*16 B = 272 dwords = 16 mod 64 banks
-#define WX_XP 116                // ... of a patch channel group: 116*16 B = 464 dwords = 16 mod 64 banks
-#define WX_GBYTES (3 * 8 * WX_GP * 16)
-#define WX_XBYTES (3 * 8 * WX_XP * 16)
-#define WX_LDS (WX_GBYTES + WX_XBYTES)
-#ifndef WX_TG
-#define WX_TG 3                  // taps whose MFMAs are interleaved
-#endif
+#define WX_GROW 128                      // bytes of one filter's gradient tile in LDS: [4 rows][16 px] bf16, 16-byte chunks XOR-swizzled
+#define WX_GPLANE (64 * WX_GROW)
+#define WX_XROW 48                       // bytes of one patch row: 24 elements, element e <-> input column ox0 - pad - 3 + e
+#define WX_XCH (6 * WX_XROW)             // bytes of one channel's patch (6 rows)
+#define WX_XPLANE (64 * WX_XCH + 8 * 16)  // (+16 per 8 channels, see wx_xaddr)
+#define WX_LDS (3 * WX_GPLANE + 3 * WX_XPLANE)
 
 bool conv_wgradx_eligible(int Cin, int O, int k) {
   return get_split_bf16() && k == 3 && Cin % 64 == 0 && O % 64 == 0;
@@ -65,10 +61,11 @@ __device__ __forceinline__ unsigned wx_cvt2(float a, float b) {
   bf16x2 r = __builtin_convertvector(v, bf16x2);
   return __builtin_bit_cast(unsigned, r);
 }
-__device__ __forceinline__ void wx_split8(const float* v, uint4& H, uint4& Mi, uint4& L) {
-  unsigned h[4], m[4], l[4];
+// four fp32 values -> their three bf16 planes (h, m, l), 8 bytes each
+__device__ __forceinline__ void wx_split4(const float* v, uint2& H, uint2& Mi, uint2& L) {
+  unsigned h[2], m[2], l[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const float x0 = v[2 * j], x1 = v[2 * j + 1];
     h[j] = wx_cvt2(x0, x1);
     const float r0 = x0 - __builtin_bit_cast(float, h[j] << 16), r1 = x1 - __builtin_bit_cast(float, h[j] & 0xFFFF0000u);
@@ -76,9 +73,7 @@ __device__ __forceinline__ void wx_split8(const float* v, uint4& H, uint4& Mi, u
     const float s0 = r0 - __builtin_bit_cast(float, m[j] << 16), s1 = r1 - __builtin_bit_cast(float, m[j] & 0xFFFF0000u);
     l[j] = wx_cvt2(s0, s1);
   }
-  H = make_uint4(h[0], h[1], h[2], h[3]);
-  Mi = make_uint4(m[0], m[1], m[2], m[3]);
-  L = make_uint4(l[0], l[1], l[2], l[3]);
+  H = make_uint2(h[0], h[1]); Mi = make_uint2(m[0], m[1]); L = make_uint2(l[0], l[1]);
 }
 
 struct WgradXArgs {
@@ -91,18 +86,44 @@ struct WgradXArgs {
   int tilesX, tilesY, oTiles, cTiles, nSplit;
 };
 
-__device__ __forceinline__ bf16x8 wx_frag(const char* p0, const char* p1) {
-  typedef bf16x4 __attribute__((address_space(3))) * lds4;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p0);
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p1);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+// LDS byte offset of channel c's patch inside a plane: the 288-byte pitch is 8 banks (of 4 bytes) mod 64, so the 16-byte
+// reads of 8 consecutive channels cover every second group of 4 banks; each further group of 8 channels starts one
+// 16-byte chunk later and fills the gaps of the one before
+__device__ __forceinline__ unsigned wx_xaddr(int c) { return (unsigned)(c * WX_XCH + (c >> 3) * 16); }
+// chunk swizzle of filter row o: a bijection of (o >> 1) & 7 whose upper two bits differ between neighbours (conflict-free
+// 16-byte fragment reads of 16 consecutive filters AND conflict-free 8-byte staging writes of 8 filters x 4 segments)
+__device__ __forceinline__ unsigned wx_gswz(int o) { const unsigned u = (o >> 1) & 7; return ((u & 3) << 1) | (u >> 2); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Pins a value at this point of the instruction stream: an empty volatile asm that "modifies" it.  sched_barrier fences the
+// machine scheduler, but instruction selection is free to sink side-effect-free arithmetic down to its first use -- without
+// the pins the split arithmetic of a tile gathers behind the last MFMA of its row instead of riding between the MFMAs.
+#define WX_PIN(x) asm volatile("" : "+v"(x))
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 
-template <bool SLOPE, bool SCALE>
+// VEC: every 4-pixel segment is one aligned 16-byte load (pad = 1, W % 4 = 0, 16-byte aligned tensors); otherwise four
+// predicated dword loads per segment (any shape)
+//
+// One block per CU, one wave per SIMD, and ONE basic block per tile in which everything overlaps (the order is laid down
+// with sched_group_barrier, the compiler on its own puts every LDS read right in front of its first use and every
+// conversion behind the last product):
+//   tile i, patch row r = 0..5:  fragment reads of row r + 1  |  the 18 / 36 / 54 MFMAs of row r, and between them
+//                                * the v_perm / v_mov that cut the three column taps of row r + 1 out of the 16 elements read,
+//                                * rows 1..3: the split of tile i + 1 (in registers since tile i - 1) and its LDS writes into
+//                                  the OTHER LDS image,
+//   after row 4: one barrier, the global loads of tile i + 2, and row 0 of tile i + 1 is read under the MFMAs of row 5.
+template <bool SLOPE, bool SCALE, bool VEC>
 __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Gs = smem;                // [plane][og][WX_GP][8]
-  char* const Xs = smem + WX_GBYTES;    // [plane][cg][WX_XP][8]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two images of WX_LDS bytes: [G planes][X planes]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave >> 1, wc = wave & 1;
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 
   // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (own L2 each); the virtual index gives every XCD a
   // contiguous range, in which the (o tile, c tile) blocks of one pixel split follow each other -- they walk the same
-  // pixel tiles at the same time and now share them through ONE L2 instead of fetching them once per XCD
+  // pixel tiles at the same time and share them through ONE L2 instead of fetching them once per XCD
   int bid;
   {
     const int nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -122,7 +143,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   const int split = bid / p.cTiles;
   const int o0 = ot * 64, c0 = ct * 64;
   const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
-  const size_t g_bytes = (size_t)HoWo * 4, in_bytes = (size_t)HW * 4;
   const float slope = SLOPE ? *p.in_slope : 1.f;
 
   f32x16 acc[9];
@@ -131,141 +151,225 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // ---- staging geometry: wave w stages gradient groups w, w+4 (pixel = lane) and patch groups 2w, 2w+1 (positions lane,
-  // 64 + lane) -- the channel group of every item is wave-uniform, so its 8 loads are scalar base + lane offset
-  const int g_ty = lane >> 4, g_tx = lane & 15;
-  int p_r[2], p_c[2];
-  bool p_in[2];
+  // ---- staging roles: thread = (row of the operand: filter / channel tid >> 2, quarter tid & 3).  Gradient: the quarter is
+  // the 4-pixel segment, items k = tile rows 0..3.  Patch: the 36 segments of a channel (6 rows x 6 segments of 4 columns)
+  // are dealt j = quarter + 4 k, k = 0..8: the LDS offset of segment j is simply 8 j.
+  const int srow = tid >> 2, sq = tid & 3;
+  const float* const gsrc = p.g + (size_t)(o0 + srow) * HoWo;
+  const float* const xsrc = p.in + (size_t)(c0 + srow) * HW;
+  const float xscale = SCALE ? p.in_scale[c0 + srow] : 1.f;
+  const unsigned gdst = (unsigned)(srow * WX_GROW) + ((((unsigned)sq >> 1) ^ wx_gswz(srow)) << 4) + (sq & 1) * 8;   // ^ (k << 5) per row
+  const unsigned xdst = 3 * WX_GPLANE + wx_xaddr(srow) + sq * 8;                                                  // + 32 k per item
+  int xr[9], xs[9];   // patch row / segment of item k
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int e = lane + 64 * m;
-    p_r[m] = e / WX_PW; p_c[m] = e - p_r[m] * WX_PW;
-    p_in[m] = e < WX_P;
+  for (int k = 0; k < 9; ++k) {
+    const int j = sq + 4 * k;
+    xr[k] = j / 6; xs[k] = j - 6 * xr[k];
   }
 
-  // ---- fragment addressing (transpose reads): this lane SUPPLIES pixel row js, channels 4*qs.. of its 16-lane group
-  const int js = (lane & 15) >> 2, qs = lane & 3, g16 = (lane >> 4) & 1;
-  const int ol = wo * 32 + 16 * g16 + 4 * qs, cl = wc * 32 + 16 * g16 + 4 * qs;
-  const char* const laneA = Gs + ((ol >> 3) * WX_GP + 8 * h + js) * 16 + (ol & 7) * 2;
-  const char* const laneB = Xs + ((cl >> 3) * WX_XP + 8 * h + js) * 16 + (cl & 7) * 2;
+  // ---- fragment addressing
+  const int oA = wo * 32 + li, cB = wc * 32 + li;
+  const unsigned abase = (unsigned)(oA * WX_GROW) + (((unsigned)h ^ wx_gswz(oA)) << 4);   // ^ (ks << 5)
+  const unsigned bbase = 3 * WX_GPLANE + wx_xaddr(cB) + h * 16;                           // + 48 r (+ 16)
 
+  // ---- the tiles of this block: t_i = split + i nSplit
   const int nPix = p.tilesX * p.tilesY;
-  // ---- every global load of a tile is issued in one go (one memory round trip, 48 values in flight per thread: gradient
-  // tile 2 items per thread, input patch 4 = 2 channel groups x 2 position slots) -- for the NEXT tile, right before the
-  // products of the current one, so that the round trip runs under 216 MFMAs instead of in front of them; the splits and
-  // LDS writes follow when the products are done.
-  float vg[2][8], vp[2][2][8];
-  bool pok[2], gok = false;
-  auto load_tile = [&](int t) {
-    const int oy0 = (t / p.tilesX) * WX_TH, ox0 = (t % p.tilesX) * WX_TW;
-    const int goy = oy0 + g_ty, gox = ox0 + g_tx;
-    gok = goy < p.Ho && gox < p.Wo;
-    const unsigned gofs = gok ? (unsigned)(goy * p.Wo + gox) * 4u : 0u;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const char* gb = reinterpret_cast<const char*>(p.g) + (size_t)(o0 + 8 * (wave + 4 * it)) * g_bytes;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vg[it][j] = *reinterpret_cast<const float*>(gb + j * g_bytes + gofs);
-    }
-    unsigned pofs[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int iy = oy0 - p.pad + p_r[m], ix = ox0 - p.pad + p_c[m];
-      pok[m] = p_in[m] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      pofs[m] = pok[m] ? (unsigned)(iy * p.W + ix) * 4u : 0u;
-    }
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      const char* ib = reinterpret_cast<const char*>(p.in) + (size_t)(c0 + 8 * (2 * wave + gi)) * in_bytes;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vp[gi][m][j] = *reinterpret_cast<const float*>(ib + j * in_bytes + pofs[m]);
-    }
+  const int nT = (nPix - split + p.nSplit - 1) / p.nSplit;
+  float vg[4][4], vx[9][4];
+  int l_oy0 = 0, l_ox0 = 0;   // origin of the tile the registers hold
+  // ---- the work that rides under the MFMAs, cut into MICRO-STEPS of about five VALU instructions.  Steps of item `it`
+  // (0..3 gradient rows, 4..12 patch segments): load (one 16-byte segment, branch-free: a segment outside the image reads the
+  // tensor's first elements and is zeroed later) | prepare (zero / activation) | split pair 0: level 1, levels 2 + 3 | split
+  // pair 1: level 1, levels 2 + 3 | three 8-byte LDS writes.
+  float sx[13][4], sr[13][4];
+  unsigned sh[13][2], sm[13][2], sl[13][2];
+  auto up_lo = [](unsigned v) { return __builtin_bit_cast(float, v << 16); };
+  auto up_hi = [](unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); };
+  auto load_origin = [&](int i) {
+    const int t = split + min(i, nT - 1) * p.nSplit;
+    l_oy0 = (t / p.tilesX) * WX_TH; l_ox0 = (t % p.tilesX) * WX_TW;
   };
-  auto stage_tile = [&]() {
+  auto load_step = [&](auto itc) {
+    constexpr int it = decltype(itc)::value;
+    const int oy0 = l_oy0, ox0 = l_ox0;
+    if constexpr (it < 4) {
+      constexpr int k = it;
+      const int oy = oy0 + k, ox = ox0 + 4 * sq;
+      if (VEC) {
+        const int ok = -(int)(oy < p.Ho && ox < p.Wo);
+        const float4 v = *reinterpret_cast<const float4*>(gsrc + ((oy * p.Wo + ox) & ok));
+        vg[k][0] = v.x; vg[k][1] = v.y; vg[k][2] = v.z; vg[k][3] = v.w;
+      } else {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = gok ? vg[it][j] : 0.f;
-      uint4 Hh, Mi, L;
-      wx_split8(x, Hh, Mi, L);
-      char* d = Gs + ((wave + 4 * it) * WX_GP + lane) * 16;
-      *reinterpret_cast<uint4*>(d) = Hh;
-      *reinterpret_cast<uint4*>(d + 8 * WX_GP * 16) = Mi;
-      *reinterpret_cast<uint4*>(d + 16 * WX_GP * 16) = L;
-    }
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      const int cg = 2 * wave + gi;
-      float sc[8];
-      if (SCALE) {
-        const float4* sp = reinterpret_cast<const float4*>(p.in_scale + c0 + 8 * cg);
-        const float4 s0 = sp[0], s1 = sp[1];
-        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = vp[gi][m][j];
-          if (SLOPE) v = v > 0.f ? v : slope * v;
-          if (SCALE) v *= sc[j];
-          x[j] = pok[m] ? v : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const int ok = -(int)(oy < p.Ho && ox + e < p.Wo);
+          vg[k][e] = gsrc[(oy * p.Wo + ox + e) & ok];
         }
-        uint4 Hh, Mi, L;
-        wx_split8(x, Hh, Mi, L);
-        if (p_in[m]) {
-          char* d = Xs + (cg * WX_XP + lane + 64 * m) * 16;
-          *reinterpret_cast<uint4*>(d) = Hh;
-          *reinterpret_cast<uint4*>(d + 8 * WX_XP * 16) = Mi;
-          *reinterpret_cast<uint4*>(d + 16 * WX_XP * 16) = L;
+      }
+    } else {
+      constexpr int k = it - 4;
+      const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
+      if (VEC) {
+        const int ok = -(int)((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
+        const float4 v = *reinterpret_cast<const float4*>(xsrc + ((iy * p.W + ix) & ok));
+        vx[k][0] = v.x; vx[k][1] = v.y; vx[k][2] = v.z; vx[k][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ok = -(int)((unsigned)iy < (unsigned)p.H && (unsigned)(ix + e) < (unsigned)p.W);
+          vx[k][e] = xsrc[(iy * p.W + ix + e) & ok];
         }
       }
     }
   };
-  if (split < nPix) load_tile(split);
-  for (int t = split; t < nPix; t += p.nSplit) {
-    stage_tile();
-    __syncthreads();
-    if (t + p.nSplit < nPix) load_tile(t + p.nSplit);
-    // ---- K = the tile's 64 pixels: K-step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it.  The loop
-    // runs over PATCH rows: the fragments of patch row r (three kx shifts x three planes) serve every (ks, ky) with
-    // ks + ky = r, so each is read from LDS once instead of up to three times -- 132 transposed reads per tile instead of
-    // 240.  (ds_read_b64_tr_b16 moves 64 B/clk: at 240 reads the LDS pipe was busier than the matrix pipe.)  The gradient
-    // fragments of the up to three K steps that meet a row stay in registers (a sliding window).
-    bf16x8 a[WX_TH][3];
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest partial products first; plane 0 = h, 1 = m, 2 = l
+  // ph 0 (and 1 for patch items): prepare; then 4 split phases; last: LDS writes.  Gradient items: 6 phases, patch items: 7.
+  auto stage_step = [&](auto itc, auto phc, unsigned wb) {
+    constexpr int it = decltype(itc)::value, ph0 = decltype(phc)::value;
+    constexpr int ph = it < 4 ? ph0 + 1 : ph0;   // common numbering: 0, 1 prepare | 2..5 split | 6 write
+    const int oy0 = l_oy0, ox0 = l_ox0;
+    if constexpr (ph == 1 && it < 4) {
+      const int oy = oy0 + it, ox = ox0 + 4 * sq;
 #pragma unroll
-    for (int r = 0; r < WX_TH + 2; ++r) {
-      if (r < WX_TH) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[r][pl] = wx_frag(laneA + (pl * 8 * WX_GP + 16 * r) * 16, laneA + (pl * 8 * WX_GP + 16 * r + 4) * 16);
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = oy < p.Ho && (VEC ? ox : ox + e) < p.Wo;
+        sx[it][e] = ok ? vg[it][e] : 0.f;
+        WX_PIN(sx[it][e]);
       }
-      bf16x8 b[3][3];
+    } else if constexpr (ph == 0 || ph == 1) {
+      constexpr int k = it - 4;
+      const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
+#pragma unroll
+      for (int e = 2 * ph; e < 2 * ph + 2; ++e) {
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)(VEC ? ix : ix + e) < (unsigned)p.W;
+        float v = vx[k][e];
+        if (SLOPE) v = v > 0.f ? v : slope * v;
+        if (SCALE) v *= xscale;
+        sx[it][e] = ok ? v : 0.f;
+        WX_PIN(sx[it][e]);
+      }
+    } else if constexpr (ph == 2 || ph == 4) {
+      constexpr int j = (ph - 2) / 2;
+      sh[it][j] = wx_cvt2(sx[it][2 * j], sx[it][2 * j + 1]);
+      sr[it][2 * j] = sx[it][2 * j] - up_lo(sh[it][j]);
+      sr[it][2 * j + 1] = sx[it][2 * j + 1] - up_hi(sh[it][j]);
+      WX_PIN(sh[it][j]); WX_PIN(sr[it][2 * j]); WX_PIN(sr[it][2 * j + 1]);
+    } else if constexpr (ph == 3 || ph == 5) {
+      constexpr int j = (ph - 3) / 2;
+      sm[it][j] = wx_cvt2(sr[it][2 * j], sr[it][2 * j + 1]);
+      const float s0 = sr[it][2 * j] - up_lo(sm[it][j]), s1 = sr[it][2 * j + 1] - up_hi(sm[it][j]);
+      sl[it][j] = wx_cvt2(s0, s1);
+      WX_PIN(sm[it][j]); WX_PIN(sl[it][j]);
+    } else {
+      char* d = it < 4 ? smem + wb + (gdst ^ ((unsigned)it << 5)) : smem + wb + xdst + 32 * (it - 4);
+      constexpr int PL = it < 4 ? WX_GPLANE : WX_XPLANE;
+      *reinterpret_cast<uint2*>(d) = make_uint2(sh[it][0], sh[it][1]);
+      *reinterpret_cast<uint2*>(d + PL) = make_uint2(sm[it][0], sm[it][1]);
+      *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(sl[it][0], sl[it][1]);
+      asm volatile("" ::: "memory");
+    }
+  };
+
+  // ---- K = the tile's 64 pixels: K step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it.  The products
+  // walk the PATCH rows: the 16 elements a lane reads of patch row r (two 16-byte reads per plane) hold its 8 pixels at all
+  // three column taps -- tap kx starts at element 3 + kx: kx = 1 is registers 2..5 as they are, kx = 0 / 2 are v_perm of
+  // neighbouring registers -- and serve every (ks, ky) with ks + ky = r.  The gradient fragments stay in registers.
+  bf16x8 a[WX_TH][3];
+  u32x4 b[3][3], bn[3][3];   // [kx][plane] of the row being multiplied / of the next one
+  u32x4 raw[3][2];
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest partial products first; plane 0 = h, 1 = m, 2 = l
+  auto read_row = [&](unsigned rb, int r) {
+    if (r < WX_TH) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[r][pl] = *reinterpret_cast<const bf16x8*>(smem + rb + pl * WX_GPLANE + (abase ^ ((unsigned)r << 5)));
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      raw[pl][0] = *reinterpret_cast<const u32x4*>(smem + rb + bbase + pl * WX_XPLANE + r * WX_XROW);
+      raw[pl][1] = *reinterpret_cast<const u32x4*>(smem + rb + bbase + pl * WX_XPLANE + r * WX_XROW + 16);
+    }
+  };
+  // step 2 pl + half: elements 2 half, 2 half + 1 of the three tap fragments of plane pl
+  auto cut_step = [&](auto sc) {
+    constexpr int pl = decltype(sc)::value >> 1, hf = decltype(sc)::value & 1;
+    const u32x4 d0 = raw[pl][0], d1 = raw[pl][1];
+    const unsigned d[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+    for (int j = 2 * hf; j < 2 * hf + 2; ++j) {
+      bn[0][pl][j] = __builtin_amdgcn_alignbit(d[j + 2], d[j + 1], 16);
+      bn[1][pl][j] = d[j + 2];
+      bn[2][pl][j] = __builtin_amdgcn_alignbit(d[j + 3], d[j + 2], 16);
+      WX_PIN(bn[0][pl][j]); WX_PIN(bn[1][pl][j]); WX_PIN(bn[2][pl][j]);
+    }
+  };
+
+  // ---- prologue: tile 0 into image 0, tile 1 into the registers, row 0 of tile 0 into fragments
+  load_origin(0);
+  static_for<13>([&](auto itc) { load_step(itc); });
+  static_for<13>([&](auto itc) { static_for<(decltype(itc)::value < 4 ? 6 : 7)>([&](auto phc) { stage_step(itc, phc, 0u); }); });
+  __syncthreads();
+  load_origin(1);
+  static_for<13>([&](auto itc) { load_step(itc); });
+  read_row(0, 0);
+  static_for<6>([&](auto sc) { cut_step(sc); });
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[kx][pl] = bn[kx][pl];
+
+  for (int i = 0; i < nT; ++i) {
+    const unsigned rb = (i & 1) ? WX_LDS : 0, wb = WX_LDS - rb;
+    int n_oy0 = 0, n_ox0 = 0;
+    auto row = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      constexpr int nky = r < 3 ? r + 1 : 6 - r;            // (ks, ky) pairs of this row: 1 2 3 3 2 1
+      constexpr int NM = 18 * nky;
+      // side work of the row: staging steps (rows 1..3), load steps (row 4), then the six tap-cut steps of the next row
+      constexpr int NSTG = r == 1 ? 4 * 6 + 7 : (r == 2 || r == 3) ? 4 * 7 : r == 4 ? 13 : 0;
+      constexpr int NS = NSTG + 6;
+      __builtin_amdgcn_sched_barrier(0);
+      if (r == 4) {   // origin of tile i + 2 (scalar): its loads are this row's side work
+        const int t = split + min(i + 2, nT - 1) * p.nSplit;
+        n_oy0 = (t / p.tilesX) * WX_TH; n_ox0 = (t % p.tilesX) * WX_TW;
+      }
+      if (r < 5) read_row(rb, r + 1); else read_row(wb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        // the (ks, ky) pairs of this row, their 3 kx taps and 6 partial products interleaved: consecutive MFMAs write
+        // different accumulators (a chain on ONE accumulator issues at its dependent latency, not at the pipe rate)
+        constexpr int q = m / (3 * nky), kyi = (m / 3) % nky, kx = m % 3;
+        constexpr int ky = (r < WX_TH ? 0 : r - (WX_TH - 1)) + kyi, ks = r - ky;
+        static_assert(ks >= 0 && ks < WX_TH && ky < 3, "tap walk");
+        acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][PA[q]], __builtin_bit_cast(bf16x8, b[kx][PB[q]]), acc[3 * ky + kx], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // rows 0 and 5 (side work = the tap cuts only) leave the first MFMAs to cover the latency of the reads above
+        constexpr int LEAD = NSTG == 0 ? 6 : 0;
+        constexpr int s0 = m < LEAD ? 0 : (m - LEAD) * NS / (NM - LEAD), s1 = m < LEAD ? 0 : (m - LEAD + 1) * NS / (NM - LEAD);
+        static_for<s1 - s0>([&](auto dc) {
+          constexpr int s = s0 + decltype(dc)::value;
+          if constexpr (s >= NSTG) {
+            cut_step(std::integral_constant<int, s - NSTG>{});
+          } else if constexpr (r == 1) {
+            constexpr int it = s < 24 ? s / 6 : 4, ph = s < 24 ? s % 6 : s - 24;
+            stage_step(std::integral_constant<int, it>{}, std::integral_constant<int, ph>{}, wb);
+          } else if constexpr (r == 2 || r == 3) {
+            stage_step(std::integral_constant<int, (r == 2 ? 5 : 9) + s / 7>{}, std::integral_constant<int, s % 7>{}, wb);
+          } else {
+            if constexpr (s == 0) { l_oy0 = n_oy0; l_ox0 = n_ox0; }
+            load_step(std::integral_constant<int, s>{});
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[kx][pl] = wx_frag(laneB + (pl * 8 * WX_XP + r * WX_PW + kx) * 16, laneB + (pl * 8 * WX_XP + r * WX_PW + kx + 4) * 16);
-      // the (ks, ky) pairs of this row, their 3 kx taps and 6 partial products interleaved: consecutive MFMAs write
-      // different accumulators (a chain on ONE accumulator issues at its dependent latency, not at the pipe rate)
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int ks = r - ky;
-          if (ks >= 0 && ks < WX_TH) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-              acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][PA[q]], b[kx][PB[q]], acc[3 * ky + kx], 0, 0, 0);
-          }
-        }
-    }
-    __syncthreads();
+        for (int pl = 0; pl < 3; ++pl) b[kx][pl] = bn[kx][pl];
+      if (r == 4) __syncthreads();   // image `wb` is complete, image `rb` has been read for the last time
+    };
+    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
+    row(std::integral_constant<int, 3>{}); row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
   }
   // ---- epilogue: D col = lane&31 -> c (contiguous in the slab), row -> o
   {
@@ -297,23 +401,30 @@ size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad) {
   return (size_t)a.nSplit * 9 * O * Cin * 4 + 256;
 }
 
-template <bool SLOPE, bool SCALE>
-static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
+template <bool SLOPE, bool SCALE, bool VEC>
+static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradx_kernel<SLOPE, SCALE>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradx_kernel<SLOPE, SCALE, VEC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int grid = a.oTiles * a.cTiles * a.nSplit;
   const double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
   if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
-  const size_t lds = std::max<size_t>(WX_LDS, 84 * 1024);   // (> 80 KB: one block per CU, whatever the register count)
-  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE>), dim3(grid), dim3(256), lds, s, a);
+  const size_t lds = 2 * WX_LDS;   // two images (> 80 KB: one block per CU)
+  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE, VEC>), dim3(grid), dim3(256), lds, s, a);
   FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
   if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+template <bool SLOPE, bool SCALE>
+static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
+  // one aligned 16-byte load per 4-pixel segment when every segment lies inside a row or outside the image as a whole
+  const bool vec = a.pad == 1 && a.W % 4 == 0 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.g & 15) == 0;
+  return vec ? launch_wgradx_v<SLOPE, SCALE, true>(a, flops, gw, s) : launch_wgradx_v<SLOPE, SCALE, false>(a, flops, gw, s);
 }
 
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,

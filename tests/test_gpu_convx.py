@@ -179,7 +179,7 @@ def test_exactness_properties_at_full_size(F):
 @pytest.mark.parametrize("C_,H,W,O_,pad", [(64, 57, 100, 128, 1), (128, 29, 50, 64, 1), (256, 38, 63, 512, 1), (64, 9, 11, 64, 1),
                                             (64, 31, 45, 64, 0)])
 def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
-    """accGradParameters (csrc/wgradx.hip): both operands split while they are staged, fragments by transpose reads."""
+    """accGradParameters (csrc/wgradx.hip): both operands split while they are staged into pixel-contiguous planes."""
     rng = np.random.RandomState(C_ * 13 + O_)
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     x = rng.randn(C_, H, W).astype(np.float32)
@@ -202,9 +202,10 @@ def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
     assert _rms(split, gw_want) <= 2.0 * _rms(direct, gw_want) + 1e-9
 
 
-def test_weight_gradient_with_fused_activation(F, O):
+@pytest.mark.parametrize("W", [34, 36, 48])   # 36 / 48: the 16-byte-segment loader (W % 4 = 0), 34: the per-element one
+def test_weight_gradient_with_fused_activation(F, O, W):
     rng = np.random.RandomState(2)
-    C_, H, W, O_, pad = 64, 21, 34, 64, 1
+    C_, H, O_, pad = 64, 21, 64, 1
     x = rng.randn(C_, H, W).astype(np.float32)
     g = (rng.randn(O_, H, W) * 0.05).astype(np.float32)
     a = np.float32(0.25)
