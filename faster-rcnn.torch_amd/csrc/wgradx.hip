@@ -155,8 +155,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // the 4-pixel segment, items k = tile rows 0..3.  Patch: the 36 segments of a channel (6 rows x 6 segments of 4 columns)
   // are dealt j = quarter + 4 k, k = 0..8: the LDS offset of segment j is simply 8 j.
   const int srow = tid >> 2, sq = tid & 3;
+  // per-thread 64-bit row bases + signed element offsets.  (The scalar-base form -- uniform tensor base + 32-bit byte offset per
+  // lane -- costs this kernel 7 %: measured, b2c2 148 against 141 us.)
   const float* const gsrc = p.g + (size_t)(o0 + srow) * HoWo;
   const float* const xsrc = p.in + (size_t)(c0 + srow) * HW;
+  auto gat = [&](int elem_off) { return gsrc + elem_off; };
+  auto xat = [&](int elem_off) { return xsrc + elem_off; };
   const float xscale = SCALE ? p.in_scale[c0 + srow] : 1.f;
   const unsigned gdst = (unsigned)(srow * WX_GROW) + ((((unsigned)sq >> 1) ^ wx_gswz(srow)) << 4) + (sq & 1) * 8;   // ^ (k << 5) per row
   const unsigned xdst = 3 * WX_GPLANE + wx_xaddr(srow) + sq * 8;                                                  // + 32 k per item
@@ -181,14 +185,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // (0..3 gradient rows, 4..12 patch segments): load (one 16-byte segment, branch-free: a segment outside the image reads the
   // tensor's first elements and is zeroed later) | prepare (zero / activation) | split pair 0: level 1, levels 2 + 3 | split
   // pair 1: level 1, levels 2 + 3 | three 8-byte LDS writes.
-  float sx[13][4], sr[13][4];
+  float sr[13][4];
   unsigned sh[13][2], sm[13][2], sl[13][2];
   auto up_lo = [](unsigned v) { return __builtin_bit_cast(float, v << 16); };
   auto up_hi = [](unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); };
-  auto load_origin = [&](int i) {
-    const int t = split + min(i, nT - 1) * p.nSplit;
-    l_oy0 = (t / p.tilesX) * WX_TH; l_ox0 = (t % p.tilesX) * WX_TW;
+  // tile walk of the block: t_i = split + i nSplit as (row, column) of the tile grid, advanced without a division; past the
+  // block's last tile the walk stays on it (its loads and its staging are harmless repeats nobody reads)
+  const int adv_y = p.nSplit / p.tilesX, adv_x = p.nSplit % p.tilesX;
+  int w_ty = split / p.tilesX, w_tx = split % p.tilesX, w_i = 0;   // the tile the NEXT load_origin() call selects
+  auto load_origin = [&]() {
+    l_oy0 = w_ty * WX_TH; l_ox0 = w_tx * WX_TW;
+    const int more = w_i + 1 < nT ? 1 : 0;   // (selects, not branches: the tile loop body stays one basic block)
+    w_tx += more * adv_x; w_ty += more * adv_y;
+    const int wrap = w_tx >= p.tilesX ? 1 : 0;
+    w_tx -= wrap * p.tilesX; w_ty += wrap;
+    ++w_i;
   };
+  // branch-free: a segment outside the image reads the tensor's first elements; the VEC form remembers one predicate per
+  // segment (a lane mask in scalar registers) for the moment the values are split, the per-element form recomputes them
+  bool okit[13];
   auto load_step = [&](auto itc) {
     constexpr int it = decltype(itc)::value;
     const int oy0 = l_oy0, ox0 = l_ox0;
@@ -196,77 +211,85 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
       constexpr int k = it;
       const int oy = oy0 + k, ox = ox0 + 4 * sq;
       if (VEC) {
-        const int ok = -(int)(oy < p.Ho && ox < p.Wo);
-        const float4 v = *reinterpret_cast<const float4*>(gsrc + ((oy * p.Wo + ox) & ok));
+        okit[it] = oy < p.Ho && ox < p.Wo;
+        const float4 v = *reinterpret_cast<const float4*>(gat((oy * p.Wo + ox) & -(int)okit[it]));
         vg[k][0] = v.x; vg[k][1] = v.y; vg[k][2] = v.z; vg[k][3] = v.w;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ok = -(int)(oy < p.Ho && ox + e < p.Wo);
-          vg[k][e] = gsrc[(oy * p.Wo + ox + e) & ok];
-        }
+        for (int e = 0; e < 4; ++e) vg[k][e] = *gat((oy * p.Wo + ox + e) & -(int)(oy < p.Ho && ox + e < p.Wo));
       }
     } else {
       constexpr int k = it - 4;
       const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
       if (VEC) {
-        const int ok = -(int)((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
-        const float4 v = *reinterpret_cast<const float4*>(xsrc + ((iy * p.W + ix) & ok));
+        okit[it] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float4 v = *reinterpret_cast<const float4*>(xat((iy * p.W + ix) & -(int)okit[it]));
         vx[k][0] = v.x; vx[k][1] = v.y; vx[k][2] = v.z; vx[k][3] = v.w;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ok = -(int)((unsigned)iy < (unsigned)p.H && (unsigned)(ix + e) < (unsigned)p.W);
-          vx[k][e] = xsrc[(iy * p.W + ix + e) & ok];
-        }
+        for (int e = 0; e < 4; ++e)
+          vx[k][e] = *xat((iy * p.W + ix + e) & -(int)((unsigned)iy < (unsigned)p.H && (unsigned)(ix + e) < (unsigned)p.W));
       }
     }
   };
-  // ph 0 (and 1 for patch items): prepare; then 4 split phases; last: LDS writes.  Gradient items: 6 phases, patch items: 7.
-  auto stage_step = [&](auto itc, auto phc, unsigned wb) {
-    constexpr int it = decltype(itc)::value, ph0 = decltype(phc)::value;
-    constexpr int ph = it < 4 ? ph0 + 1 : ph0;   // common numbering: 0, 1 prepare | 2..5 split | 6 write
-    const int oy0 = l_oy0, ox0 = l_ox0;
-    if constexpr (ph == 1 && it < 4) {
-      const int oy = oy0 + it, ox = ox0 + 4 * sq;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool ok = oy < p.Ho && (VEC ? ox : ox + e) < p.Wo;
-        sx[it][e] = ok ? vg[it][e] : 0.f;
-        WX_PIN(sx[it][e]);
-      }
-    } else if constexpr (ph == 0 || ph == 1) {
+  // is element e of item `it` (as held in the registers) inside the image?
+  auto inside = [&](auto itc, int e) -> bool {
+    constexpr int it = decltype(itc)::value;
+    if (VEC) return okit[it];
+    if constexpr (it < 4) return l_oy0 + it < p.Ho && l_ox0 + 4 * sq + e < p.Wo;
+    else return (unsigned)(l_oy0 - p.pad + xr[it < 4 ? 0 : it - 4]) < (unsigned)p.H &&
+                (unsigned)(l_ox0 - p.pad - 3 + 4 * xs[it < 4 ? 0 : it - 4] + e) < (unsigned)p.W;
+  };
+  // phases of an item, common numbering: 0..3 activation of a patch segment (one value each) | 4..7 split | 8 LDS writes.
+  // Gradient items start at phase 4 (5 phases), patch items at 0 when there is an activation to apply (9), else at 4 (5).
+  constexpr int XPH0 = (SLOPE || SCALE) ? 0 : 4;
+  auto stage_step = [&](auto itc, auto phc, unsigned gwb, unsigned xwb) {
+    constexpr int it = decltype(itc)::value, ph = decltype(phc)::value;
+    if constexpr (ph < 4) {
       constexpr int k = it - 4;
-      const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
-#pragma unroll
-      for (int e = 2 * ph; e < 2 * ph + 2; ++e) {
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)(VEC ? ix : ix + e) < (unsigned)p.W;
+      {
+        constexpr int e = ph;
         float v = vx[k][e];
         if (SLOPE) v = v > 0.f ? v : slope * v;
         if (SCALE) v *= xscale;
-        sx[it][e] = ok ? v : 0.f;
-        WX_PIN(sx[it][e]);
+        vx[k][e] = inside(itc, e) ? v : 0.f;
+        WX_PIN(vx[k][e]);
       }
-    } else if constexpr (ph == 2 || ph == 4) {
-      constexpr int j = (ph - 2) / 2;
-      sh[it][j] = wx_cvt2(sx[it][2 * j], sx[it][2 * j + 1]);
-      sr[it][2 * j] = sx[it][2 * j] - up_lo(sh[it][j]);
-      sr[it][2 * j + 1] = sx[it][2 * j + 1] - up_hi(sh[it][j]);
+    } else if constexpr (ph == 4 || ph == 6) {
+      constexpr int j = (ph - 4) / 2;
+      float x0 = it < 4 ? vg[it < 4 ? it : 0][2 * j] : vx[it < 4 ? 0 : it - 4][2 * j];
+      float x1 = it < 4 ? vg[it < 4 ? it : 0][2 * j + 1] : vx[it < 4 ? 0 : it - 4][2 * j + 1];
+      if (it < 4 || XPH0 == 4) {   // (patch segments with an activation were zeroed when it was applied)
+        x0 = inside(itc, 2 * j) ? x0 : 0.f;
+        x1 = inside(itc, 2 * j + 1) ? x1 : 0.f;
+      }
+      sh[it][j] = wx_cvt2(x0, x1);
+      sr[it][2 * j] = x0 - up_lo(sh[it][j]);
+      sr[it][2 * j + 1] = x1 - up_hi(sh[it][j]);
       WX_PIN(sh[it][j]); WX_PIN(sr[it][2 * j]); WX_PIN(sr[it][2 * j + 1]);
-    } else if constexpr (ph == 3 || ph == 5) {
-      constexpr int j = (ph - 3) / 2;
+    } else if constexpr (ph == 5 || ph == 7) {
+      constexpr int j = (ph - 5) / 2;
       sm[it][j] = wx_cvt2(sr[it][2 * j], sr[it][2 * j + 1]);
       const float s0 = sr[it][2 * j] - up_lo(sm[it][j]), s1 = sr[it][2 * j + 1] - up_hi(sm[it][j]);
       sl[it][j] = wx_cvt2(s0, s1);
       WX_PIN(sm[it][j]); WX_PIN(sl[it][j]);
     } else {
-      char* d = it < 4 ? smem + wb + (gdst ^ ((unsigned)it << 5)) : smem + wb + xdst + 32 * (it - 4);
+      char* d = it < 4 ? smem + (gwb ^ ((unsigned)it << 5)) : smem + xwb + 32 * (it - 4);
       constexpr int PL = it < 4 ? WX_GPLANE : WX_XPLANE;
       *reinterpret_cast<uint2*>(d) = make_uint2(sh[it][0], sh[it][1]);
       *reinterpret_cast<uint2*>(d + PL) = make_uint2(sm[it][0], sm[it][1]);
       *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(sl[it][0], sl[it][1]);
       asm volatile("" ::: "memory");
     }
+  };
+  // step s of the staging sequence of items [I0, I1): item-major, each item's phases in order
+  auto stage_seq = [&](auto i0c, auto sc, unsigned gwb, unsigned xwb) {
+    constexpr int I0 = decltype(i0c)::value, s = decltype(sc)::value;
+    constexpr int NG = I0 < 4 ? 4 - I0 : 0;                     // gradient items at the head of the range (5 phases each)
+    constexpr int NPX = 9 - XPH0;                               // phases of a patch item
+    constexpr int it = s < 5 * NG ? I0 + s / 5 : I0 + NG + (s - 5 * NG) / NPX;
+    constexpr int ph = s < 5 * NG ? 4 + s % 5 : XPH0 + (s - 5 * NG) % NPX;
+    stage_step(std::integral_constant<int, it>{}, std::integral_constant<int, ph>{}, gwb, xwb);
   };
 
   // ---- K = the tile's 64 pixels: K step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it.  The products
@@ -294,6 +317,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
     constexpr int pl = decltype(sc)::value >> 1, hf = decltype(sc)::value & 1;
     const u32x4 d0 = raw[pl][0], d1 = raw[pl][1];
     const unsigned d[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+    // elements 0 and 7 are never used: keep their registers occupied until here all the same -- handed out early they become
+    // scratch of the staging arithmetic while the read is still in flight, and that write has to wait for the whole LDS queue
+    if (hf == 1) asm volatile("" ::"v"(d[0]), "v"(d[7]));
 #pragma unroll
     for (int j = 2 * hf; j < 2 * hf + 2; ++j) {
       bn[0][pl][j] = __builtin_amdgcn_alignbit(d[j + 2], d[j + 1], 16);
@@ -304,11 +330,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   };
 
   // ---- prologue: tile 0 into image 0, tile 1 into the registers, row 0 of tile 0 into fragments
-  load_origin(0);
+  load_origin();
   static_for<13>([&](auto itc) { load_step(itc); });
-  static_for<13>([&](auto itc) { static_for<(decltype(itc)::value < 4 ? 6 : 7)>([&](auto phc) { stage_step(itc, phc, 0u); }); });
+  constexpr int NST = 4 * 5 + 9 * (9 - XPH0);   // staging steps of a whole tile
+  static_for<NST>([&](auto sc) { stage_seq(std::integral_constant<int, 0>{}, sc, gdst, xdst); });
   __syncthreads();
-  load_origin(1);
+  load_origin();
   static_for<13>([&](auto itc) { load_step(itc); });
   read_row(0, 0);
   static_for<6>([&](auto sc) { cut_step(sc); });
@@ -319,19 +346,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 
   for (int i = 0; i < nT; ++i) {
     const unsigned rb = (i & 1) ? WX_LDS : 0, wb = WX_LDS - rb;
-    int n_oy0 = 0, n_ox0 = 0;
+    const unsigned gwb = gdst + wb, xwb = xdst + wb;   // (WX_LDS is a multiple of 128: the row XOR of gdst still applies)
     auto row = [&](auto rc) {
       constexpr int r = decltype(rc)::value;
       constexpr int nky = r < 3 ? r + 1 : 6 - r;            // (ks, ky) pairs of this row: 1 2 3 3 2 1
       constexpr int NM = 18 * nky;
       // side work of the row: staging steps (rows 1..3), load steps (row 4), then the six tap-cut steps of the next row
-      constexpr int NSTG = r == 1 ? 4 * 6 + 7 : (r == 2 || r == 3) ? 4 * 7 : r == 4 ? 13 : 0;
+      constexpr int NPX = 9 - XPH0;
+      constexpr int NSTG = r == 1 ? 4 * 5 + NPX : (r == 2 || r == 3) ? 4 * NPX : r == 4 ? 13 : 0;
       constexpr int NS = NSTG + 6;
       __builtin_amdgcn_sched_barrier(0);
-      if (r == 4) {   // origin of tile i + 2 (scalar): its loads are this row's side work
-        const int t = split + min(i + 2, nT - 1) * p.nSplit;
-        n_oy0 = (t / p.tilesX) * WX_TH; n_ox0 = (t % p.tilesX) * WX_TW;
-      }
       if (r < 5) read_row(rb, r + 1); else read_row(wb, 0);
       __builtin_amdgcn_sched_barrier(0);
       static_for<NM>([&](auto mc) {
@@ -350,13 +374,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
           constexpr int s = s0 + decltype(dc)::value;
           if constexpr (s >= NSTG) {
             cut_step(std::integral_constant<int, s - NSTG>{});
-          } else if constexpr (r == 1) {
-            constexpr int it = s < 24 ? s / 6 : 4, ph = s < 24 ? s % 6 : s - 24;
-            stage_step(std::integral_constant<int, it>{}, std::integral_constant<int, ph>{}, wb);
-          } else if constexpr (r == 2 || r == 3) {
-            stage_step(std::integral_constant<int, (r == 2 ? 5 : 9) + s / 7>{}, std::integral_constant<int, s % 7>{}, wb);
+          } else if constexpr (r >= 1 && r <= 3) {   // items 0..4 | 5..8 | 9..12
+            stage_seq(std::integral_constant<int, r == 1 ? 0 : r == 2 ? 5 : 9>{}, std::integral_constant<int, s>{}, gwb, xwb);
           } else {
-            if constexpr (s == 0) { l_oy0 = n_oy0; l_ox0 = n_ox0; }
+            if constexpr (s == 0) load_origin();   // tile i + 2: the staging of tile i + 1 is complete
             load_step(std::integral_constant<int, s>{});
           }
         });

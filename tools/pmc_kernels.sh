@@ -2,7 +2,7 @@
 # Runs on the GPU box: per-kernel PMC averages of one command, one rocprofv3 pass per counter group (kernel-trace only).
 # usage: bash tools/pmc_kernels.sh <out-dir> <kernel-name-substring> -- <command...>
 O=$(realpath -m $1); PAT=$2; shift 3
-R=/root/repo; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
