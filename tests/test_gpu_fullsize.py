@@ -43,10 +43,40 @@ def test_vgg_large_fullsize_step(F, O):
     _fullsize(F, O, large=True)
 
 
-def _fullsize(F, O, large=False):
+def test_vgg_large_config5_as_stated(F, O):
+    """BASELINE config 5 exactly as BASELINE.json states it: vgg_large 3x600x1000, 7x7 ROI pooling
+    (config/imagenet.lua:9-12, README.md:19) and an example list of R = 300 (negatives sampled up to that count)."""
+    _fullsize(F, O, large=True, pool=7, examples=300)
+
+
+def test_fullsize_detect(F, O):
+    """BASELINE config 2 at its stated size: Detector:detect (Detector.lua:17-141) on synthetic 3x450x800 frames against
+    orc_detect, every stage (test_gpu_model.check_detect: lists may differ only where a border case is shown)."""
+    import torch
+    from test_gpu_model import _amplified_weights, check_detect
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)
+    weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
+    om = oracle_model(O, cfg)
+    w = _amplified_weights(model["native"], weights.cpu().numpy().copy(), cfg["class_count"] + 1, cls_gain=200.0)
+    # (x60 on the anchor nets' class logits passes most of the 26 544 anchors; x30 -- bench.py's gain -- about 8 000)
+    for off, cnt, kind, aux in model["native"].param_table:
+        if kind == 0 and aux == 18:
+            v = w[off:off + cnt].reshape(18, -1)
+            for a in range(3):
+                v[a * 6:a * 6 + 2] *= 0.5
+    weights.copy_(torch.from_numpy(w))
+    r = check_detect(F, O, model, om, w, range(2), 450, 800)
+    print("full-size detect: frame %(seed)d, %(matches)d matches, %(candidates)d candidates, %(winners)d winners, %(frames_compared)d frames" % r)
+    assert r["matches"] > 1000 and r["winners"] > 0
+
+
+def _fullsize(F, O, large=False, pool=None, examples=None):
     import torch
     H, W = (600, 1000) if large else (450, 800)
     cfg = dict(F.imgnet_cfg if large else F.duplo_cfg)
+    if pool:
+        cfg["roi_pooling"] = dict(kw=pool, kh=pool)
     model = (F.vgg_large if large else F.vgg_small)(cfg)
     weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
     nat = model["native"]
@@ -54,6 +84,16 @@ def _fullsize(F, O, large=False):
     w = weights.cpu().numpy().copy()
     anchors, rois, pos, neg, img = fullsize_inputs(
         F, cfg, model, H, W, [(73, 123), (36, 61), (34, 59), (32, 57)] if large else [(55, 98), (27, 48), (25, 46), (23, 44)])
+    if examples:   # pad the list with further sampled negatives (Anchors.lua:197-235, the same generator stream going on)
+        mt = F.MT19937(11)
+        more = F.clean_examples(anchors.sampleNegative(F.Rect(0, 0, W, H), rois, cfg["negative_threshold"], 4 * examples, mt),
+                                F.output_map_sizes(model, H, W))
+        seen = set((n[0].layer, n[0].aspect, n[0].index[1], n[0].index[2]) for n in neg)
+        for n in more:
+            k = (n[0].layer, n[0].aspect, n[0].index[1], n[0].index[2])
+            if len(pos) + len(neg) < examples and k not in seen:
+                neg.append(n); seen.add(k)
+        assert len(pos) + len(neg) == examples
     if large:
         assert 3 * sum(h * w_ for h, w_ in [(73, 123), (36, 61), (34, 59), (32, 57)]) == 45015
     R = len(pos) + len(neg)
@@ -70,6 +110,8 @@ def _fullsize(F, O, large=False):
         f = F.create_objective(model, weights, gradient, _OneBatch([dict(img=img, positive=pos, negative=neg)], anchors), stats)
         with decisions.CaptureBeforeBackward(F, model, f) as cap:    # the device's pool winners / PReLU branches
             loss, grad = f(weights)
+        model["pnet"].training()
+        outs_dev = [o.numpy() for o in model["pnet"].forward(img)]   # the five outputs of this very frame (same masks)
     finally:
         model["pnet"].drop_masks = None
         model["cnet"].drop_masks = None
@@ -78,6 +120,11 @@ def _fullsize(F, O, large=False):
     own = decisions.blank_like(cap.captured[0])
     with O.decisions(inject=cap.captured[0], record=own):
         O.train_image(om, w, g_want, img, *oracle_tables(pos, neg, rois), pm, cm, bn_o, acc)
+        outs_want, _ = O.pnet_forward(om, w, img, True, pm)
+    # the forward pass itself, directly: the five pnet outputs of the frame at 1e-4 (not only through the four losses)
+    for i, (a, b) in enumerate(zip(outs_dev, outs_want)):
+        assert a.shape == b.shape
+        assert_close(a, b, 1e-4, "pnet output %d of the full-size frame" % (i + 1))
     differing = decisions.count_differences(cap.captured[0], own)
     g_want /= acc[2]
     want = dict(pcls=acc[0] / acc[2], preg=acc[1] / acc[3], dcls=acc[6] / acc[7], dreg=acc[4] / acc[5])
