@@ -108,6 +108,7 @@ _SIGS = {
     "frcnn_comm_get_unique_id": ([vp], C.c_int),
     "frcnn_comm_exchange_id_file": ([C.c_char_p, C.c_int, vp, C.c_int], C.c_int),
     "frcnn_comm_init_rank": ([C.POINTER(vp), C.c_int, C.c_int, vp], C.c_int),
+    "frcnn_comm_init_rank_timeout": ([C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int], C.c_int),
     "frcnn_comm_init_rank_file": ([C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_int], C.c_int),
     "frcnn_comm_destroy": ([vp], C.c_int),
     "frcnn_comm_info": ([vp, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),

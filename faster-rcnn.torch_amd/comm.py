@@ -35,7 +35,7 @@ class Comm(object):
         h = C.c_void_p()
         if id_bytes is not None:
             buf = C.create_string_buffer(bytes(id_bytes), 128)
-            _lib.call("frcnn_comm_init_rank", C.byref(h), self.world_size, self.rank, buf)
+            _lib.call("frcnn_comm_init_rank_timeout", C.byref(h), self.world_size, self.rank, buf, int(timeout_ms))
         else:
             if not path:
                 raise _lib.FrcnnError("Comm needs a rendezvous path or an id")

@@ -14,7 +14,11 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -31,6 +35,10 @@ struct Rccl {
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  // optional (RCCL >= 2.14): the non-blocking initialisation the watchdog of frcnn_comm_init_rank_timeout uses
+  ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   std::string err;
 };
 
@@ -62,6 +70,9 @@ bool rccl_load() {
   FR_SYM(CommUserRank, "ncclCommUserRank")
   FR_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef FR_SYM
+  *(void**)(&g_rccl.CommInitRankConfig) = dlsym(so, "ncclCommInitRankConfig");
+  *(void**)(&g_rccl.CommGetAsyncError) = dlsym(so, "ncclCommGetAsyncError");
+  *(void**)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
   g_rccl.so = so;
   return true;
 }
@@ -101,14 +112,29 @@ int frcnn_comm_get_unique_id(void* id_host) {
   return FRCNN_OK;
 }
 
-// The rendezvous file: {128-byte id, 8-byte job nonce, 8-byte pid of the writer}.  A reader accepts it only when the
-// nonce is its own job's (FRCNN_COMM_NONCE) and the writer is still alive: what a crashed or killed job left behind
-// under the same path is ignored (and removed by the next rank 0 before it writes).
+// The rendezvous file: {128-byte id, 8-byte job nonce, 8-byte pid of the writer, its host name}.  A reader accepts it only
+// when the nonce is its own job's (FRCNN_COMM_NONCE) and -- when the writer ran on the reader's own host, where a pid can
+// be probed -- the writer is still alive: what a crashed or killed job left behind under the same path is ignored (and
+// removed by the next rank 0 before it writes).  A writer on ANOTHER host (the file on a shared file system, or another
+// container's pid namespace under another host name) is judged by the nonce alone.
 struct IdFile {
   unsigned char id[FRCNN_COMM_ID_BYTES];
   unsigned long long nonce;
   long long pid;
+  char host[64];
 };
+
+static void this_host(char out[64]) {
+  memset(out, 0, 64);
+  if (const char* e = getenv("FRCNN_COMM_HOSTNAME")) { strncpy(out, e, 63); return; }   // (tests: pose as another host)
+  if (gethostname(out, 63) != 0) out[0] = 0;
+  // two containers may share a host name but not a pid namespace: the namespace's inode is part of the identity
+  struct stat st;
+  if (stat("/proc/self/ns/pid", &st) == 0) {
+    size_t n = strlen(out);
+    snprintf(out + n, 63 - n, "#%lx", (unsigned long)st.st_ino);
+  }
+}
 
 static unsigned long long job_nonce() {
   const char* e = getenv("FRCNN_COMM_NONCE");
@@ -129,6 +155,7 @@ int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int t
     IdFile rec;
     memcpy(rec.id, id_host, FRCNN_COMM_ID_BYTES);
     rec.nonce = nonce; rec.pid = (long long)getpid();
+    this_host(rec.host);
     ssize_t w = write(fd, &rec, sizeof(rec));
     close(fd);
     FR_CHECK(w == (ssize_t)sizeof(rec), "frcnn_comm_exchange_id_file: short write to %s", tmp.c_str());
@@ -137,6 +164,8 @@ int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int t
   }
   const double t0 = now_ms();
   const char* why = "no file";
+  char me[64];
+  this_host(me);
   for (;;) {
     int fd = open(path, O_RDONLY);
     if (fd >= 0) {
@@ -145,7 +174,8 @@ int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int t
       close(fd);
       if (r != (ssize_t)sizeof(rec)) why = "short or foreign file";
       else if (rec.nonce != nonce) why = "another job's nonce (stale file?)";
-      else if (kill((pid_t)rec.pid, 0) != 0 && errno == ESRCH) why = "its writer is gone (stale file of a dead job)";
+      else if (memcmp(rec.host, me, 64) == 0 && kill((pid_t)rec.pid, 0) != 0 && errno == ESRCH)
+        why = "its writer is gone (stale file of a dead job)";
       else { memcpy(id_host, rec.id, FRCNN_COMM_ID_BYTES); return FRCNN_OK; }
     }
     if (now_ms() - t0 > timeout_ms) {
@@ -156,29 +186,99 @@ int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int t
   }
 }
 
-int frcnn_comm_init_rank(frcnn_comm** out_host, int nranks, int rank, const void* id_host) {
+// ncclCommInitRank is a collective: a rank whose peer died between the rendezvous and this call would wait forever.
+// timeout_ms > 0 puts a watchdog on it.  With an RCCL that has the non-blocking initialisation (ncclCommInitRankConfig,
+// blocking = 0) the call returns at once, ncclCommGetAsyncError is polled until the communicator is ready, and on expiry
+// ncclCommAbort tears the half-built communicator down.  Otherwise the blocking call runs on a helper thread the caller
+// waits for with a deadline; on expiry the thread is abandoned (it owns nothing the caller touches again).
+// FRCNN_COMM_CHANNELS=n caps the channels (= CUs) RCCL's kernels take: a throughput-bound training step shares the CUs
+// with the all-reduce of the previous bucket (NCCL_MAX_NCHANNELS, read by RCCL when the communicator is built).
+// FRCNN_COMM_FAULT=hang_init (tests): the initialisation never returns, as with a dead peer.
+static int comm_init(frcnn_comm** out_host, int nranks, int rank, const void* id_host, int timeout_ms) {
   FR_CHECK(out_host && id_host && nranks >= 1 && rank >= 0 && rank < nranks, "frcnn_comm_init_rank: bad arguments");
-  if (!rccl_load()) { frcnn::set_error("cannot load librccl: %s", g_rccl.err.c_str()); return FRCNN_ERR_STATE; }
+  const char* fault = getenv("FRCNN_COMM_FAULT");
+  const bool hang = fault && strcmp(fault, "hang_init") == 0;
+  if (!hang && !rccl_load()) { frcnn::set_error("cannot load librccl: %s", g_rccl.err.c_str()); return FRCNN_ERR_STATE; }
+  if (const char* ch = getenv("FRCNN_COMM_CHANNELS"))
+    if (atoi(ch) > 0) setenv("NCCL_MAX_NCHANNELS", ch, 1);
   ncclUniqueId id;
   memcpy(&id, id_host, sizeof(id));
-  frcnn_comm* c = new frcnn_comm();
-  c->nranks = nranks; c->rank = rank;
-  if (hipGetDevice(&c->device) != hipSuccess) { delete c; frcnn::set_error("frcnn_comm_init_rank: no HIP device"); return FRCNN_ERR_HIP; }
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);   // collective: every rank of the job calls it
+  int device = 0;
+  if (!hang && hipGetDevice(&device) != hipSuccess) { frcnn::set_error("frcnn_comm_init_rank: no HIP device"); return FRCNN_ERR_HIP; }
+  const double t0 = now_ms();
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = ncclSuccess;
+  if (timeout_ms <= 0 && !hang) {
+    r = g_rccl.CommInitRank(&comm, nranks, id, rank);   // collective: every rank of the job calls it
+  } else if (!hang && g_rccl.CommInitRankConfig && g_rccl.CommGetAsyncError && g_rccl.CommAbort) {
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    r = g_rccl.CommInitRankConfig(&comm, nranks, id, rank, &cfg);
+    while (r == ncclSuccess || r == ncclInProgress) {
+      ncclResult_t st = ncclSuccess;
+      r = g_rccl.CommGetAsyncError(comm, &st);
+      if (r != ncclSuccess) break;
+      r = st;
+      if (st != ncclInProgress) break;
+      if (now_ms() - t0 > timeout_ms) {
+        g_rccl.CommAbort(comm);
+        frcnn::set_error("ncclCommInitRank(rank %d of %d) did not complete within %d ms: a peer is missing or dead "
+                         "(communicator aborted)", rank, nranks, timeout_ms);
+        return FRCNN_ERR_STATE;
+      }
+      usleep(1000);
+    }
+  } else {
+    struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclComm_t comm = nullptr; ncclResult_t r = ncclSuccess; };
+    std::shared_ptr<Job> job = std::make_shared<Job>();
+    std::thread([job, nranks, id, rank, device, hang]() {
+      if (hang) for (;;) sleep(3600);
+      (void)hipSetDevice(device);
+      ncclComm_t c = nullptr;
+      ncclResult_t rr = g_rccl.CommInitRank(&c, nranks, id, rank);
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->comm = c; job->r = rr; job->done = true;
+      job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    const bool in_time = job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 1000), [&] { return job->done; });
+    if (!in_time) {
+      frcnn::set_error("ncclCommInitRank(rank %d of %d) did not complete within %d ms: a peer is missing or dead "
+                       "(the initialising thread was abandoned)", rank, nranks, timeout_ms > 0 ? timeout_ms : 1000);
+      return FRCNN_ERR_STATE;
+    }
+    comm = job->comm; r = job->r;
+  }
   if (r != ncclSuccess) {
     frcnn::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString(r));
-    delete c;
     return FRCNN_ERR_HIP;
   }
+  frcnn_comm* c = new frcnn_comm();
+  c->nranks = nranks; c->rank = rank; c->device = device; c->comm = comm;
   *out_host = c;
   return FRCNN_OK;
 }
 
+int frcnn_comm_init_rank(frcnn_comm** out_host, int nranks, int rank, const void* id_host) {
+  return comm_init(out_host, nranks, rank, id_host, 0);
+}
+
+int frcnn_comm_init_rank_timeout(frcnn_comm** out_host, int nranks, int rank, const void* id_host, int timeout_ms) {
+  return comm_init(out_host, nranks, rank, id_host, timeout_ms);
+}
+
+// timeout_ms bounds the wait for the id file AND (what is left of it, at least a second) the collective initialisation
 int frcnn_comm_init_rank_file(frcnn_comm** out_host, int nranks, int rank, const char* path, int timeout_ms) {
   unsigned char id[FRCNN_COMM_ID_BYTES];
-  if (rank == 0) FR_TRY(frcnn_comm_get_unique_id(id));
+  const bool hang = getenv("FRCNN_COMM_FAULT") && strcmp(getenv("FRCNN_COMM_FAULT"), "hang_init") == 0;
+  if (rank == 0) {
+    if (hang) memset(id, 0, sizeof(id));
+    else FR_TRY(frcnn_comm_get_unique_id(id));
+  }
+  const double t0 = now_ms();
   FR_TRY(frcnn_comm_exchange_id_file(path, rank, id, timeout_ms));
-  return frcnn_comm_init_rank(out_host, nranks, rank, id);
+  const int left = timeout_ms > 0 ? std::max(1000, timeout_ms - (int)(now_ms() - t0)) : 0;
+  return comm_init(out_host, nranks, rank, id, left);
 }
 
 int frcnn_comm_destroy(frcnn_comm* c) {

@@ -424,6 +424,11 @@ typedef struct frcnn_comm frcnn_comm;
 int frcnn_comm_get_unique_id(void *id_host);
 int frcnn_comm_exchange_id_file(const char *path, int rank, void *id_host, int timeout_ms);   /* host only, no RCCL */
 int frcnn_comm_init_rank(frcnn_comm **out_host, int nranks, int rank, const void *id_host);
+/* The same under a watchdog: a peer that died between the rendezvous and this collective call surfaces as an error after
+ * timeout_ms instead of a hang (non-blocking ncclCommInitRankConfig + ncclCommAbort where RCCL has them).
+ * frcnn_comm_init_rank_file applies its timeout_ms to the file wait and to the initialisation.  Environment:
+ * FRCNN_COMM_CHANNELS=n caps the channels (CUs) RCCL's kernels occupy beside the training step. */
+int frcnn_comm_init_rank_timeout(frcnn_comm **out_host, int nranks, int rank, const void *id_host, int timeout_ms);
 int frcnn_comm_init_rank_file(frcnn_comm **out_host, int nranks, int rank, const char *path, int timeout_ms);
 int frcnn_comm_destroy(frcnn_comm *);
 int frcnn_comm_info(const frcnn_comm *, int *nranks_host, int *rank_host);

@@ -42,7 +42,7 @@ def test_file_rendezvous_times_out_with_a_message(F, tmp_path):
         F._lib.call("frcnn_comm_init_rank", C.byref(C.c_void_p()), 2, 5, C.create_string_buffer(128))   # rank >= nranks
 
 
-def _write_id_file(path, nonce, pid_alive):
+def _write_id_file(path, nonce, pid_alive, host=None):
     """rank 0's side of the rendezvous in a child process with its own FRCNN_COMM_NONCE; the child exits (dead writer)
     unless pid_alive, in which case it lingers until the file is removed."""
     import subprocess, sys
@@ -52,6 +52,8 @@ def _write_id_file(path, nonce, pid_alive):
             + ("[time.sleep(0.05) for _ in range(600) if os.path.exists(%r)]" % path if pid_alive else "pass")) % (
                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
     env = dict(os.environ, FRCNN_COMM_NONCE=nonce)
+    if host:
+        env["FRCNN_COMM_HOSTNAME"] = host
     p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE)
     assert p.stdout.readline().strip() == b"written"
     return p
@@ -87,7 +89,57 @@ def test_stale_id_files_are_not_joined(F, tmp_path, monkeypatch):
     F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 0, C.create_string_buffer(bytes(range(128)), 128), 1000)
     buf = C.create_string_buffer(128)
     F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, buf, 2000)   # (this process is the live writer)
-    assert buf.raw == bytes(range(128)) and os.path.getsize(path) == 144
+    assert buf.raw == bytes(range(128)) and os.path.getsize(path) == 208   # id 128 + nonce 8 + pid 8 + host 64
+
+
+def test_id_file_of_a_writer_on_another_host_is_judged_by_its_nonce(F, tmp_path, monkeypatch):
+    """the liveness probe (kill(pid, 0)) only means something on the writer's own host.  A record written under
+    another host name -- the file on a shared file system, rank 0 in another container -- is accepted on its nonce although
+    no process of that pid exists here; the same record under THIS host's name is a dead job's and is refused."""
+    path = str(tmp_path / "id")
+    monkeypatch.setenv("FRCNN_COMM_NONCE", "job-A")
+    p = _write_id_file(path, "job-A", pid_alive=False, host="node-17"); p.wait(30)      # the writer's pid is gone HERE
+    buf = C.create_string_buffer(128)
+    F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, buf, 300)
+    assert buf.raw == bytes([7]) * 128
+    monkeypatch.setenv("FRCNN_COMM_HOSTNAME", "node-17")                               # ... and now we ARE that host
+    with pytest.raises(F.FrcnnError, match="writer is gone"):
+        F._lib.call("frcnn_comm_exchange_id_file", path.encode(), 1, C.create_string_buffer(128), 300)
+
+
+def test_a_dead_peer_surfaces_as_an_error_within_the_timeout(F, tmp_path, monkeypatch):
+    """frcnn_comm_init_rank_timeout / frcnn_comm_init_rank_file: the collective initialisation under a watchdog.  The fault
+    knob makes the initialisation hang exactly as ncclCommInitRank does when a peer died after the rendezvous (the real
+    thing -- one rank of two missing, real RCCL -- runs on the GPU box below)."""
+    monkeypatch.setenv("FRCNN_COMM_FAULT", "hang_init")
+    t0 = time.time()
+    with pytest.raises(F.FrcnnError, match="did not complete within 400 ms"):
+        F._lib.call("frcnn_comm_init_rank_timeout", C.byref(C.c_void_p()), 2, 0, C.create_string_buffer(128), 400)
+    assert time.time() - t0 < 5
+    t0 = time.time()
+    with pytest.raises(F.FrcnnError, match="did not complete within"):
+        F._lib.call("frcnn_comm_init_rank_file", C.byref(C.c_void_p()), 2, 0, str(tmp_path / "id").encode(), 500)
+    assert time.time() - t0 < 6
+
+
+@pytest.mark.gpu
+def test_a_missing_rank_times_out_on_real_rccl(F, tmp_path):
+    """One rank of a two-rank communicator never shows up: real ncclCommInitRank under the watchdog returns an error
+    (and the process goes on to build a working one-rank communicator afterwards)."""
+    F._lib.call("frcnn_set_device", 0)
+    ident = C.create_string_buffer(128)
+    F._lib.call("frcnn_comm_get_unique_id", ident)
+    t0 = time.time()
+    with pytest.raises(F.FrcnnError, match="did not complete within 3000 ms"):
+        F._lib.call("frcnn_comm_init_rank_timeout", C.byref(C.c_void_p()), 2, 0, ident, 3000)
+    assert time.time() - t0 < 30
+    F._lib.call("frcnn_comm_get_unique_id", ident)
+    h = C.c_void_p()
+    F._lib.call("frcnn_comm_init_rank_timeout", C.byref(h), 1, 0, ident, 60000)
+    n = C.c_int()
+    F._lib.call("frcnn_comm_query", h, C.byref(n), None, None)
+    assert n.value == 1
+    F._lib.call("frcnn_comm_destroy", h)
 
 
 def test_bench_refuses_a_world_it_cannot_run():
