@@ -331,9 +331,14 @@ int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const f
     const size_t Rp = (size_t)linear_x_rows_padded(R);
     void *gp = nullptr, *gpT = nullptr, *xpT = nullptr;
     int rc = FRCNN_OK;
-    if (xd) FR_HIP(hipMalloc(&gp, (size_t)3 * R * O * 2));
-    if (xw) { FR_HIP(hipMalloc(&gpT, (size_t)3 * O * Rp * 2)); FR_HIP(hipMalloc(&xpT, (size_t)3 * I * Rp * 2)); }
-    rc = split_planes(gy, R, O, gp, gpT, S(stream));
+    auto alloc = [&](void** p, size_t bytes) {   // (a failed allocation frees what the earlier ones got: no early return)
+      if (rc != FRCNN_OK) return;
+      hipError_t e = hipMalloc(p, bytes);
+      if (e != hipSuccess) { set_error("frcnn_linear_backward: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); rc = FRCNN_ERR_HIP; }
+    };
+    if (xd) alloc(&gp, (size_t)3 * R * O * 2);
+    if (xw) { alloc(&gpT, (size_t)3 * O * Rp * 2); alloc(&xpT, (size_t)3 * I * Rp * 2); }
+    if (rc == FRCNN_OK) rc = split_planes(gy, R, O, gp, gpT, S(stream));
     if (rc == FRCNN_OK && xw) rc = split_planes(x, R, I, nullptr, xpT, S(stream));
     if (rc == FRCNN_OK && xd) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream));
     if (rc == FRCNN_OK && xw) rc = linear_x_wgrad(gpT, xpT, R, O, I, gweight, S(stream));

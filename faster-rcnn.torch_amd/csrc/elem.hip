@@ -373,7 +373,6 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
 
 __global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks, float* part_b) {
   __shared__ float sh[16];
-  __shared__ double shd[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long per = cdivl(hw, chunks);
   const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;

@@ -176,6 +176,36 @@ def test_linear_fc1_split_form_tile_heights_and_ragged_rows(F, O, R, tm, monkeyp
     assert_close(got["wgrad"], gw0.astype(np.float64) + g64.T @ x64, 1e-4, "FC1 weight gradient R=%d tm=%s" % (R, tm))
 
 
+def test_linear_split_form_with_weights_at_a_4_byte_offset(F, O):
+    """inside the flat parameter vector the weights of a Linear start at ANY multiple of 4 bytes (single PReLU
+    slopes sit in front of them), while gemm_planes_kernel fetches them with 16-byte LDS-DMA.  gfx950 takes dword-aligned
+    b128 loads; this pins it: W (and the gradient it accumulates into) one float off a 16-byte boundary."""
+    import ctypes as C
+    R, I, Oo = 320, 13824, 1024
+    rng = np.random.RandomState(4)
+    x = rng.randn(R, I).astype(np.float32)
+    w = (rng.randn(Oo, I) / np.sqrt(I)).astype(np.float32); b = rng.randn(Oo).astype(np.float32)
+    gy = (rng.randn(R, Oo) / R).astype(np.float32)
+    wbuf = _dev(F, np.concatenate([[0.25], w.ravel()]).astype(np.float32))       # a slope, then the weights
+    gwbuf = F.DeviceTensor.zeros((1 + Oo * I,))
+    off = lambda t: C.c_void_p(F.ptr(t).value + 4)
+    assert off(wbuf).value % 16 == 4
+    dx, db, dgy = _dev(F, x), _dev(F, b), _dev(F, gy)
+    F._lib.call("frcnn_set_option", b"gemm_x_roles", 7)
+    try:
+        y = F.DeviceTensor.empty((R, Oo)); gx = F.DeviceTensor.empty((R, I)); gb = F.DeviceTensor.zeros((Oo,))
+        F._lib.call("frcnn_linear_forward", F.ptr(dx), R, I, off(wbuf), F.ptr(db), Oo, F.ptr(y), F.stream_ptr())
+        F._lib.call("frcnn_linear_backward", F.ptr(dx), F.ptr(dgy), R, I, off(wbuf), Oo, F.ptr(gx), off(gwbuf), F.ptr(gb), F.stream_ptr())
+    finally:
+        F._lib.call("frcnn_set_option", b"gemm_x_roles", -1)
+    x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), gy.astype(np.float64)
+    assert_close(y.numpy(), x64 @ w64.T + b, 1e-4, "forward, W at +4 bytes")
+    assert_close(gx.numpy(), g64 @ w64, 1e-4, "input gradient, W at +4 bytes")
+    gw = gwbuf.numpy()
+    assert gw[0] == 0.0
+    assert_close(gw[1:].reshape(Oo, I), g64.T @ x64, 1e-4, "weight gradient at +4 bytes")
+
+
 def test_rmsprop_and_scale(F, O):
     rng = np.random.RandomState(9)
     n = 100003
