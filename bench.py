@@ -498,6 +498,9 @@ def main():
     every = 1 if args.profile_all else 4
     sampled = 0
     barrier()
+    if native_comm is not None:
+        native_comm.timing = []       # per-bucket all-reduce durations of the timed region (config.exchange.buckets)
+    state["_timing"] = dict(enqueue=0.0, wait=0.0, steps=0)   # utilities.rmsprop fills it: host time per step
     t0 = time.perf_counter()
     for i in range(args.steps):
         on = (i % every) == 0
@@ -509,6 +512,11 @@ def main():
             F._lib.call("frcnn_prof_enable", 0)
     barrier()
     dt = time.perf_counter() - t0
+    host_t = state.pop("_timing")
+    bucket_times = None
+    if native_comm is not None:
+        bucket_times = native_comm.bucket_times()
+        native_comm.timing = None
     nk = len(F._lib.KC_NAMES)
     launches = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
     F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
@@ -575,10 +583,13 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS
         ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
         traffic = None
+        traffic_taken = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_bytes_per_launch" % F._lib.KC_NAMES[k])
+                tj = json.load(open(tpath))
+                traffic = tj.get("%s_bytes_per_launch" % F._lib.KC_NAMES[k])
+                traffic_taken = tj.get("taken")    # {git, date}: which tree the PMC passes measured (a stale table shows here)
             except Exception:
                 traffic = None
         classes = {}
@@ -607,6 +618,11 @@ def main():
                         conv_kernel_ms_per_step=round(conv_ms, 3), kernel_classes=classes,
                         kernel_classes_serial_pass=iso_classes,
                         last_loss=stats["pcls"][-1] + stats["preg"][-1] if stats["pcls"] else None),
+            host=dict(enqueue_ms_per_step=round(1e3 * host_t["enqueue"] / max(host_t["steps"], 1), 3),
+                      wait_ms_per_step=round(1e3 * host_t["wait"] / max(host_t["steps"], 1), 3),
+                      note="rank 0, timed region: time the host needs to queue one step through the C ABI (batch draw, example tables, "
+                           "every launch, the update) and the time it then waits for the step's 64-byte statistics; while wait > 0 the "
+                           "host is ahead of the device and does not bound `value`"),
             roofline=dict(bound="mfma",
                           kernel=("conv_x3_kernel (3x3 conv forward + input-gradient, split-bf16 operands: 6 bf16 MFMA partial products "
                                   "per fp32 product)" if split_on else
@@ -616,6 +632,7 @@ def main():
                           traffic_source=("profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
                                           "--pmc WRITE_SIZE passes of this command (FETCH x2, the gfx950 correction; tools/pmc_traffic.py), "
                                           "taken when the profile was made -- not counted in this run" if traffic is not None else None),
+                          traffic_taken=traffic_taken,
                           peak_note=("algorithmic (fp32-product) TFLOP/s against the dense bf16 matrix-core peak 2516.6 / 6 partial "
                                      "products; executed bf16 MFMA rate = 6 x achieved = %.0f TFLOP/s; the fp32 matrix-core peak is "
                                      "157.3 TFLOP/s" % (SPLIT_PRODUCTS * ach) if split_on else "fp32 matrix-core peak"),
@@ -627,7 +644,7 @@ def main():
             backend=("frcnn_comm (RCCL through the C ABI: frcnn_comm_init_rank_file / frcnn_allreduce_f32 / _f64)" if native_comm is not None
                      else ("torch.distributed nccl (RCCL)" if backend == "nccl" else "torch.distributed %s (debug: ranks may share a device)" % backend)
                      if world > 1 else "none (single process)"),
-            ranks=world, **(exchange_info or {}))
+            ranks=world, buckets=bucket_times, **(exchange_info or {}))
         ok = True
         full = args.model == "vgg_small" and (H, W) == (FULL_H, FULL_W)
         if world == 1 and not args.no_cpu_baseline and full:

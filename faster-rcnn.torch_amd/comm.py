@@ -87,15 +87,32 @@ class Comm(object):
             raise _lib.FrcnnError("the native communicator reduces device tensors only")
         if not t.is_contiguous():
             raise _lib.FrcnnError("all_reduce needs a contiguous tensor (a slice of the flat vector is)")
-        done = torch.cuda.Event()
+        timed = getattr(self, "timing", None) is not None     # bench.py: per-bucket durations on the communicator's stream
+        done = torch.cuda.Event(enable_timing=timed)
         ready = torch.cuda.Event()
         ready.record()                        # the operand is final where the caller's stream stands now
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
+            if timed:
+                start = torch.cuda.Event(enable_timing=True)
+                start.record()
             fn(t, stream_ptr(), *extra)
             done.record()
+        if timed:
+            self.timing.append((t.numel() * t.element_size(), start, done))
         t.record_stream(self.stream)
         return _Work(done)
+
+    def bucket_times(self):
+        """[(bytes, launches, mean ms)] of the collectives recorded since `self.timing = []` (after a device synchronize):
+        what each bucket of the exchange step costs on the communicator's stream, beside the kernels of the step."""
+        import torch
+        torch.cuda.synchronize()
+        acc = {}
+        for nbytes, a, b in (getattr(self, "timing", None) or []):
+            n, ms = acc.get(nbytes, (0, 0.0))
+            acc[nbytes] = (n + 1, ms + a.elapsed_time(b))
+        return [dict(bytes=k, launches=n, mean_ms=round(ms / n, 4)) for k, (n, ms) in sorted(acc.items(), reverse=True)]
 
     def all_reduce(self, t, async_op=False, group=None):
         """In-place sum over the ranks of a float32 / float64 device tensor."""

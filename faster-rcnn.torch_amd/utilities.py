@@ -42,6 +42,10 @@ def rmsprop(opfunc, x, state):
     if "m" not in state:
         state["m"] = torch.zeros_like(x)
     begin = getattr(opfunc, "begin_fold", None)
+    timing = state.get("_timing")     # bench.py: seconds the host spends queueing a step / waiting for its statistics
+    if timing is not None:
+        import time
+        t_in = time.perf_counter()
     if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued,
         finish, dfdx, gscale = begin(x)   # and gradient:div(n) rides on the update's own pass over the vectors
         if hasattr(gscale, "ptr"):   # data parallel: the divisor is the all-reduced count, still on the device
@@ -52,7 +56,11 @@ def rmsprop(opfunc, x, state):
         else:
             _lib.call("frcnn_scale_rmsprop", ptr(x), ptr(dfdx), gscale, ptr(state["m"]), x.numel(), lr, alpha, eps,
                       stream_ptr())
+        if timing is not None:
+            t_q = time.perf_counter()
         fx, _ = finish()
+        if timing is not None:
+            timing["enqueue"] += t_q - t_in; timing["wait"] += time.perf_counter() - t_q; timing["steps"] += 1
         return x, [fx]
     fx, dfdx = opfunc(x)
     _lib.call("frcnn_rmsprop", ptr(x), ptr(dfdx), ptr(state["m"]), x.numel(), lr, alpha, eps, stream_ptr())

@@ -33,6 +33,16 @@ for key, prefix in (("conv_igemm_k3", "conv_igemm_kernel<3, 8"), ("conv_x3", "co
 rm = next((v for k, v in out["kernels"].items() if k.startswith("rmsprop_kernel")), None)
 if rm:
     out["calibration_rmsprop"] = dict(fetch_corrected=rm["fetch_bytes_per_launch_corrected"], write=rm["write_bytes_per_launch"])
+# provenance: bench.py copies it into roofline.traffic_taken, so that a table from another tree is visible in the bench line.
+# (the GPU box has no .git: tools/refresh_round.sh passes the hash of the tree it was started from in FRCNN_GIT_HASH)
+import datetime, os, subprocess
+git = os.environ.get("FRCNN_GIT_HASH")
+if not git:
+    try:
+        git = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
+    except Exception:
+        git = "unknown (no .git on the GPU box: set FRCNN_GIT_HASH)"
+out["taken"] = dict(git=git, date=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"))
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("bytes/launch: conv_x3", out.get("conv_x3_bytes_per_launch"), " conv_wgradx", out.get("conv_wgradx_bytes_per_launch"),
       " conv_igemm_k3", out.get("conv_igemm_k3_bytes_per_launch"), " rmsprop:", out.get("calibration_rmsprop"))
