@@ -215,12 +215,15 @@ struct CxArgs {
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 3 split-K slab
+  X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
 
 // WM = waves along the filter dimension: 2 -> block = 128 filters, 2 x 2 waves of 64 x 64 (four 32x32 accumulators each);
 // 1 -> block = 64 filters, 1 x 4 waves of 64 filters x 32 pixels (two accumulators each) for layers whose filter count is
 // not a multiple of 128 (the 64-channel input gradients).
-template <int KS, int WM, bool SLOPE, bool SCALE>
+// EPI = 1 (input-gradient launches that store, out_mode 0): the stored tile goes through the backward of the activation
+// that follows in the chain (X3PostAct) -- one read of x per element instead of act_backward's read + read + write pass.
+template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0>
 __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   constexpr int KK = KS * KS;
   constexpr int BMK = 64 * WM, NTW = WM, AST = 6 * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
@@ -447,6 +450,41 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
       }
     }
   };
+  if (EPI == 1) {
+    const float pa = *p.post.slope;
+    float sa = 0.f;   // this lane's share of the slope gradient: sum over x <= 0 of x * scale * g
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int q = wn * (32 * NTW) + nt * 32 + li;
+      const int ty = q / p.TW, tx = q - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      const bool ok = q < NT && oy < p.Ho && ox < p.Wo;
+      const size_t colo = ok ? (size_t)oy * p.Wo + ox : (size_t)0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const size_t rowo = (size_t)(mrow0 + mt * 32) * HoWo + colo;
+        float xv[16], sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {   // one batch of loads (pixel clamped, not branched around)
+          xv[r] = p.post.x[rowo + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo];
+          sc[r] = p.post.scale ? p.post.scale[mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2)] : 1.f;
+        }
+        if (ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float g = acc[mt][nt][r] * sc[r];
+            const bool pos = xv[r] > 0.f;
+            if (!pos) sa += xv[r] * g;
+            p.out[rowo + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = pos ? g : pa * g;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
+    if (lane == 0 && p.post.gslope) unsafeAtomicAdd(p.post.gslope, sa);
+    return;
+  }
   if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
   else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
   else store_tile(std::integral_constant<int, 3>{});
@@ -455,11 +493,15 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 // out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
 // Four consecutive pixels of one filter per thread when the map size allows (16-byte loads, the slabs of up to eight splits
 // in flight at once), in split order -- the sum is the same number whatever the vector width.
+// post.x != null: the folded value goes through the activation backward of X3PostAct (see conv_x3_kernel, EPI = 1)
 template <int VEC>
 __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw,
-                                                               const float* __restrict__ bias, float* __restrict__ out, int accumulate) {
+                                                               const float* __restrict__ bias, float* __restrict__ out, int accumulate,
+                                                               X3PostAct post) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const long total = (long)M * hw, nvec = total / VEC;
+  const float pa = post.x ? *post.slope : 1.f;
+  float sa = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     const long t = i * VEC;
     const float b = bias ? bias[t / hw] : 0.f;   // (VEC divides hw: the vector stays inside one filter's map)
@@ -479,7 +521,26 @@ __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __re
     }
     if (s < nSplit) v += *reinterpret_cast<const vec_t*>(slab + (size_t)s * total + t);
     vec_t* o = reinterpret_cast<vec_t*>(out + t);
+    if (post.x) {
+      const vec_t xv = *reinterpret_cast<const vec_t*>(post.x + t);
+      const float sc = post.scale ? post.scale[t / hw] : 1.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float g = v[j] * sc;
+        const bool pos = xv[j] > 0.f;
+        if (!pos) sa += xv[j] * g;
+        v[j] = pos ? g : pa * g;
+      }
+    }
     if (accumulate) *o += v; else *o = v;
+  }
+  if (post.x && post.gslope) {
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sa;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(post.gslope, (part[0] + part[1]) + (part[2] + part[3]));
   }
 }
 
@@ -512,24 +573,25 @@ static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
-template <int KS, int WM, bool SLOPE, bool SCALE>
+template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0>
 static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   const size_t lds = (size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * CX_BBUF;
-  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE>), dim3(grid), dim3(256), lds, a);
+  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
-            const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot) {
+            const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot,
+            const X3PostAct* post) {
   FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % 64 == 0,
            "conv_x3: %d channels -> %d filters, %dx%d is not a split-bf16 shape", Cin, M, k, k);
   FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
@@ -551,6 +613,9 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
+  a.post = post ? *post : X3PostAct{nullptr, nullptr, nullptr, nullptr};
+  FR_CHECK(!post || (k == 3 && out_mode == OUT_STORE && !in_slope && !in_scale && !bias && post->x && post->slope),
+           "conv_x3: the fused activation backward belongs to a storing 3x3 input-gradient launch");
   bool slab = false;
   if (a.splitK > 1) {
     float* ws = nullptr;
@@ -560,7 +625,9 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
-  if (k == 3 && bm == 128) {
+  if (post && a.splitK == 1) {   // (with a K split the fold below applies it)
+    rc = bm == 128 ? launch_x3<3, 2, false, false, 1>(a, algo_flops, s) : launch_x3<3, 1, false, false, 1>(a, algo_flops, s);
+  } else if (k == 3 && bm == 128) {
     rc = act == 3 ? launch_x3<3, 2, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 2, true, false>(a, algo_flops, s)
        : act == 1 ? launch_x3<3, 2, false, true>(a, algo_flops, s) : launch_x3<3, 2, false, false>(a, algo_flops, s);
   } else if (k == 3) {
@@ -575,18 +642,19 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     long total = (long)M * a.Ho * a.Wo;
     int grid;
     const long hw = (long)a.Ho * a.Wo;
-    const bool al = ((uintptr_t)out & 15) == 0 && ((uintptr_t)a.out & 15) == 0;
+    const X3PostAct pa = post ? *post : X3PostAct{nullptr, nullptr, nullptr, nullptr};
+    const bool al = ((uintptr_t)out & 15) == 0 && ((uintptr_t)a.out & 15) == 0 && (!post || ((uintptr_t)post->x & 15) == 0);
     const int vec = al && hw % 4 == 0 ? 4 : al && hw % 2 == 0 ? 2 : 1;
     grid = (int)std::min<long>(cdivl(total / vec, 256), 4096);
     if (vec == 4)
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<4>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
     else if (vec == 2)
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
     else
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
     FR_LAUNCH_CHECK();
   }
   return FRCNN_OK;

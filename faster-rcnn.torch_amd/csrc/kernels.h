@@ -47,13 +47,24 @@ int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
 int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo);
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
-            const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0);
+            const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0,
+            const struct X3PostAct* post = nullptr);
+// Backward of the PReLU + SpatialDropout the OUTPUT gradient of an input-gradient launch passes through next, fused into the
+// launch's epilogue (or into the fold of its split-K slabs): out = prelu'(x) * scale[m] * (conv result), *gslope += sum over
+// x <= 0 of x * scale[m] * (conv result).  What act_backward (elem.hip) does in a pass of its own, minus the bias sums,
+// which the weight-gradient launch reading `out` takes along (conv_wgrad's gbias).
+struct X3PostAct {
+  const float* x;        // [M][Ho][Wo] pre-activation output of the layer whose activation is undone
+  const float* slope;    // device scalar
+  const float* scale;    // [M] dropout scale or null
+  float* gslope;         // device scalar, accumulated
+};
 
 // weight gradient in the same split-bf16 form (wgradx.hip): k == 3, Cin % 64 == 0, O % 64 == 0; conv_wgrad routes to it
 bool conv_wgradx_eligible(int Cin, int O, int k);
 size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad);
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
-                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s);
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr);
 // gw[o][c][tap] += sum_s slab[s][tap][o][c]   (the fold shared by the weight-gradient kernels)
 int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s);
 
@@ -61,7 +72,8 @@ int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hip
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
-               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s);
+               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s,
+               float* gbias = nullptr);   // gbias: also gbias[o] += sum over pixels of g (in the same launch where the kernel can)
 
 // ---------------------------------------------------------------- deterministic mode (frcnn_set_option("deterministic", 1))
 // Default: per-block partial sums of the bias / slope gradients and the scatter-adds of the ROI-pooling and sparse anchor-net

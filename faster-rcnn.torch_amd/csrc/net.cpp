@@ -910,12 +910,23 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   if (use_side) FR_TRY(ensure_side(m));
   hipStream_t ws = use_side ? m->side : s;
   size_t n_fork = 0;
+  // Fused activation backward (round 4): the input-gradient launch of convolution st writes its result THROUGH the backward of
+  // convolution st - 1's PReLU / SpatialDropout (conv_x3's X3PostAct: epilogue, or the fold of its split-K slabs) and adds the
+  // slope gradient; the bias gradient of st - 1 rides on its weight-gradient launch (conv_wgrad's gbias).  act_backward --
+  // a read-read-write pass over the tensor on the dependent chain -- is then not launched for st - 1.  (Not in deterministic
+  // mode: the sums leave through atomics.)
+  const bool fuse_act = !deterministic() && !(getenv("FRCNN_FUSE_ACT") && atoi(getenv("FRCNN_FUSE_ACT")) == 0);
+  bool act_done = false;   // the gradient tensor of the convolution being visited already went through its activation
   for (int b = nb - 1; b >= 0; --b) {
     Block& blk = m->blocks[b];
     for (int st = blk.nconv - 1; st >= 0; --st) {
       Conv& c = m->convs[blk.first_conv + st];
       const float* scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;
-      if (st == blk.nconv - 1) {
+      const bool fused_here = act_done;
+      act_done = false;
+      if (fused_here) {
+        // (nothing: c.gx is final; its bias gradient comes with the weight gradient below)
+      } else if (st == blk.nconv - 1) {
         FR_TRY(maxpool_act_backward(blk.gpooled.f(), (const unsigned char*)blk.pidx.p, c.x.f(), c.Cout, c.Ho, c.Wo,
                                     w + c.a_off, scale, c.gx.f(), grad + c.b_off, grad + c.a_off, s));
       } else {
@@ -938,11 +949,12 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       if (use_side && !on_caller) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
       if (on_caller) {
         FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws_first.p,
-                          m->wg_ws_first.bytes, s));
+                          m->wg_ws_first.bytes, s, fused_here ? grad + c.b_off : nullptr));
         FR_HIP(hipEventRecord(m->join_ev, ws));          // (block 0's other convolutions, if any, are on the side stream)
         FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
       } else {
-        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws));
+        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws,
+                          fused_here ? grad + c.b_off : nullptr));
       }
       if (st == 0) {   // every gradient of block b's parameters is final once this launch has run (its fork also
                        // covers the bias / slope sums that act_backward accumulates on the caller's stream)
@@ -957,7 +969,12 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
-      if (c.x_d)
+      if (c.x_d && st > 0 && fuse_act && c.k == 3) {
+        Conv& pc = m->convs[blk.first_conv + st - 1];
+        X3PostAct post{pc.x.f(), w + pc.a_off, (st - 1 == 0 && blk.has_drop) ? blk.scale.f() : nullptr, grad + pc.a_off};
+        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, &post));
+        act_done = true;
+      } else if (c.x_d)
         FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s));
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,

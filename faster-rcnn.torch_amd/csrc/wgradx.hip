@@ -82,6 +82,7 @@ struct WgradXArgs {
   const float* in_scale;
   const float* g;
   float* slab;   // [nSplit][9][O][Cin]
+  float* gbias;  // optional [O]: += sum over pixels of g (accGradParameters' bias half), taken from the staged gradient tiles
   int Cin, H, W, O, Ho, Wo, pad;
   int tilesX, tilesY, oTiles, cTiles, nSplit;
 };
@@ -187,6 +188,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // pair 1: level 1, levels 2 + 3 | three 8-byte LDS writes.
   float sr[13][4];
   unsigned sh[13][2], sm[13][2], sl[13][2];
+  float bsum = 0.f;        // this thread's share of the bias gradient of filter o0 + srow (its 4-pixel segments of every tile)
+  bool bsum_on = true;     // off while the walk repeats the block's last tile
   auto up_lo = [](unsigned v) { return __builtin_bit_cast(float, v << 16); };
   auto up_hi = [](unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); };
   // tile walk of the block: t_i = split + i nSplit as (row, column) of the tile grid, advanced without a division; past the
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
         x0 = inside(itc, 2 * j) ? x0 : 0.f;
         x1 = inside(itc, 2 * j + 1) ? x1 : 0.f;
       }
+      if (it < 4) bsum += bsum_on ? x0 + x1 : 0.f;
       sh[it][j] = wx_cvt2(x0, x1);
       sr[it][2 * j] = x0 - up_lo(sh[it][j]);
       sr[it][2 * j + 1] = x1 - up_hi(sh[it][j]);
@@ -347,6 +351,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   for (int i = 0; i < nT; ++i) {
     const unsigned rb = (i & 1) ? WX_LDS : 0, wb = WX_LDS - rb;
     const unsigned gwb = gdst + wb, xwb = xdst + wb;   // (WX_LDS is a multiple of 128: the row XOR of gdst still applies)
+    bsum_on = i + 1 < nT;                                 // rows 1..3 stage tile i + 1
     auto row = [&](auto rc) {
       constexpr int r = decltype(rc)::value;
       constexpr int nky = r < 3 ? r + 1 : 6 - r;            // (ks, ky) pairs of this row: 1 2 3 3 2 1
@@ -391,6 +396,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
     };
     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{}); row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
+  }
+  // ---- bias gradient: the blocks of channel tile 0 saw every gradient tile of their filters exactly once
+  if (p.gbias && ct == 0) {
+    float v = bsum;
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);      // the four quarters of one filter row are neighbouring lanes
+    if (sq == 0) unsafeAtomicAdd(p.gbias + o0 + srow, v);
   }
   // ---- epilogue: D col = lane&31 -> c (contiguous in the slab), row -> o
   {
@@ -449,9 +460,9 @@ static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) 
 }
 
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
-                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s) {
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias) {
   WgradXArgs a;
-  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g;
+  a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g; a.gbias = gbias;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
   FR_CHECK(Cin % 64 == 0 && O % 64 == 0, "conv_wgradx: %d channels x %d filters is not a split-bf16 shape", Cin, O);
   FR_CHECK((long)Cin * H * W < (1L << 30) && (long)O * a.Ho * a.Wo < (1L << 30), "conv_wgradx: tensor too large for 32-bit offsets");
