@@ -2,32 +2,31 @@
 // objective.lua:189) in the split-bf16 operand form of convx.hip: fp32 tensors in and out, every product formed from six
 // exact bf16 x bf16 partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
 //
-//   gw[o][c][ky][kx] += sum_pix g[o][pix] * act(in)[c][pix + (ky,kx) - pad]
+//   gw[o][c][ky][kx] += sum_pix g[o][pix] * act(in)[c][pix + (ky,kx) - pad]          (+ optionally gbias[o] += sum_pix g[o][pix])
 //
 // GEMM view per tap: M = o, N = c, K = pixels -- BOTH operands are activations, so both are split while they are staged
-// (global -> registers -> PReLU / dropout scale -> three bf16 planes -> LDS).  The reduction index of an MFMA operand
-// lives inside the lane's 8-element vector, and a tap is a shift along that index: with pixel-contiguous operand rows
-// two of three taps would start 2 or 4 bytes off a 16-byte boundary.  The planes are therefore stored PIXEL-major,
-// [plane][8-channel group][position][8 channels] (the layout convx.hip stages), where a tap is a whole number of 16-byte
-// entries, and the fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16: per 16-lane group a
-// [4 pixels][16 channels] block comes back with lane = channel holding its 4 pixels (tools/tr_probe.hip prints the lane
-// map this kernel relies on: result lane i, element j  <-  supplier lane 4j + (i>>2), element i&3).
+// (global -> registers -> PReLU / dropout scale -> three bf16 planes -> LDS).  The reduction index of an MFMA operand lives
+// inside the lane's 8-element vector and a tap is a shift along that index.  Round 4 layout: the planes are PIXEL-CONTIGUOUS --
+// gradient [plane][o][4 rows x 16 px], patch [plane][c][6 rows][24 columns] -- read with plain 16-byte ds_read_b128, and the
+// column taps are cut IN REGISTERS: the 16 elements a lane reads of a patch row hold its 8 pixels at all three taps (tap kx
+// starts at element 3 + kx: one is the registers as they are, the other two are v_perm of neighbours).  (Rounds 2-3 kept the
+// planes pixel-major and fetched fragments with the transposing ds_read_b64_tr_b16: 8 bytes per lane, half the LDS rate, five
+// to nine LDS cycles per MFMA -- the kernel was LDS-bound at 0.37 of its peak.)
 //
-// Block = 64 o x 64 c x 9 taps (2 x 2 waves, nine 32x32 accumulators = 144 registers each), walking its share of 4 x 16
-// pixel tiles (K = 64 per tile: 216 MFMAs per wave).  ONE block per CU (<= 256 blocks), four waves of ~300 registers:
-//   * the 48 global loads of the NEXT tile are issued right before the products of the current one and stay in flight
-//     under its 216 MFMAs (with two 254-register blocks per CU -- rounds 1 and 2 -- there was no room to hold them: each
-//     tile paid its memory round trip in front of its products, covered only by the CU's other block);
-//   * the products walk the PATCH rows: the fragments of patch row r (three kx shifts x three planes) serve every
-//     (K step ks, tap row ky) with ks + ky = r, so each is read once instead of up to three times -- 132 transposed reads
-//     per wave and tile instead of 240 (ds_read_b64_tr_b16 moves ~50-64 B/clk: at 240 reads the LDS pipe was as busy as
-//     the matrix pipe);
-//   * a wave of this kernel leaves 200 registers per lane of its SIMD free, i.e. room for a wave of the main stream's
-//     convolution kernels beside it: launches alone take what they took (b2c2 167 vs 153 us), the training step is 1.5 %
-//     faster.
-// Tried and measured slower (all parity-green): the same with double-buffered LDS images and the next
-// tile's conversion interleaved into the products (189 us: the scheduler serialises conversion and MFMAs in one wave),
-// twelve waves = quadrants x tap rows or tap columns with three accumulators each and three waves per SIMD (205 / 174 us).
+// Block = 64 o x 64 c x 9 taps (2 x 2 waves, nine 32x32 accumulators = 144 AGPRs each), walking its share of 4 x 16 pixel
+// tiles (K = 64 per tile: 216 MFMAs per wave).  ONE block per CU, one wave per SIMD -- so nothing hides a wave's own
+// latencies but the wave itself, and the whole tile is ONE basic block laid out by hand (see the kernel's comment): LDS reads
+// of the next patch row, the tap cuts, the split of the NEXT tile into the other of two LDS images and the global loads of
+// the tile after it all ride between the MFMAs as micro-steps of about five VALU instructions, fenced by sched_barrier and
+// pinned by empty asm (the compiler's own order puts every read in front of its first use and every conversion behind the
+// last product).  One barrier per tile.
+//
+// Measured (MI355X, alone, with the fold): b2c2 167 -> 141 us, the six launches of a vgg_small step 845 -> 654 us;
+// SQ_LDS_IDX_ACTIVE 59 % -> 19 % of the launch, matrix pipe busy 43 % -> 61 %.  Tried on the way and dropped:
+// per-XCD fp32 atomics in L2 instead of slabs (correct -- blockIdx & 7 IS the XCC id -- but 320 G atomics/s make it no
+// faster than slab + fold), the scalar-base load form (7 % slower), sched_group_barrier (the greedy solver interleaves some
+// rows only, the exact one does not terminate), fp32 LDS images split behind the fragment reads (106 KB instead of 160:
+// 8 % slower alone, the step unchanged).
 // Partial sums go to slabs [split][tap][o][c] and are folded by wgrad_reduce_kernel (conv.hip) exactly as in the fp32
 // matrix-core kernel.
 #include <cstdlib>
