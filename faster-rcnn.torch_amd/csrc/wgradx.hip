@@ -179,8 +179,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // ---- the tiles of this block: t_i = split + i nSplit
   const int nPix = p.tilesX * p.tilesY;
   const int nT = (nPix - split + p.nSplit - 1) / p.nSplit;
-  float vg[4][4], vx[9][4];
-  int l_oy0 = 0, l_ox0 = 0;   // origin of the tile the registers hold
+  // TWO sets of prefetch registers: the loads of a tile are issued two tiles ahead (row 4 of tile i loads tile i + 3 into the set
+  // tile i + 1 has just been staged from), so that they have a whole tile -- 216 MFMAs, 4 us -- to arrive whatever the memory
+  // system's mood (with one set and one tile of lead a slow box spent three times as long in s_waitcnt: SQ_WAIT_ANY).
+  struct Pre {
+    float vg[4][4], vx[9][4];
+    bool ok[13];
+    int oy0, ox0;   // origin of the tile the set holds
+  };
+  Pre pre[2];
   // ---- the work that rides under the MFMAs, cut into MICRO-STEPS of about five VALU instructions.  Steps of item `it`
   // (0..3 gradient rows, 4..12 patch segments): load (one 16-byte segment, branch-free: a segment outside the image reads the
   // tensor's first elements and is zeroed later) | prepare (zero / activation) | split pair 0: level 1, levels 2 + 3 | split
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // block's last tile the walk stays on it (its loads and its staging are harmless repeats nobody reads)
   const int adv_y = p.nSplit / p.tilesX, adv_x = p.nSplit % p.tilesX;
   int w_ty = split / p.tilesX, w_tx = split % p.tilesX, w_i = 0;   // the tile the NEXT load_origin() call selects
-  auto load_origin = [&]() {
-    l_oy0 = w_ty * WX_TH; l_ox0 = w_tx * WX_TW;
+  auto load_origin = [&](Pre& P) {
+    P.oy0 = w_ty * WX_TH; P.ox0 = w_tx * WX_TW;
     const int more = w_i + 1 < nT ? 1 : 0;   // (selects, not branches: the tile loop body stays one basic block)
     w_tx += more * adv_x; w_ty += more * adv_y;
     const int wrap = w_tx >= p.tilesX ? 1 : 0;
@@ -205,65 +212,64 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   };
   // branch-free: a segment outside the image reads the tensor's first elements; the VEC form remembers one predicate per
   // segment (a lane mask in scalar registers) for the moment the values are split, the per-element form recomputes them
-  bool okit[13];
-  auto load_step = [&](auto itc) {
+  auto load_step = [&](auto itc, Pre& P) {
     constexpr int it = decltype(itc)::value;
-    const int oy0 = l_oy0, ox0 = l_ox0;
+    const int oy0 = P.oy0, ox0 = P.ox0;
     if constexpr (it < 4) {
       constexpr int k = it;
       const int oy = oy0 + k, ox = ox0 + 4 * sq;
       if (VEC) {
-        okit[it] = oy < p.Ho && ox < p.Wo;
-        const float4 v = *reinterpret_cast<const float4*>(gat((oy * p.Wo + ox) & -(int)okit[it]));
-        vg[k][0] = v.x; vg[k][1] = v.y; vg[k][2] = v.z; vg[k][3] = v.w;
+        P.ok[it] = oy < p.Ho && ox < p.Wo;
+        const float4 v = *reinterpret_cast<const float4*>(gat((oy * p.Wo + ox) & -(int)P.ok[it]));
+        P.vg[k][0] = v.x; P.vg[k][1] = v.y; P.vg[k][2] = v.z; P.vg[k][3] = v.w;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vg[k][e] = *gat((oy * p.Wo + ox + e) & -(int)(oy < p.Ho && ox + e < p.Wo));
+        for (int e = 0; e < 4; ++e) P.vg[k][e] = *gat((oy * p.Wo + ox + e) & -(int)(oy < p.Ho && ox + e < p.Wo));
       }
     } else {
       constexpr int k = it - 4;
       const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
       if (VEC) {
-        okit[it] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float4 v = *reinterpret_cast<const float4*>(xat((iy * p.W + ix) & -(int)okit[it]));
-        vx[k][0] = v.x; vx[k][1] = v.y; vx[k][2] = v.z; vx[k][3] = v.w;
+        P.ok[it] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float4 v = *reinterpret_cast<const float4*>(xat((iy * p.W + ix) & -(int)P.ok[it]));
+        P.vx[k][0] = v.x; P.vx[k][1] = v.y; P.vx[k][2] = v.z; P.vx[k][3] = v.w;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          vx[k][e] = *xat((iy * p.W + ix + e) & -(int)((unsigned)iy < (unsigned)p.H && (unsigned)(ix + e) < (unsigned)p.W));
+          P.vx[k][e] = *xat((iy * p.W + ix + e) & -(int)((unsigned)iy < (unsigned)p.H && (unsigned)(ix + e) < (unsigned)p.W));
       }
     }
   };
   // is element e of item `it` (as held in the registers) inside the image?
-  auto inside = [&](auto itc, int e) -> bool {
+  auto inside = [&](auto itc, int e, Pre& P) -> bool {
     constexpr int it = decltype(itc)::value;
-    if (VEC) return okit[it];
-    if constexpr (it < 4) return l_oy0 + it < p.Ho && l_ox0 + 4 * sq + e < p.Wo;
-    else return (unsigned)(l_oy0 - p.pad + xr[it < 4 ? 0 : it - 4]) < (unsigned)p.H &&
-                (unsigned)(l_ox0 - p.pad - 3 + 4 * xs[it < 4 ? 0 : it - 4] + e) < (unsigned)p.W;
+    if (VEC) return P.ok[it];
+    if constexpr (it < 4) return P.oy0 + it < p.Ho && P.ox0 + 4 * sq + e < p.Wo;
+    else return (unsigned)(P.oy0 - p.pad + xr[it < 4 ? 0 : it - 4]) < (unsigned)p.H &&
+                (unsigned)(P.ox0 - p.pad - 3 + 4 * xs[it < 4 ? 0 : it - 4] + e) < (unsigned)p.W;
   };
   // phases of an item, common numbering: 0..3 activation of a patch segment (one value each) | 4..7 split | 8 LDS writes.
   // Gradient items start at phase 4 (5 phases), patch items at 0 when there is an activation to apply (9), else at 4 (5).
   constexpr int XPH0 = (SLOPE || SCALE) ? 0 : 4;
-  auto stage_step = [&](auto itc, auto phc, unsigned gwb, unsigned xwb) {
+  auto stage_step = [&](auto itc, auto phc, unsigned gwb, unsigned xwb, Pre& P) {
     constexpr int it = decltype(itc)::value, ph = decltype(phc)::value;
     if constexpr (ph < 4) {
       constexpr int k = it - 4;
       {
         constexpr int e = ph;
-        float v = vx[k][e];
+        float v = P.vx[k][e];
         if (SLOPE) v = v > 0.f ? v : slope * v;
         if (SCALE) v *= xscale;
-        vx[k][e] = inside(itc, e) ? v : 0.f;
-        WX_PIN(vx[k][e]);
+        P.vx[k][e] = inside(itc, e, P) ? v : 0.f;
+        WX_PIN(P.vx[k][e]);
       }
     } else if constexpr (ph == 4 || ph == 6) {
       constexpr int j = (ph - 4) / 2;
-      float x0 = it < 4 ? vg[it < 4 ? it : 0][2 * j] : vx[it < 4 ? 0 : it - 4][2 * j];
-      float x1 = it < 4 ? vg[it < 4 ? it : 0][2 * j + 1] : vx[it < 4 ? 0 : it - 4][2 * j + 1];
+      float x0 = it < 4 ? P.vg[it < 4 ? it : 0][2 * j] : P.vx[it < 4 ? 0 : it - 4][2 * j];
+      float x1 = it < 4 ? P.vg[it < 4 ? it : 0][2 * j + 1] : P.vx[it < 4 ? 0 : it - 4][2 * j + 1];
       if (it < 4 || XPH0 == 4) {   // (patch segments with an activation were zeroed when it was applied)
-        x0 = inside(itc, 2 * j) ? x0 : 0.f;
-        x1 = inside(itc, 2 * j + 1) ? x1 : 0.f;
+        x0 = inside(itc, 2 * j, P) ? x0 : 0.f;
+        x1 = inside(itc, 2 * j + 1, P) ? x1 : 0.f;
       }
       if (it < 4) bsum += bsum_on ? x0 + x1 : 0.f;
       sh[it][j] = wx_cvt2(x0, x1);
@@ -286,13 +292,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
     }
   };
   // step s of the staging sequence of items [I0, I1): item-major, each item's phases in order
-  auto stage_seq = [&](auto i0c, auto sc, unsigned gwb, unsigned xwb) {
+  auto stage_seq = [&](auto i0c, auto sc, unsigned gwb, unsigned xwb, Pre& P) {
     constexpr int I0 = decltype(i0c)::value, s = decltype(sc)::value;
     constexpr int NG = I0 < 4 ? 4 - I0 : 0;                     // gradient items at the head of the range (5 phases each)
     constexpr int NPX = 9 - XPH0;                               // phases of a patch item
     constexpr int it = s < 5 * NG ? I0 + s / 5 : I0 + NG + (s - 5 * NG) / NPX;
     constexpr int ph = s < 5 * NG ? 4 + s % 5 : XPH0 + (s - 5 * NG) % NPX;
-    stage_step(std::integral_constant<int, it>{}, std::integral_constant<int, ph>{}, gwb, xwb);
+    stage_step(std::integral_constant<int, it>{}, std::integral_constant<int, ph>{}, gwb, xwb, P);
   };
 
   // ---- K = the tile's 64 pixels: K step ks = tile row ks (16 pixels), lane half h takes pixels 8h..8h+7 of it.  The products
@@ -333,13 +339,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   };
 
   // ---- prologue: tile 0 into image 0, tile 1 into the registers, row 0 of tile 0 into fragments
-  load_origin();
-  static_for<13>([&](auto itc) { load_step(itc); });
+  load_origin(pre[0]);
+  static_for<13>([&](auto itc) { load_step(itc, pre[0]); });
   constexpr int NST = 4 * 5 + 9 * (9 - XPH0);   // staging steps of a whole tile
-  static_for<NST>([&](auto sc) { stage_seq(std::integral_constant<int, 0>{}, sc, gdst, xdst); });
+  static_for<NST>([&](auto sc) { stage_seq(std::integral_constant<int, 0>{}, sc, gdst, xdst, pre[0]); });
   __syncthreads();
-  load_origin();
-  static_for<13>([&](auto itc) { load_step(itc); });
+  load_origin(pre[1]);                                                // tile 1
+  static_for<13>([&](auto itc) { load_step(itc, pre[1]); });
+  load_origin(pre[0]);                                                // tile 2
+  static_for<13>([&](auto itc) { load_step(itc, pre[0]); });
   read_row(0, 0);
   static_for<6>([&](auto sc) { cut_step(sc); });
 #pragma unroll
@@ -347,7 +355,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) b[kx][pl] = bn[kx][pl];
 
-  for (int i = 0; i < nT; ++i) {
+  // tile i: products from image i & 1; tile i + 1 is staged from set P (= (i + 1) & 1), which then receives tile i + 3
+  auto tile = [&](int i, Pre& P) {
     const unsigned rb = (i & 1) ? WX_LDS : 0, wb = WX_LDS - rb;
     const unsigned gwb = gdst + wb, xwb = xdst + wb;   // (WX_LDS is a multiple of 128: the row XOR of gdst still applies)
     bsum_on = i + 1 < nT;                                 // rows 1..3 stage tile i + 1
@@ -379,10 +388,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
           if constexpr (s >= NSTG) {
             cut_step(std::integral_constant<int, s - NSTG>{});
           } else if constexpr (r >= 1 && r <= 3) {   // items 0..4 | 5..8 | 9..12
-            stage_seq(std::integral_constant<int, r == 1 ? 0 : r == 2 ? 5 : 9>{}, std::integral_constant<int, s>{}, gwb, xwb);
+            stage_seq(std::integral_constant<int, r == 1 ? 0 : r == 2 ? 5 : 9>{}, std::integral_constant<int, s>{}, gwb, xwb, P);
           } else {
-            if constexpr (s == 0) load_origin();   // tile i + 2: the staging of tile i + 1 is complete
-            load_step(std::integral_constant<int, s>{});
+            if constexpr (s == 0) load_origin(P);   // tile i + 3: the staging of tile i + 1 out of this set is complete
+            load_step(std::integral_constant<int, s>{}, P);
           }
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -395,6 +404,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
     };
     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
     row(std::integral_constant<int, 3>{}); row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{});
+  };
+  {
+    int i = 0;
+    for (; i + 1 < nT; i += 2) { tile(i, pre[1]); tile(i + 1, pre[0]); }
+    if (i < nT) tile(i, pre[1]);
   }
   // ---- bias gradient: the blocks of channel tile 0 saw every gradient tile of their filters exactly once
   if (p.gbias && ct == 0) {

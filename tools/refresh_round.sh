@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): every measurement that profiles/ holds for one round, from the current tree, into
 # gpurun_out/<tag>/ (copy what should be judged into profiles/).  usage: bash tools/refresh_round.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
+export FRCNN_GIT_HASH=${2:-${FRCNN_GIT_HASH:-unknown}}   # the tree the measurements belong to (the GPU box has no .git): pass `git rev-parse --short HEAD`
 R=/root/repo; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-upload-leg"
 # 1. PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes)
@@ -66,5 +67,14 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/detect -- python $R/tools/bench_detect.py 30 > $O/detect.log 2>&1
 cd $R
 cp $O/detect/*/*kernel_stats.csv $O/${TAG}_detect_kernel_stats.csv 2>/dev/null
-rm -rf $O/fetch $O/write $O/mfma $O/stats $O/detect
+# 6. the weight-gradient kernel by itself: per-launch durations of kernel and fold, and the PMC groups behind the LDS / matrix-pipe figures
+{
+  echo "# conv_wgradx_kernel + wgrad_reduce4_kernel per layer -- bash tools/ktrace.sh wgrad -- python tools/bench_conv.py wgrad <layers>"
+  bash tools/ktrace.sh wgrad -- python $R/tools/bench_conv.py wgrad b2c1 b2c2 b3c1 b3c2 b4c1 b4c2 2>/dev/null
+  echo "# PMC groups, b2c2 (128 -> 128 @ 225x400), 256 blocks of 4 waves -- bash tools/pmc_kernels.sh <dir> wgradx -- python tools/bench_conv.py wgrad b2c2"
+  bash tools/pmc_kernels.sh $O/pmcw wgradx -- python $R/tools/bench_conv.py wgrad b2c2 2>/dev/null
+} > $O/${TAG}_wgradx_evidence.txt 2>&1
+# 7. the un-profiled timeline of one step from the library's own event brackets
+python tools/ev_timeline.py 3 > $O/${TAG}_ev_timeline.txt 2>/dev/null
+rm -rf $O/fetch $O/write $O/mfma $O/stats $O/detect $O/pmcw
 ls -la $O | head -40
