@@ -75,7 +75,7 @@ int frcnn_device_name(char* buf, int len) {
 }
 
 int frcnn_malloc(void** ptr, size_t bytes) {
-  FR_HIP(hipMalloc(ptr, bytes ? bytes : 16));
+  FR_HIP(hipMalloc(ptr, (bytes ? bytes : 16) + 64));   // (64 bytes of slack, as the model's own buffers: see conv_wgradx's loaders)
   return FRCNN_OK;
 }
 int frcnn_free(void* ptr) {

@@ -32,7 +32,7 @@ struct DevBuf {
     if (p && owned) (void)hipFree(p);
     owned = true;
     p = nullptr; bytes = 0;
-    FR_HIP(hipMalloc(&p, need));
+    FR_HIP(hipMalloc(&p, need + 64));   // (64 bytes of slack: conv_wgradx's unaligned 16-byte segment loads may read 12 bytes past a tensor)
     bytes = need;
     return FRCNN_OK;
   }

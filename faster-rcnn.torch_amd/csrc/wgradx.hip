@@ -95,6 +95,7 @@ __device__ __forceinline__ unsigned wx_xaddr(int c) { return (unsigned)(c * WX_X
 __device__ __forceinline__ unsigned wx_gswz(int o) { const unsigned u = (o >> 1) & 7; return ((u & 3) << 1) | (u >> 2); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte load the compiler may not assume aligned
 
 // Pins a value at this point of the instruction stream: an empty volatile asm that "modifies" it.  sched_barrier fences the
 // machine scheduler, but instruction selection is free to sink side-effect-free arithmetic down to its first use -- without
@@ -110,8 +111,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// VEC: every 4-pixel segment is one aligned 16-byte load (pad = 1, W % 4 = 0, 16-byte aligned tensors); otherwise four
-// predicated dword loads per segment (any shape)
+// VEC = 1: every 4-pixel segment is one aligned 16-byte load that lies inside a row or outside the image as a whole (pad = 1,
+// W % 4 = 0, 16-byte aligned tensors).  VEC = 2: one UNALIGNED 16-byte load per segment for any width (pad = 1): a segment may
+// hang over the end of its row -- those elements are zeroed when the values are split -- and the last one of the tensor reads up
+// to 12 bytes past its end, which the launcher only allows when the allocation is known to extend that far.  VEC = 0: four
+// predicated dword loads per segment (any shape).
 //
 // One block per CU, one wave per SIMD, and ONE basic block per tile in which everything overlaps (the order is laid down
 // with sched_group_barrier, the compiler on its own puts every LDS read right in front of its first use and every
@@ -121,7 +125,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //                                * rows 1..3: the split of tile i + 1 (in registers since tile i - 1) and its LDS writes into
 //                                  the OTHER LDS image,
 //   after row 4: one barrier, the global loads of tile i + 2, and row 0 of tile i + 1 is read under the MFMAs of row 5.
-template <bool SLOPE, bool SCALE, bool VEC>
+template <bool SLOPE, bool SCALE, int VEC>
 __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // two images of WX_LDS bytes: [G planes][X planes]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -220,8 +224,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
       const int oy = oy0 + k, ox = ox0 + 4 * sq;
       if (VEC) {
         P.ok[it] = oy < p.Ho && ox < p.Wo;
-        const float4 v = *reinterpret_cast<const float4*>(gat((oy * p.Wo + ox) & -(int)P.ok[it]));
-        P.vg[k][0] = v.x; P.vg[k][1] = v.y; P.vg[k][2] = v.z; P.vg[k][3] = v.w;
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(gat((oy * p.Wo + ox) & -(int)P.ok[it]));
+        P.vg[k][0] = v[0]; P.vg[k][1] = v[1]; P.vg[k][2] = v[2]; P.vg[k][3] = v[3];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) P.vg[k][e] = *gat((oy * p.Wo + ox + e) & -(int)(oy < p.Ho && ox + e < p.Wo));
@@ -230,9 +234,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
       constexpr int k = it - 4;
       const int iy = oy0 - p.pad + xr[k], ix = ox0 - p.pad - 3 + 4 * xs[k];
       if (VEC) {
-        P.ok[it] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float4 v = *reinterpret_cast<const float4*>(xat((iy * p.W + ix) & -(int)P.ok[it]));
-        P.vx[k][0] = v.x; P.vx[k][1] = v.y; P.vx[k][2] = v.z; P.vx[k][3] = v.w;
+        P.ok[it] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;   // (pad = 1: ix is -4 or >= 0)
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(xat((iy * p.W + ix) & -(int)P.ok[it]));
+        P.vx[k][0] = v[0]; P.vx[k][1] = v[1]; P.vx[k][2] = v[2]; P.vx[k][3] = v[3];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -243,7 +247,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // is element e of item `it` (as held in the registers) inside the image?
   auto inside = [&](auto itc, int e, Pre& P) -> bool {
     constexpr int it = decltype(itc)::value;
-    if (VEC) return P.ok[it];
+    if (VEC == 1) return P.ok[it];
+    if (VEC == 2) {   // the segment's predicate from load time, and the element's own column
+      if constexpr (it < 4) return P.ok[it] && P.ox0 + 4 * sq + e < p.Wo;
+      else return P.ok[it] && P.ox0 - p.pad - 3 + 4 * xs[it < 4 ? 0 : it - 4] + e < p.W;
+    }
     if constexpr (it < 4) return P.oy0 + it < p.Ho && P.ox0 + 4 * sq + e < p.Wo;
     else return (unsigned)(P.oy0 - p.pad + xr[it < 4 ? 0 : it - 4]) < (unsigned)p.H &&
                 (unsigned)(P.ox0 - p.pad - 3 + 4 * xs[it < 4 ? 0 : it - 4] + e) < (unsigned)p.W;
@@ -446,7 +454,7 @@ size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad) {
   return (size_t)a.nSplit * 9 * O * Cin * 4 + 256;
 }
 
-template <bool SLOPE, bool SCALE, bool VEC>
+template <bool SLOPE, bool SCALE, int VEC>
 static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -465,11 +473,32 @@ static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s
   return FRCNN_OK;
 }
 
+// does the allocation `p` lives in extend at least `slack` bytes past p + bytes?  (hipMemGetAddressRange; answers are cached per
+// allocation base: the model's tensors are allocated once per image size)
+static bool readable_past_end(const void* p, size_t bytes, size_t slack) {
+  struct Range { uintptr_t base, end; };
+  static Range cache[16];
+  static int ncache = 0;
+  const uintptr_t a = (uintptr_t)p;
+  for (int i = 0; i < ncache; ++i)
+    if (a >= cache[i].base && a < cache[i].end) return a + bytes + slack <= cache[i].end;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const Range r{(uintptr_t)base, (uintptr_t)base + size};
+  cache[ncache < 16 ? ncache++ : (ncache = 1, 0)] = r;
+  return a + bytes + slack <= r.end;
+}
+
 template <bool SLOPE, bool SCALE>
 static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
-  // one aligned 16-byte load per 4-pixel segment when every segment lies inside a row or outside the image as a whole
-  const bool vec = a.pad == 1 && a.W % 4 == 0 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.g & 15) == 0;
-  return vec ? launch_wgradx_v<SLOPE, SCALE, true>(a, flops, gw, s) : launch_wgradx_v<SLOPE, SCALE, false>(a, flops, gw, s);
+  // one aligned 16-byte load per 4-pixel segment when every segment lies inside a row or outside the image as a whole; one
+  // unaligned one when the width is arbitrary and the 12 bytes behind both tensors belong to their allocations
+  if (a.pad == 1 && a.W % 4 == 0 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.g & 15) == 0)
+    return launch_wgradx_v<SLOPE, SCALE, 1>(a, flops, gw, s);
+  if (a.pad == 1 && readable_past_end(a.in, (size_t)a.Cin * a.H * a.W * 4, 12) && readable_past_end(a.g, (size_t)a.O * a.Ho * a.Wo * 4, 12))
+    return launch_wgradx_v<SLOPE, SCALE, 2>(a, flops, gw, s);
+  return launch_wgradx_v<SLOPE, SCALE, 0>(a, flops, gw, s);
 }
 
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,

@@ -177,7 +177,7 @@ def test_exactness_properties_at_full_size(F):
 
 
 @pytest.mark.parametrize("C_,H,W,O_,pad", [(64, 57, 100, 128, 1), (128, 29, 50, 64, 1), (256, 38, 63, 512, 1), (64, 9, 11, 64, 1),
-                                            (64, 31, 45, 64, 0)])
+                                            (64, 31, 45, 64, 0), (64, 75, 125, 64, 1), (128, 37, 250, 64, 1)])
 def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
     """accGradParameters (csrc/wgradx.hip): both operands split while they are staged into pixel-contiguous planes."""
     rng = np.random.RandomState(C_ * 13 + O_)
