@@ -99,6 +99,7 @@ _SIGS = {
     "frcnn_pnet_wait_block_gradients": ([vp, C.c_int, vp], C.c_int),
     "frcnn_cnet_forward": ([vp, vp, vp, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_backward": ([vp, vp, vp, vp, vp, vp, vp], C.c_int),
+    "frcnn_cnet_backward_join": ([vp, vp], C.c_int),
     "frcnn_cnet_losses": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp], C.c_int),
     "frcnn_cnet_decode": ([vp, C.c_int, C.c_int, vp, vp, vp], C.c_int),
     "frcnn_anchors_create": ([vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),

@@ -79,6 +79,7 @@ struct ClsLayer {
   float p_drop;
   long w_off, b_off, bnw_off, bnb_off, a_off;
   DevBuf lin, pre, post, xhat, invstd, mask, g;
+  DevBuf gin;                 // gradient wrt this layer's input (layers > 0; a buffer of its own: the weight gradient reads the input beside it)
   DevBuf xp, xpT, gp, gpT;    // split-bf16 planes of the layer's input and of its output gradient (gemmx.hip), when it takes that form
   int x_form = 0;             // set per call: which of this layer's products run in the split-bf16 operand form
                               // (bit 1 forward, 2 input gradient, 4 weight gradient: linear_x_eligible)
@@ -107,6 +108,10 @@ struct frcnn_model {
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
+  hipStream_t cw = nullptr;        // the classification net's weight gradients / bias sums (beside its input-gradient chain)
+  hipEvent_t cw_fork = nullptr, cw_done = nullptr;
+  bool cw_pending = false;         // work on `cw` that no stream has been made to wait for yet
+  std::vector<hipEvent_t> cw_ev;   // one fork point per layer + one for the two heads
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   bool heads_begun = false;        // anchor-net backward already running on the side stream
@@ -383,6 +388,10 @@ int frcnn_model_destroy(frcnn_model* m) {
   }
   if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+  for (auto e : m->cw_ev) (void)hipEventDestroy(e);
+  if (m->cw_fork) (void)hipEventDestroy(m->cw_fork);
+  if (m->cw_done) (void)hipEventDestroy(m->cw_done);
+  if (m->cw) (void)hipStreamDestroy(m->cw);
   if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
   for (auto e : m->block_ev) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
@@ -434,12 +443,32 @@ static bool side_enabled() {
   return g_side_stream != 0;
 }
 
+// The classification net's weight-gradient products and bias sums are needed by nobody before the optimiser (or the exchange of
+// the cnet slice): with the option on (default) frcnn_cnet_backward queues them on a stream of their own, beside the
+// input-gradient chain that the ROI-pooling backward and the backbone wait for, and returns with that stream still busy --
+// frcnn_pnet_backward, the next frcnn_cnet_forward and frcnn_cnet_backward_join make the caller's stream wait for it.
+static int g_cnet_wgrad_async = getenv("FRCNN_CNET_WGRAD_ASYNC") ? (atoi(getenv("FRCNN_CNET_WGRAD_ASYNC")) != 0) : 1;
+
+static int cw_join(frcnn_model* m, hipStream_t s) {
+  if (m->cw_pending) {
+    FR_HIP(hipStreamWaitEvent(s, m->cw_done, 0));
+    m->cw_pending = false;
+  }
+  return FRCNN_OK;
+}
+
+int frcnn_cnet_backward_join(frcnn_model* m, void* stream) {
+  FR_CHECK(m != nullptr, "cnet_backward_join: null model");
+  return cw_join(m, S(stream));
+}
+
 int frcnn_get_option(const char* name, int* value) {
   FR_CHECK(name != nullptr && value != nullptr, "get_option: null argument");
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { *value = get_gemm_x_roles(); return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "winograd") == 0) { *value = 0; return FRCNN_OK; }   // removed in round 3; kept as a name that reads 0
+  if (strcmp(name, "cnet_wgrad_async") == 0) { *value = g_cnet_wgrad_async; return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
@@ -452,6 +481,7 @@ int frcnn_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   if (strcmp(name, "winograd") == 0) return FRCNN_OK;   // deprecated no-op: the Winograd kernels were removed in round 3
+  if (strcmp(name, "cnet_wgrad_async") == 0) { g_cnet_wgrad_async = value ? 1 : 0; return FRCNN_OK; }
   FR_CHECK(false, "set_option: unknown option '%s'", name);
   return FRCNN_OK;
 }
@@ -466,9 +496,11 @@ static int ensure_side(frcnn_model* m) {
     // a 1 x 1 convolution on a pooled map; backward on the sampled anchors ~17 small launches each), so that their chains
     // run beside each other instead of one after the other.  Measured on the training step: the anchor nets' backward
     // chains shrink from 670 to 310 us, but the classification net's chain on the caller's stream, which runs beside them,
-    // slows down by as much (both are bound by the launch rate of small kernels): 223.6 against 225.4 images/s.  Off by
-    // default: all anchor nets on the one side stream.
-    static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 0;
+    // slows down by as much: 223.6 against 225.4 images/s (round 2).  Round 4: the two chains of the middle phase -- the
+    // anchor nets' and the classification net's -- are about equally long, so shortening ONE of them changes nothing; with
+    // the classification net's weight gradients off its chain as well (g_cnet_wgrad_async) the step goes from 3.11 to
+    // 3.02 ms, with either change alone it stays at 3.11.  On by default since then.
+    static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 1;
     for (auto& h : m->heads) {
       if (head_streams) FR_HIP(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
       FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
@@ -797,7 +829,9 @@ static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
   // groups, so as soon as ONE net is dense every net runs on the side stream, one after the other.
   bool any_dense = false;
   for (size_t i = 0; i < m->heads.size(); ++i) any_dense = any_dense || !head_is_sparse(m->heads[i]);
-  if (any_dense) std::fill(own.begin(), own.end(), 0);
+  // Deterministic mode: the order-independent forms (the gathering col2im, in-order folds) assume ONE writer of the shared
+  // pooled-map gradient at a time.
+  if (any_dense || deterministic()) std::fill(own.begin(), own.end(), 0);
   for (size_t i = 0; i < m->heads.size(); ++i) {
     Head& h = m->heads[i];
     if (!own[i]) continue;
@@ -982,6 +1016,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     }
   }
   m->block_ev_valid = true;
+  FR_TRY(cw_join(m, s));   // the classification net's weight gradients (frcnn_cnet_backward) belong to the same gradient vector
   if (use_side) {   // the caller's stream continues after every weight gradient has landed
     FR_HIP(hipEventRecord(m->join_ev, ws));
     FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
@@ -998,6 +1033,7 @@ static int ensure_cnet(frcnn_model* m, int R) {
     if (L.bn) { FR_TRY(L.pre.ensure(n)); FR_TRY(L.xhat.ensure(n)); FR_TRY(L.invstd.ensure((size_t)L.n * 4)); }
     FR_TRY(L.post.ensure(n));
     FR_TRY(L.g.ensure(n));
+    FR_TRY(L.gin.ensure((size_t)R * L.in * 4));
     if (L.p_drop > 0.f) FR_TRY(L.mask.ensure(n));
     L.x_form = 0;
     for (int role : {1, 2, 4}) if (linear_x_eligible(role, R, L.in, L.n)) L.x_form |= role;
@@ -1020,6 +1056,7 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
                        float* bbox_out, float* cls_out, void* stream) {
   hipStream_t s = S(stream);
   FR_CHECK(R > 0, "cnet_forward: empty batch");
+  FR_TRY(cw_join(m, s));   // (weight gradients of a previous backward pass still read the buffers written below)
   FR_TRY(ensure_cnet(m, R));
   m->R = R; m->cnet_x = x; m->training = training;
   const float* w = weights;
@@ -1077,15 +1114,38 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
   const int nf = m->cls.empty() ? m->D : m->cls.back().n;
   const int nc = m->d.class_count + 1;
   const float* feat = m->cls.empty() ? m->cnet_x : m->cls.back().post.f();
-  // bbox head
-  FR_TRY(gemm_f32(g_bbox, 4, 1, w + m->bbox_w_off, nf, 1, m->feat_g.f(), nf, R, nf, 4, OUT_STORE, nullptr, s));
-  FR_TRY(gemm_f32(g_bbox, 1, 4, feat, nf, 1, grad + m->bbox_w_off, nf, 4, nf, R, OUT_ADD, nullptr, s));
-  FR_TRY(channel_sum_cols(g_bbox, R, 4, grad + m->bbox_b_off, s));
-  // class head (LogSoftMax backward first)
+  // `s` carries the input-gradient chain (what roi_pool_backward and the backbone wait for); the weight-gradient products and
+  // bias sums go to `ws`: a stream of their own (see g_cnet_wgrad_async), or `s` itself
+  FR_TRY(cw_join(m, s));
+  const bool async = g_cnet_wgrad_async && !deterministic();
+  if (async && !m->cw) {
+    FR_HIP(hipStreamCreateWithFlags(&m->cw, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&m->cw_done, hipEventDisableTiming));
+  }
+  while (async && m->cw_ev.size() < m->cls.size() + 1) {
+    hipEvent_t e;
+    FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->cw_ev.push_back(e);
+  }
+  hipStream_t ws = async ? m->cw : s;
+  const int wslot = async ? 7 : 0;     // split-K workspace of the products on `ws`
+  size_t nfork = 0;
+  auto fork = [&]() -> int {           // everything queued on `s` so far is final for `ws`
+    if (!async) return FRCNN_OK;
+    FR_HIP(hipEventRecord(m->cw_ev[nfork], s));
+    FR_HIP(hipStreamWaitEvent(ws, m->cw_ev[nfork], 0));
+    ++nfork;
+    return FRCNN_OK;
+  };
+  // heads: LogSoftMax backward first, then the two input gradients on the chain, the two weight gradients beside it
   FR_TRY(log_softmax_backward(g_cls, m->lsm.f(), R, nc, m->glog.f(), s));
+  FR_TRY(fork());
+  FR_TRY(gemm_f32(g_bbox, 4, 1, w + m->bbox_w_off, nf, 1, m->feat_g.f(), nf, R, nf, 4, OUT_STORE, nullptr, s));
   FR_TRY(gemm_f32(m->glog.f(), nc, 1, w + m->clsw_off, nf, 1, m->feat_g.f(), nf, R, nf, nc, OUT_ADD, nullptr, s));
-  FR_TRY(gemm_f32(m->glog.f(), 1, nc, feat, nf, 1, grad + m->clsw_off, nf, nc, nf, R, OUT_ADD, nullptr, s));
-  FR_TRY(channel_sum_cols(m->glog.f(), R, nc, grad + m->clsb_off, s));
+  FR_TRY(gemm_f32(g_bbox, 1, 4, feat, nf, 1, grad + m->bbox_w_off, nf, 4, nf, R, OUT_ADD, nullptr, ws, wslot));
+  FR_TRY(channel_sum_cols(g_bbox, R, 4, grad + m->bbox_b_off, ws));
+  FR_TRY(gemm_f32(m->glog.f(), 1, nc, feat, nf, 1, grad + m->clsw_off, nf, nc, nf, R, OUT_ADD, nullptr, ws, wslot));
+  FR_TRY(channel_sum_cols(m->glog.f(), R, nc, grad + m->clsb_off, ws));
   const float* g = m->feat_g.f();
   for (int l = (int)m->cls.size() - 1; l >= 0; --l) {
     ClsLayer& L = m->cls[l];
@@ -1096,33 +1156,33 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     if (L.bn)
       FR_TRY(bn_backward(L.g.f(), L.xhat.f(), L.invstd.f(), w + L.bnw_off, R, L.n, m->training, L.g.f(),
                          grad + L.bnw_off, grad + L.bnb_off, s));
+    FR_TRY(fork());   // L.g is final
     const float* in = l == 0 ? m->cnet_x : m->cls[l - 1].post.f();
-    float* gin = l == 0 ? gx : m->cls[l - 1].post.f();  // post[l-1] is dead after this point: reuse as gradient
-    if (L.x_form & 6) {   // the gradient's planes once, in the orientations the split-form products of this layer read
-      const bool xw = (L.x_form & 4) != 0, xd = (L.x_form & 2) != 0 && gin;
-      if (xw || xd) FR_TRY(split_planes(L.g.f(), R, L.n, xd ? L.gp.p : nullptr, xw ? L.gpT.p : nullptr, s));
-      if (xw) {
-        FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, s));
-        FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, s));
-      } else {
-        FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
-      }
-      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
-      if (xd) FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
-      else if (gin) FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
-    } else if (l > 0) {
-      // gradient wrt post[l-1] must not overwrite `in` before the weight gradient used it
-      FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
-      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
+    float* gin = l == 0 ? gx : L.gin.f();
+    const bool xw = (L.x_form & 4) != 0, xd = (L.x_form & 2) != 0 && gin;
+    // chain: the gradient's planes (row-major orientation) and the input-gradient product
+    if (xd) {
+      FR_TRY(split_planes(L.g.f(), R, L.n, L.gp.p, nullptr, s));
+      FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
+    } else if (gin) {
       FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
-    } else {
-      FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, s));
-      FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, s));
-      if (gin) FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
     }
+    // beside it: the weight gradient (planes in the transposed orientation) and the bias sums
+    if (xw) {
+      FR_TRY(split_planes(L.g.f(), R, L.n, nullptr, L.gpT.p, ws));
+      FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, ws));
+      FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, ws, wslot));
+    } else {
+      FR_TRY(gemm_f32(L.g.f(), 1, L.n, in, L.in, 1, grad + L.w_off, L.in, L.n, L.in, R, OUT_ADD, nullptr, ws, wslot));
+    }
+    FR_TRY(channel_sum_cols(L.g.f(), R, L.n, grad + L.b_off, ws));
     g = gin;
   }
   if (m->cls.empty() && gx) FR_HIP(hipMemcpyAsync(gx, g, (size_t)R * m->D * 4, hipMemcpyDeviceToDevice, s));
+  if (async) {
+    FR_HIP(hipEventRecord(m->cw_done, ws));
+    m->cw_pending = true;
+  }
   return FRCNN_OK;
 }
 

@@ -338,6 +338,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 # the classification net's slice of the flat gradient (55 % of it) is final, and so is the anchor
                 # nets' slice once the side stream's part is joined: their all-reduces run beside the backbone's
                 # backward pass; only the backbone's 3.3 M elements remain for the end
+                _lib.call("frcnn_cnet_backward_join", native.h, stream_ptr())   # its weight gradients ride on a stream of their own
                 pending.append(allreduce_begin(gradient, native.pnet_params, gradient.numel()))
                 # The decision must not depend on this rank's data (every rank issues the same collectives): with the
                 # side stream on and one image per batch the slice is final here on every rank -- either the

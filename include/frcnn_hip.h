@@ -344,6 +344,11 @@ int frcnn_cnet_forward(frcnn_model *, const float *weights, const float *x, int 
                        const float *const *drop_masks_host, unsigned long long seed,
                        float *bn_running, float *bbox_out, float *cls_out, void *stream);
 /* cnet:backward(cinput, {crdelta, ccdelta}) (objective.lua:179) -> gx [R][D] */
+/* cnet:backward.  The input gradient gx is final on `stream` in stream order; the weight gradients and bias sums it adds to
+ * `grad` are queued on a library-owned stream beside that chain (option "cnet_wgrad_async", default 1) and are final on
+ * `stream` after frcnn_pnet_backward, the next frcnn_cnet_forward, or frcnn_cnet_backward_join -- or after a device-wide
+ * synchronisation. */
+int frcnn_cnet_backward_join(frcnn_model *, void *stream);
 int frcnn_cnet_backward(frcnn_model *, const float *weights, const float *g_bbox,
                         const float *g_cls, float *gx, float *grad, void *stream);
 /* objective.lua:170-177: zero negative rows of crout, SmoothL1*10 and ClassNLL with gradients.
