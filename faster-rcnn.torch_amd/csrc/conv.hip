@@ -978,6 +978,55 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nSplit, 
   }
 }
 
+// The same fold for a SMALL result under MANY slabs (first layer: 1728 elements x 512 slabs): 16 elements x 64 slab groups per
+// block, so every thread has its (up to 8) loads in flight at once -- the kernel above walked 128 slabs per thread four at a
+// time on 27 blocks (~12 us of the first layer's ~48).  Same fixed summation order on every run.
+__global__ __launch_bounds__(1024) void wgrad_reduce_tall_kernel(const float* __restrict__ slab, int nSplit, int taps, int OC,
+                                                                 float* __restrict__ gw, int nExtra, float* __restrict__ gbias,
+                                                                 float* __restrict__ gslope) {
+  __shared__ float sh[64][17];
+  const int total = taps * OC + nExtra;   // per slab: [tap][o][c], then (fused first layer) O bias sums and the slope sum
+  const int tx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + tx;
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = 0.f;
+  if (t < total) {
+    for (int s0 = g; s0 < nSplit; s0 += 512) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int s = s0 + 64 * i;
+        if (s < nSplit) a[i] += slab[(size_t)s * total + t];
+      }
+    }
+  }
+  sh[g][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+#pragma unroll
+  for (int w = 32; w > 0; w >>= 1) {
+    if (g < w) sh[g][tx] += sh[g + w][tx];
+    __syncthreads();
+  }
+  if (g == 0 && t < total) {
+    if (t < taps * OC) {
+      const int tap = t / OC, oc = t - tap * OC;
+      gw[(size_t)oc * taps + tap] += sh[0][tx];
+    } else if (t < total - 1) {
+      if (gbias) gbias[t - taps * OC] += sh[0][tx];
+    } else if (gslope) {
+      *gslope += sh[0][tx];
+    }
+  }
+}
+static void wgrad_reduce_first(const float* slab, int nSplit, int OC, float* gw, hipStream_t s, int nExtra = 0, float* gbias = nullptr,
+                               float* gslope = nullptr) {
+  if (nSplit >= 128 || nExtra)
+    hipLaunchKernelGGL(wgrad_reduce_tall_kernel, dim3(cdiv(9 * OC + nExtra, 16)), dim3(1024), 0, s, slab, nSplit, 9, OC, gw, nExtra, gbias,
+                       gslope);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<long>(cdivl(9L * OC, 64), 4096)), dim3(256), 0, s, slab, nSplit, 9, OC, gw);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight gradient of the FIRST layer (Cin*k*k <= 32, O <= 64: 3 -> 64 @ 450x800).  With three input
 // channels the (o, c) tiling above would leave 29 of 32 MFMA columns empty, so here the GEMM is
@@ -987,8 +1036,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nSplit, 
 #define W1_TH 4
 #define W1_TW 64
 #define W1_GP 257   // odd pitch of gs[o][256]
-template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_first_kernel(WgradArgs p) {
+#define W1_PATCH ((3 * (W1_TH + 2) * (W1_TW + 2) + 255) / 256 * 256)   // floats of the input patch (<= 3 channels), whole passes of 256
+// FUSED (round 4): the gradient tile is not read but COMPUTED while it is staged -- the 2x2 max-pooling backward and the PReLU
+// backward of the layer's own output (elem.hip act_backward_kernel<POOLED>): g = (the window's winner ? gpooled : 0) * prelu'(x)
+// -- so the full-resolution gradient (92 MB for 64 x 450 x 800) is neither written nor read back.  The slope gradient leaves
+// through one atomic per block; the bias gradient is column 27 of the product: a B column of ones sums g over the pixels.
+struct WgradFirstFused {
+  const float* gpool;            // [O][Hp][Wp] gradient of the pooled map
+  const unsigned char* pidx;     // [O][Hp][Wp] winner code 2 * (y & 1) + (x & 1)
+  const float* x;                // [O][Ho][Wo] pre-activation output of this convolution
+  const float* slope;            // device scalar
+  float* gslope;                 // device scalar, accumulated
+  float* gbias;                  // [O], accumulated
+  int Hp, Wp;
+};
+template <int KS, bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_first_kernel(WgradArgs p, WgradFirstFused q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PW = W1_TW + KS - 1, PH = W1_TH + KS - 1, PLANE = PH * PW;
   float* gs = smem;                   // [64][W1_GP]
@@ -1002,42 +1065,118 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_first_kernel(WgradArgs p) {
   const int jc = jj / (KS * KS), jt = jj % (KS * KS);
   const int tapoff = jc * PLANE + (jt / KS) * PW + (jt % KS);
   const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
+  const bool ones = FUSED && li == ntap;     // the extra B column of ones (bias gradient): reads a row of 1.0 behind the patch
+  const float pa = FUSED ? *q.slope : 1.f;
+  float sa = 0.f;                            // slope gradient: sum over x <= 0 of x * g
   f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int nPix = p.tilesX * p.tilesY;
-  for (int t = blockIdx.x; t < nPix; t += gridDim.x) {
+  // Staging (round 4): thread = one 2x2 window of the tile (64 windows: 2 rows of 32) x 16 channels (its wave's), so a channel
+  // costs two 8-byte loads of the full-resolution tensor -- plus, FUSED, one dword of the pooled gradient and one winner byte --
+  // instead of four dword loads; and the loads of tile t + 1 are issued BEFORE the MFMA phase of tile t (registers: 64 / 96),
+  // where the first version waited four times per tile for 16 loads each with eight waves a CU (latency-bound: 48 us for
+  // 96 MB; fused 160 us).
+  constexpr int NPATCH = (3 * PLANE + 255) / 256;
+  const int wq = tid & 63, wy = wq >> 5, wx = wq & 31, o0 = wave * 16;
+  const float* full = FUSED ? q.x : p.g;
+  const int HpWp = FUSED ? q.Hp * q.Wp : 0;
+  // buffer loads: one resource per tensor (SGPRs), the channel's plane as the scalar offset, ONE 32-bit lane offset per row --
+  // with global loads the compiler kept a 64-bit address pair per load and spilled
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t full_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(full), 0, p.O * HoWo * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gp_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FUSED ? q.gpool : full), 0, FUSED ? p.O * HpWp * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ib_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(FUSED ? q.pidx : nullptr), 0, FUSED ? p.O * HpWp : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.Cin * HW * 4, 0x00020000);
+  float2 r0[16], r1[16];
+  float gp[FUSED ? 16 : 1];
+  unsigned char ib[FUSED ? 16 : 1];
+  float pv[NPATCH];
+  bool shifted = false, okx0 = false, okx1 = false, oky0 = false, oky1 = false;
+  auto load = [&](int t, bool live) {   // !live (no next tile): every offset outside its resource -- zeros, no traffic, no branch
     const int oy0 = (t / p.tilesX) * W1_TH, ox0 = (t % p.tilesX) * W1_TW;
-    // ---- gradient tile: 64 rows (o) x 256 pixels; thread -> pixel tid, loop over o (coalesced along x)
-    {
-      const int ty = tid / W1_TW, tx = tid % W1_TW;
-      const int oy = oy0 + ty, ox = ox0 + tx;
-      const bool ok = oy < p.Ho && ox < p.Wo;
-      const int ofs = ok ? oy * p.Wo + ox : 0;
+    const int y0 = oy0 + 2 * wy, x0 = ox0 + 2 * wx;
+    // the pair (x0, x0 + 1) is read from column min(x0, Wo - 2): at an odd width the last column arrives in .y
+    // (the launchers take this kernel for Wo >= 2 only)
+    const int xb = x0 < p.Wo - 1 ? x0 : p.Wo - 2;
+    shifted = x0 == p.Wo - 1;
+    okx0 = x0 < p.Wo; okx1 = x0 + 1 < p.Wo; oky0 = y0 < p.Ho; oky1 = y0 + 1 < p.Ho;
+    const int ya = y0 < p.Ho ? y0 : p.Ho - 1, yb = y0 + 1 < p.Ho ? y0 + 1 : p.Ho - 1;
+    // (BYTE offsets in 32 bits: base in SGPRs + zero-extended lane offset, not a 64-bit address per load)
+    const unsigned ofa = live ? 4u * (ya * p.Wo + xb) : 0x7FFFFFFFu, ofb = live ? 4u * (yb * p.Wo + xb) : 0x7FFFFFFFu;
+    unsigned pofs = 0;
+    if (FUSED) {
+      const int py = (y0 >> 1) < q.Hp ? (y0 >> 1) : q.Hp - 1, px = (x0 >> 1) < q.Wp ? (x0 >> 1) : q.Wp - 1;
+      pofs = live ? py * q.Wp + px : 0x1FFFFFFFu;
+    }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int o = b * 16 + j; v[j] = p.g[(size_t)(o < p.O ? o : 0) * HoWo + ofs]; }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int o = b * 16 + j; gs[o * W1_GP + tid] = (ok && o < p.O) ? v[j] : 0.f; }
+    for (int j = 0; j < 16; ++j) {
+      const int o = o0 + j, oo = o < p.O ? o : 0;
+      const unsigned so = (unsigned)oo * (unsigned)HoWo * 4u;   // wave-uniform: the channel's plane rides in soffset
+      const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(full_rsrc, ofa, so, 0);
+      const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(full_rsrc, ofb, so, 0);
+      r0[j].x = __uint_as_float(a.x); r0[j].y = __uint_as_float(a.y);
+      r1[j].x = __uint_as_float(b.x); r1[j].y = __uint_as_float(b.y);
+      if (FUSED) {
+        const unsigned sp = (unsigned)oo * (unsigned)HpWp;
+        gp[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gp_rsrc, 4u * pofs, 4u * sp, 0));
+        ib[j] = __builtin_amdgcn_raw_buffer_load_b8(ib_rsrc, pofs, sp, 0);
       }
     }
-    // ---- input patch with halo
-    for (int e = tid; e < p.Cin * PLANE; e += 256) {
+#pragma unroll
+    for (int i = 0; i < NPATCH; ++i) {
+      const int e = tid + 256 * i;
       const int c = e / PLANE, r2 = e - c * PLANE;
       const int r = r2 / PW, col = r2 - r * PW;
       const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + col;
-      float v = 0.f;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = p.in[(size_t)c * HW + iy * p.W + ix];
-      ps[e] = v;
+      // (a position outside the image or the patch gets an offset outside the resource and arrives as zero: no branch)
+      const bool okp = live & (e < p.Cin * PLANE) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+      pv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rsrc, okp ? 4u * (unsigned)(c * HW + iy * p.W + ix) : 0x7FFFFFFFu, 0, 0));
+    }
+  };
+  if (FUSED && tid < W1_TW) ps[NPATCH * 256 + tid] = 1.f;   // (visible after the first barrier; nothing else writes there)
+  const bool dbg_dead = p.dbg & 8;
+  load(blockIdx.x, (int)blockIdx.x < nPix && !dbg_dead);
+  for (int t = blockIdx.x; t < nPix; t += gridDim.x) {
+    // ---- gradient tile: 64 rows (o) x 256 pixels (4 rows of 64)
+    if (!(p.dbg & 4)) {
+      float* gw = gs + (2 * wy) * W1_TW + 2 * wx;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o = o0 + j;
+        const bool oko = o < p.O;
+        float v[4] = {shifted ? r0[j].y : r0[j].x, r0[j].y, shifted ? r1[j].y : r1[j].x, r1[j].y};
+        const bool ok[4] = {oko && oky0 && okx0, oko && oky0 && okx1, oko && oky1 && okx0, oko && oky1 && okx1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g;
+          if (FUSED) {
+            g = (ok[e] && ib[j] == e) ? gp[j] : 0.f;
+            const bool pos = v[e] > 0.f;
+            sa = fmaf(pos ? 0.f : v[e], g, sa);
+            g = pos ? g : pa * g;
+          } else {
+            g = ok[e] ? v[e] : 0.f;
+          }
+          gw[o * W1_GP + (e >> 1) * W1_TW + (e & 1)] = g;
+        }
+        // one channel at a time: left alone, the scheduler does all 64 stores first and the slope sums last, with every
+        // value, gradient and comparison mask of the tile alive in between (256 registers, masks spilled lane by lane)
+        if (FUSED) asm volatile("" : "+v"(sa)::"memory");   // (and the slope sums HERE: they were moved behind the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < NPATCH; ++i) ps[tid + 256 * i] = pv[i];   // (NPATCH * 256 floats are there; zeros behind the patch)
     }
     __syncthreads();
-    {
+    load(t + gridDim.x, t + (int)gridDim.x < nPix && !dbg_dead);   // in flight under the MFMA phase
+    if (!(p.dbg & 2)) {
       const float* ga = gs + li * W1_GP + wave * W1_TW + h;          // pixel pair (x, x+1): h selects
-      const float* pb = ps + tapoff + wave * PW + h;
+      const float* pb = ones ? ps + NPATCH * 256 : ps + tapoff + wave * PW + h;
 #pragma unroll 4
       for (int x = 0; x < W1_TW; x += 2) {
         const float b = pb[x];
@@ -1059,13 +1198,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_first_kernel(WgradArgs p) {
     }
   __syncthreads();
   const int OC = p.O * p.Cin;
-  float* sl = p.slab + (size_t)blockIdx.x * KS * KS * OC;
+  // FUSED: the bias sums (column 27) and the slope sum ride behind the block's slab slice and are folded with it -- 512 blocks
+  // adding to the same 65 addresses with atomics cost ~90 us (they serialise at the memory side)
+  const int stride = KS * KS * OC + (FUSED ? p.O + 1 : 0);
+  float* sl = p.slab + (size_t)blockIdx.x * stride;
   for (int e = tid; e < 64 * 32; e += 256) {
     const int o = e >> 5, j = e & 31;
     if (o < p.O && j < ntap) {
       const float v = red[e] + red[64 * 32 + e] + red[2 * 64 * 32 + e] + red[3 * 64 * 32 + e];
       sl[(size_t)(j % (KS * KS)) * OC + o * p.Cin + j / (KS * KS)] = v;
+    } else if (FUSED && o < p.O && j == ntap) {
+      sl[KS * KS * OC + o] = red[e] + red[64 * 32 + e] + red[2 * 64 * 32 + e] + red[3 * 64 * 32 + e];
     }
+  }
+  if (FUSED) {
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
+    if (lane == 0) red[wave] = sa;
+    __syncthreads();
+    if (tid == 0) sl[KS * KS * OC + p.O] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -1087,15 +1239,17 @@ static void choose_wgrad_tile(int Ho, int Wo, int k, int tys, int* TH, int* TW) 
 }
 
 static bool g_wgrad_first_ok = true;  // cleared by conv_wgrad when the input carries a fused activation
-static bool wgrad_is_first(int Cin, int O, int k) { return g_wgrad_first_ok && k == 3 && Cin * 9 <= 32 && O <= 64; }
+static bool wgrad_is_first(int Cin, int O, int k, int Wo) { return g_wgrad_first_ok && k == 3 && Cin * 9 <= 32 && O <= 64 && Wo >= 2; }
 
 static void wgrad_plan(WgradArgs& a, int k) {
-  if (wgrad_is_first(a.Cin, a.O, k)) {
+  if (wgrad_is_first(a.Cin, a.O, k, a.Wo)) {
     a.TH = W1_TH; a.TW = W1_TW;
     a.tilesX = cdiv(a.Wo, W1_TW); a.tilesY = cdiv(a.Ho, W1_TH);
     a.oTiles = a.cTiles = a.kyGroups = 1;
     a.nSplit = std::min(512, a.tilesX * a.tilesY);   // one slab slice per block
     a.dbg = 0;
+    if (const char* e = getenv("FRCNN_WG_DBG")) a.dbg = atoi(e);
+    if (const char* e = getenv("FRCNN_W1_SPLIT")) a.nSplit = std::min(atoi(e), a.tilesX * a.tilesY);
     return;
   }
   const int tys = k == 3 ? 3 : 1;
@@ -1173,7 +1327,8 @@ size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad) 
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   wgrad_plan(a, k);
-  return (size_t)a.nSplit * k * k * O * Cin * 4 + 256;
+  // (first-layer shapes: room for the bias / slope sums that conv_wgrad_first_pooled keeps behind every slab slice)
+  return (size_t)a.nSplit * (k * k * O * Cin + O + 1) * 4 + 256;
 }
 
 template <int KS, int TYS, int PM>
@@ -1223,19 +1378,17 @@ int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, co
   a.slab = (float*)(((uintptr_t)ws + 255) / 256 * 256);
   double flops = 2.0 * O * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_WGRAD_K3 : KC_CONV_WGRAD_OTHER;
-  if (wgrad_is_first(Cin, O, k)) {
-    size_t lds = ((size_t)64 * W1_GP + (size_t)Cin * (W1_TH + 2) * (W1_TW + 2)) * 4;
+  if (wgrad_is_first(Cin, O, k, a.Wo)) {
+    size_t lds = ((size_t)64 * W1_GP + W1_PATCH) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<3>),
+      FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<3, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
     if (frcnn::prof_enabled(klass)) frcnn::prof_before(klass, s);
-    hipLaunchKernelGGL((conv_wgrad_first_kernel<3>), dim3(a.nSplit), dim3(256), lds, s, a);
-    const int OC = O * Cin;
-    int rgrid = (int)std::min<long>(cdivl(9L * OC, 64), 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)a.slab, a.nSplit, 9, OC, gw);
+    hipLaunchKernelGGL((conv_wgrad_first_kernel<3, false>), dim3(a.nSplit), dim3(256), lds, s, a, WgradFirstFused{});
+    wgrad_reduce_first(a.slab, a.nSplit, O * Cin, gw, s);
     if (frcnn::prof_enabled(klass)) frcnn::prof_after(klass, flops, 4.0 * ((double)Cin * H * W + (double)O * a.Ho * a.Wo), s);
     FR_LAUNCH_CHECK();
     return FRCNN_OK;
@@ -1244,6 +1397,44 @@ int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, co
   if (k == 1) return launch_wgrad<1, 1>(a, klass, flops, gw, s);
   if (k == 5) return launch_wgrad<5, 1>(a, klass, flops, gw, s);
   return launch_wgrad<7, 1>(a, klass, flops, gw, s);
+}
+
+// accGradParameters of the first layer straight from the POOLED map's gradient (see WgradFirstFused): replaces
+// maxpool_act_backward + conv_wgrad for a block of one convolution whose input gradient nobody needs (objective.lua:189).
+bool conv_wgrad_first_pooled_eligible(int Cin, int O, int k, int Wo) { return k == 3 && Cin * 9 < 32 && O <= 64 && Wo >= 2; }
+int conv_wgrad_first_pooled(const float* in, int Cin, int H, int W, const float* gpool, const unsigned char* pidx, const float* x,
+                            const float* slope, int O, int pad, float* gw, float* gbias, float* gslope, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
+  FR_CHECK(conv_wgrad_first_pooled_eligible(Cin, O, 3, W + 2 * pad - 2) && slope, "conv_wgrad_first_pooled: not a first-layer shape");
+  WgradArgs a;
+  a.in = in; a.in_slope = nullptr; a.in_scale = nullptr; a.g = nullptr;
+  a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
+  a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
+  a.TH = W1_TH; a.TW = W1_TW;
+  a.tilesX = cdiv(a.Wo, W1_TW); a.tilesY = cdiv(a.Ho, W1_TH);
+  a.oTiles = a.cTiles = a.kyGroups = 1;
+  a.nSplit = std::min(512, a.tilesX * a.tilesY);
+  a.dbg = 0;
+  if (const char* e = getenv("FRCNN_WG_DBG")) a.dbg = atoi(e);
+  const size_t need = (size_t)a.nSplit * (9 * O * Cin + O + 1) * 4 + 256;
+  FR_CHECK(ws && ws_bytes >= need, "conv_wgrad_first_pooled: workspace too small (%zu < %zu)", ws_bytes, need);
+  a.slab = (float*)(((uintptr_t)ws + 255) / 256 * 256);
+  WgradFirstFused q{gpool, pidx, x, slope, gslope, gbias, (a.Ho - 2 + 1) / 2 + 1, (a.Wo - 2 + 1) / 2 + 1};
+  const size_t lds = ((size_t)64 * W1_GP + W1_PATCH + W1_TW) * 4;   // + the row of ones
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_first_kernel<3, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const double flops = 2.0 * O * Cin * 9 * (double)a.Ho * a.Wo;
+  if (frcnn::prof_enabled(KC_CONV_WGRAD_K3)) frcnn::prof_before(KC_CONV_WGRAD_K3, s);
+  hipLaunchKernelGGL((conv_wgrad_first_kernel<3, true>), dim3(a.nSplit), dim3(256), lds, s, a, q);
+  wgrad_reduce_first(a.slab, a.nSplit, O * Cin, gw, s, O + 1, gbias, gslope);
+  if (frcnn::prof_enabled(KC_CONV_WGRAD_K3))
+    frcnn::prof_after(KC_CONV_WGRAD_K3, flops, 4.0 * ((double)Cin * H * W + (double)O * a.Ho * a.Wo * 1.3125), s);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 
 }  // namespace frcnn

@@ -67,6 +67,11 @@ int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, c
                 int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr);
 // gw[o][c][tap] += sum_s slab[s][tap][o][c]   (the fold shared by the weight-gradient kernels)
 int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s);
+// first layer of a one-convolution block: weight, bias and slope gradients straight from the pooled map's gradient
+bool conv_wgrad_first_pooled_eligible(int Cin, int O, int k, int Wo);
+int conv_wgrad_first_pooled(const float* in, int Cin, int H, int W, const float* gpool, const unsigned char* pidx, const float* x,
+                            const float* slope, int O, int pad, float* gw, float* gbias, float* gslope, void* ws, size_t ws_bytes,
+                            hipStream_t s);
 
 // gw[O][Cin][k][k] += sum_pix g[O][Ho][Wo] * act(in)[Cin][H][W]   (split-K slabs in `ws`, folded in a fixed order)
 // `ws`: split-K slab workspace of at least conv_wgrad_workspace_bytes(...) bytes.

@@ -958,6 +958,24 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       const float* scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;
       const bool fused_here = act_done;
       act_done = false;
+      // the very first convolution when it is its block's only one: its input gradient is not needed, so the pooling + PReLU
+      // backward is computed inside its weight-gradient launch and the full-resolution gradient never exists
+      static const bool first_pooled_on = !(getenv("FRCNN_FIRST_POOLED") && atoi(getenv("FRCNN_FIRST_POOLED")) == 0);
+      const bool first_pooled = fuse_act && first_pooled_on && b == 0 && st == 0 && blk.nconv == 1 && scale == nullptr &&
+                                conv_wgrad_first_pooled_eligible(c.Cin, c.Cout, c.k, c.Wo);
+      if (first_pooled) {
+        // (on the caller's stream with the slab workspace of its own, like the unfused first layer: see on_caller below)
+        FR_TRY(conv_wgrad_first_pooled(m->img.f(), c.Cin, c.H, c.W, blk.gpooled.f(), (const unsigned char*)blk.pidx.p, c.x.f(),
+                                       w + c.a_off, c.Cout, c.pad, grad + c.w_off, grad + c.b_off, grad + c.a_off,
+                                       m->wg_ws_first.p, m->wg_ws_first.bytes, s));
+        while (m->block_ev.size() < (size_t)nb) {
+          hipEvent_t e;
+          FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          m->block_ev.push_back(e);
+        }
+        FR_HIP(hipEventRecord(m->block_ev[b], s));
+        break;
+      }
       if (fused_here) {
         // (nothing: c.gx is final; its bias gradient comes with the weight gradient below)
       } else if (st == blk.nconv - 1) {

@@ -389,6 +389,39 @@ def test_sparse_head_backward_equals_dense(F, setup):
     _compare_gradient(nat, g_sparse, g_dense, 0, nat.pnet_params, tol_l2=1e-5, elementwise=False)
 
 
+def test_fused_activation_backward_equals_unfused(F, setup, monkeypatch):
+    """Round 4: the PReLU / SpatialDropout / max-pooling backward folded into the neighbouring convolution launches (conv_x3's
+    X3PostAct; the first layer's weight gradient straight from the pooled gradient, conv_wgrad_first_pooled) against the same
+    pass with every activation backward as a launch of its own (FRCNN_FUSE_ACT=0): the whole proposal-net gradient, 1e-5 L2
+    (the sums differ in order only), at an even and at an odd image size (ceil-mode pooling windows cut by the border)."""
+    s = setup
+    model = s["model"]
+    pnet, nat = model["pnet"], model["native"]
+    rng = np.random.RandomState(9)
+    for (h, w) in ((H, W), (117, 155)):
+        img = F.synthetic_image(h, w, 2)
+        pnet.training()
+        pnet.drop_masks = _masks(rng, model)
+        try:
+            outs = pnet.forward(img)
+            deltas = [(rng.randn(*o.shape) / np.sqrt(o.numel())).astype(np.float32) for o in outs]
+            res = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("FRCNN_FUSE_ACT", mode)
+                pnet.forward(img)
+                s["gradient"].zero_()
+                dd = pnet.delta_outputs(zero=True)
+                for d, hst in zip(dd, deltas):
+                    d.copy_from_numpy(hst)
+                pnet.backward(img, dd)
+                res[mode] = s["gradient"].cpu().numpy().copy()
+        finally:
+            pnet.drop_masks = None
+            monkeypatch.delenv("FRCNN_FUSE_ACT", raising=False)
+        assert np.abs(res["1"][:nat.pnet_params]).max() > 0
+        _compare_gradient(nat, res["1"], res["0"], 0, nat.pnet_params, tol_l2=1e-5, elementwise=False)
+
+
 def test_side_stream_equals_serial(F, setup):
     """frcnn_set_option("side_stream"): issuing the anchor nets / weight gradients on the library's second
     stream (and starting the anchor nets' backward early, frcnn_pnet_backward_heads_begin) must not change the
