@@ -224,6 +224,60 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         return [e for e in examples
                 if not (e[0].index[1] > outputs[e[0].layer - 1].shape[1] or e[0].index[2] > outputs[e[0].layer - 1].shape[2])]
 
+    prepared = {}   # id(batch entry) -> tables packed ahead of the pass (finish(), while the host waits for the device)
+
+    def map_sizes(H, W):
+        """Sizes of the anchor nets' outputs and of the last pooled map for an H x W image (ceil-mode pooling,
+        model_utilities.lua:23; valid k x k head convolution, :31) -- what pnet.forward will hand out."""
+        from .synthetic import output_map_sizes
+        h, w = H, W
+        for l in model["layers"]:
+            for _ in range(l["conv_steps"]):
+                h = h + 2 * l["padH"] - l["kH"] + 1; w = w + 2 * l["padW"] - l["kW"] + 1
+            h = -(-(h - 2) // 2) + 1; w = -(-(w - 2) // 2) + 1
+        return [tuple(t) for t in output_map_sizes(model, H, W)], (h, w)
+
+    def prepare_examples(x):
+        """The host half of objective.lua:74-140 for one image: cleanAnchors, the example tables (anchor / ground-truth
+        rectangles, (layer, aspect, y, x), classes), the ROI-pooling windows and the positions the sparse head backward
+        will touch, packed into the ONE blob that is uploaded behind the forward pass."""
+        from .synthetic import clean_examples
+        shp = x["img"].shape
+        sizes, (fmH, fmW) = map_sizes(int(shp[1]), int(shp[2]))
+        p = clean_examples(x["positive"], sizes)  # :74-75
+        n = clean_examples(x["negative"], sizes)
+        npos, E = len(p), len(p) + len(n)
+        prep = dict(p=p, n=n, sizes=sizes, fm=(fmH, fmW))
+        if E == 0:
+            return prep
+        anch = [e[0] for e in p] + [e[0] for e in n]
+        ex_idx = np.array([(a.layer, a.aspect, a.index[1], a.index[2]) for a in anch], dtype=np.int32)
+        ex_anchor = np.array([(a.minX, a.minY, a.maxX, a.maxY) for a in anch], dtype=np.float64)
+        ex_roi = np.zeros((max(npos, 1), 4), dtype=np.float64)
+        ex_class = np.zeros(max(npos, 1), dtype=np.int32)
+        if npos:
+            ex_roi[:npos] = [(e[1].rect.minX, e[1].rect.minY, e[1].rect.maxX, e[1].rect.maxY) for e in p]
+            ex_class[:npos] = [e[1].class_index for e in p]
+            if ex_class[:npos].min() < 1 or ex_class[:npos].max() > cfg["class_count"]:
+                # nn.ClassNLLCriterion raises on a target outside 1..n (objective.lua:174); the batched loss
+                # kernel indexes with it, so a stale index in a training-data file must stop here
+                raise _lib.FrcnnError("roi.class_index %d outside 1..%d (class_count)"
+                                      % (int(ex_class[:npos].min() if ex_class[:npos].min() < 1 else ex_class[:npos].max()),
+                                         cfg["class_count"]))
+        # positives pool the GT rect (:117), negatives pool the anchor rect itself (:137)
+        wins = roi_windows(np.concatenate([ex_roi[:npos], ex_anchor[npos:]], 0), localizer, fmH, fmW)
+        # positions where delta_outputs[l] will be non-zero (hint for the sparse head backward)
+        sp = []
+        for l in range(4):
+            sel = ex_idx[ex_idx[:, 0] == l + 1]
+            sp.append(np.unique((sel[:, 2] - 1) * sizes[l][1] + (sel[:, 3] - 1)).astype(np.int32))
+        sp_all = np.concatenate(sp)
+        blob = np.concatenate([ex_anchor.view(np.uint8).ravel(), ex_roi.view(np.uint8).ravel(),
+                               ex_idx.view(np.uint8).ravel(), ex_class.view(np.uint8).ravel(),
+                               wins.view(np.uint8).ravel(), sp_all.view(np.uint8).ravel()])
+        prep.update(ex_anchor=ex_anchor, ex_roi=ex_roi, ex_idx=ex_idx, ex_class=ex_class, wins=wins, sp=sp, blob=blob)
+        return prep
+
     def run(w, defer):
         """Queues the whole pass.  Returns finish() -> (loss, gradient); with defer=True (single process) the
         accumulators travel to pinned host memory asynchronously and finish() only waits for that copy, so the
@@ -257,42 +311,21 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             acc_dev.zero_()
         for bi, x in enumerate(batch):
             last = bi == len(batch) - 1   # (by position: an iterator may hand out the same pooled image twice)
+            # the example tables are host work that needs no device result (the map sizes follow from the image size): they
+            # were packed while the host waited for the previous step (finish()), or are packed now -- before the forward
+            # pass is queued, not between it and the stage that consumes them, where the device would run dry
+            prep = prepared.pop(id(x), None) or prepare_examples(x)
             img = to_device(x["img"])  # :66
             outputs = pnet.forward(img, async_heads=True)  # :71 (the anchor nets stay in flight beside the cnet stage)
-            p = cleanAnchors(x["positive"], outputs)  # :74-75
-            n = cleanAnchors(x["negative"], outputs)
+            assert prep["sizes"] == [tuple(o.shape[1:]) for o in outputs[:len(prep["sizes"])]] and prep["fm"] == tuple(outputs[-1].shape[1:])
+            p, n = prep["p"], prep["n"]  # :74-75
             delta_outputs = pnet.delta_outputs(zero=True)  # :78-84
             npos, nneg = len(p), len(n)
             E = npos + nneg
             fm = outputs[-1]
             fmC, fmH, fmW = fm.shape
             if E > 0:
-                # ---- host: pack the example tables (one H2D copy) ----------------------------
-                anch = [e[0] for e in p] + [e[0] for e in n]
-                ex_idx = np.array([(a.layer, a.aspect, a.index[1], a.index[2]) for a in anch], dtype=np.int32)
-                ex_anchor = np.array([(a.minX, a.minY, a.maxX, a.maxY) for a in anch], dtype=np.float64)
-                ex_roi = np.zeros((max(npos, 1), 4), dtype=np.float64)
-                ex_class = np.zeros(max(npos, 1), dtype=np.int32)
-                if npos:
-                    ex_roi[:npos] = [(e[1].rect.minX, e[1].rect.minY, e[1].rect.maxX, e[1].rect.maxY) for e in p]
-                    ex_class[:npos] = [e[1].class_index for e in p]
-                    if ex_class[:npos].min() < 1 or ex_class[:npos].max() > cfg["class_count"]:
-                        # nn.ClassNLLCriterion raises on a target outside 1..n (objective.lua:174); the batched loss
-                        # kernel indexes with it, so a stale index in a training-data file must stop here
-                        raise _lib.FrcnnError("roi.class_index %d outside 1..%d (class_count)"
-                                              % (int(ex_class[:npos].min() if ex_class[:npos].min() < 1 else ex_class[:npos].max()),
-                                                 cfg["class_count"]))
-                # positives pool the GT rect (:117), negatives pool the anchor rect itself (:137)
-                wins = roi_windows(np.concatenate([ex_roi[:npos], ex_anchor[npos:]], 0), localizer, fmH, fmW)
-                # positions where delta_outputs[l] will be non-zero (hint for the sparse head backward)
-                sp = []
-                for l in range(4):
-                    sel = ex_idx[ex_idx[:, 0] == l + 1]
-                    sp.append(np.unique((sel[:, 2] - 1) * outputs[l].shape[2] + (sel[:, 3] - 1)).astype(np.int32))
-                sp_all = np.concatenate(sp) if E else np.zeros(0, np.int32)
-                blob = np.concatenate([ex_anchor.view(np.uint8).ravel(), ex_roi.view(np.uint8).ravel(),
-                                       ex_idx.view(np.uint8).ravel(), ex_class.view(np.uint8).ravel(),
-                                       wins.view(np.uint8).ravel(), sp_all.view(np.uint8).ravel()])
+                ex_anchor, ex_roi, ex_idx, ex_class, wins, sp, blob = (prep[k] for k in ("ex_anchor", "ex_roi", "ex_idx", "ex_class", "wins", "sp", "blob"))
                 dblob = scratch.get("blob", (blob.size,), np.uint8)
                 hblob, staged = pinned.stage(blob)   # page-locked: the upload is asynchronous, the host keeps its lead
                 _lib.call("frcnn_memcpy_h2d", ptr(dblob), C.c_void_p(hblob), blob.nbytes, s)
@@ -415,6 +448,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             # the next call, where the device would wait for it.  Same call sequence on the iterator, one call early.
             if next_batch[0] is None and prefetch_batches:
                 next_batch[0] = batch_iterator.nextTraining()
+                prepared.clear()
+                for xb in next_batch[0]:   # ... and its example tables are packed (host work with no device input)
+                    prepared[id(xb)] = prepare_examples(xb)
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
         if counts is None:   # device tail: the (all-reduced) counts sit in the slots the kernels leave alone
