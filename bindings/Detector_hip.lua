@@ -67,15 +67,25 @@ function Detector:detect(input)                                         -- Detec
                          cnt, ws.ptr, wsb, nil))
   -- NON-MAXIMUM SUPPRESSION (:74-85) on the device, the match count read from DEVICE memory (no round trip between scan
   -- and NMS); the score tensor is ignored by nms.lua -> key = max-y
-  local nwsb = tonumber(C.frcnn_nms_workspace_bytes(cap))
+  -- (launch and workspace sized for a bound on the matches, not for every anchor of the maps; a frame with more matches
+  -- repeats the pass sized by the count just read)
+  local ncap = math.min(cap, 16384)
+  local nwsb = tonumber(C.frcnn_nms_workspace_bytes(ncap))
   local nws = scratch('nms_ws', nwsb)
   local dpick = ffi.cast('long long*', scratch('pick', 8 * cap).ptr)
-  check(C.frcnn_nms_device_n(mb, cap, cnt, 4, 0.25, 0, 0, nil, dpick, cnt + 1, nws.ptr, nwsb, nil))
+  check(C.frcnn_nms_device_n(mb, ncap, cnt, 4, 0.25, 0, 0, nil, dpick, cnt + 1, nws.ptr, nwsb, nil))
   local count = ffi.new('int[2]')
   check(C.frcnn_memcpy_d2h(count, cnt, 8, nil))                          -- ---- read-back 1 of 2: two counts
   check(C.frcnn_stream_sync(nil))
   if count[0] > cap then
     error(string.format('Detector: %d anchors pass p > 0.95, more than the %d the maps hold', count[0], cap))
+  end
+  if count[0] > ncap then
+    nwsb = tonumber(C.frcnn_nms_workspace_bytes(count[0]))
+    nws = scratch('nms_ws_full', nwsb)
+    check(C.frcnn_nms_device(mb, count[0], 4, 0.25, 0, 0, dpick, cnt + 1, nws.ptr, nwsb, nil))
+    check(C.frcnn_memcpy_d2h(count + 1, cnt + 1, 4, nil))
+    check(C.frcnn_stream_sync(nil))
   end
   local nm, R = count[0], count[1]
 

@@ -124,6 +124,8 @@ class Detector(object):
                   float(threshold), cap, ptr(mp), ptr(mi), ptr(mr), ptr(mb), ptr(cnt), ptr(ws), wsb, stream_ptr())
         return dict(cap=cap, p=mp, idx=mi, rect=mr, box=mb, cnt=cnt, threshold=threshold)
 
+    NMS_FIRST_CAP = 16384   # rows the first NMS launch is sized for (see detect)
+
     @property
     def last_pick(self):
         """1-based rows of the match arrays that survived the first NMS, in pick order (Detector.lua:82)."""
@@ -161,14 +163,24 @@ class Detector(object):
         cap = m["cap"]
         # NON-MAXIMUM SUPPRESSION (:74-85) on the device, the match count read from device memory; the score tensor is
         # ignored by nms.lua -> key = max-y
-        wsb = L.frcnn_nms_workspace_bytes(cap)
+        # The launch and its workspace are sized for a BOUND on the matches, not for every anchor of the maps (vgg_large:
+        # 45 015 anchors -> 253 MB of masks and a 704 x 704 tile grid per frame for a few hundred matches); a frame with more
+        # matches than the bound repeats the pass sized by the count just read.
+        ncap = min(cap, self.NMS_FIRST_CAP)
+        wsb = L.frcnn_nms_workspace_bytes(ncap)
         ws = self._buf("nms_ws", (wsb,), np.uint8)
         pick = self._buf("nms_pick", (cap,), np.int64)
-        _lib.call("frcnn_nms_device_n", ptr(m["box"]), cap, ptr(counts), 4, C.c_float(0.25), 0, 0, None, ptr(pick),
+        _lib.call("frcnn_nms_device_n", ptr(m["box"]), ncap, ptr(counts), 4, C.c_float(0.25), 0, 0, None, ptr(pick),
                   C.c_void_p(counts.ptr + 4), ptr(ws), wsb, s)
         n, R = [int(v) for v in self._read(counts.ptr, 8, np.int32)]          # ---- read-back 1 of 2: two counts
         if n > cap:
             raise _lib.FrcnnError("Detector: %d anchors pass p > %g, more than the %d the maps hold" % (n, m["threshold"], cap))
+        if n > ncap:
+            wsb = L.frcnn_nms_workspace_bytes(n)
+            ws = self._buf("nms_ws_full", (wsb,), np.uint8)
+            _lib.call("frcnn_nms_device", ptr(m["box"]), n, 4, C.c_float(0.25), 0, 0, ptr(pick), C.c_void_p(counts.ptr + 4),
+                      ptr(ws), wsb, s)
+            R = int(self._read(counts.ptr + 4, 4, np.int32)[0])
         self.last_scan = dict(n=n, p=DeviceTensor(m["p"].ptr, (n,), np.float32, owner=m["p"]),
                               idx=DeviceTensor(m["idx"].ptr, (n, 4), np.int32, owner=m["idx"]),
                               rect=DeviceTensor(m["rect"].ptr, (n, 4), np.float64, owner=m["rect"]),

@@ -101,7 +101,10 @@ __device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint
 // One block = one (M tile, chunk) pair: its 128 x 16 x k*k source floats are contiguous runs (mode 0: 16 k*k floats per
 // filter row; mode 1: 128 k*k floats per K channel), read coalesced into LDS (ROWS filter rows at a time), split, and
 // written as the k*k 12 KB stages.
-#define PX_FLOATS (CX_BM * 145)   // LDS floats of the pack kernels: 128 rows x (144 + 1) for k = 3
+// LDS floats of the pack kernels: 64 filter rows x (144 + 1) for k = 3 -- 37 KB, four blocks per CU: the ~540 (M tile, chunk)
+// pairs of a vgg_small step are ONE round on the 1024 slots (with 128 rows / 74 KB / two per CU they were 1.05 rounds of 512:
+// the launch took two block times, 50 us at the head of every step)
+#define PX_FLOATS (64 * 145)
 template <int KS, int ROWS>
 __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
   constexpr int KK = KS * KS, PITCH = CX_CH * KK + 1;   // odd pitch: the stride-KK reads of a lane's 8 channels spread over the banks
@@ -111,10 +114,13 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
   const int BM = j.bm, AST = 6 * BM * 16;
   const int nCh = KC / CX_CH, pairs = (M / BM) * nCh;
   const int tid = threadIdx.x;
-  for (int pr = blk; pr < pairs; pr += nblk) {
+  const int groups = BM / ROWS;   // work unit = ROWS filter rows of one pair: equal units, one per block (conv_x3_pack_assign_blocks)
+  for (int u = blk; u < pairs * groups; u += nblk) {
+    const int pr = u / groups;
     const int mt = pr / nCh, chunk = pr - mt * nCh;
     char* base = reinterpret_cast<char*>(j.dst) + (size_t)pr * KK * AST;
-    for (int r0 = 0; r0 < BM; r0 += ROWS) {
+    {
+      const int r0 = (u - pr * groups) * ROWS;
       // tile[r][kc16 * KK + tap] (source tap order), r = filter row inside this group of ROWS rows
       if (j.mode == 0) {
         for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
@@ -147,10 +153,9 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
   }
 }
 __device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
-  if (j.k == 3 && j.bm == 128) pack_x_job<3, 128>(weights, j, blk, nblk, tile);
-  else if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
-  else if (j.k == 5) pack_x_job<5, 32>(weights, j, blk, nblk, tile);
-  else pack_x_job<7, 16>(weights, j, blk, nblk, tile);
+  if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
+  else if (j.k == 5) pack_x_job<5, 16>(weights, j, blk, nblk, tile);
+  else pack_x_job<7, 8>(weights, j, blk, nblk, tile);
 }
 
 __global__ __launch_bounds__(256) void pack_x3_multi_kernel(const float* __restrict__ weights, const PackXJob* __restrict__ jobs, int njobs) {
@@ -181,7 +186,8 @@ int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs) {
   for (int i = 0; i < njobs; ++i) {
     jobs[i].blk_begin = b;
     const int M = jobs[i].mode == 0 ? jobs[i].O : jobs[i].C, KC = jobs[i].mode == 0 ? jobs[i].C : jobs[i].O;
-    jobs[i].nblk = (M / jobs[i].bm) * (KC / CX_CH);   // one block per (M tile, chunk) pair
+    const int rows = jobs[i].k == 3 ? 64 : jobs[i].k == 5 ? 16 : 8;   // (pack_x3_job's ROWS)
+    jobs[i].nblk = (M / jobs[i].bm) * (KC / CX_CH) * (jobs[i].bm / rows);   // one block per (M tile, chunk) pair and group of rows
     b += jobs[i].nblk;
   }
   return b;

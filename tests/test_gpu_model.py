@@ -349,6 +349,29 @@ def test_detect(F, O, setup):
         s["weights"].copy_(torch.from_numpy(s["w"]))
 
 
+def test_detect_first_nms_bound(F, setup):
+    """Detector.NMS_FIRST_CAP: the first NMS launch is sized for a bound on the matches; a frame with more matches than
+    the bound repeats the pass sized by the count read back.  Same candidates, same winners either way."""
+    import torch
+    s = setup
+    model = s["model"]
+    w = _amplified_weights(model["native"], s["w"], 17, cls_gain=200.0)
+    s["weights"].copy_(torch.from_numpy(w))
+    try:
+        img = F.synthetic_image(H, W, 5)
+        res = []
+        for bound in (16384, 8):
+            d = F.Detector(model)
+            d.NMS_FIRST_CAP = bound
+            win = d.detect(img)
+            assert d.last_scan["n"] > 8
+            res.append((d.last_pick.tolist(), [(x["class"], x["confidence"], x["r2"].minX, x["r2"].minY, x["r2"].maxX, x["r2"].maxY) for x in win]))
+        assert len(res[0][0]) > 0
+        assert res[0] == res[1]
+    finally:
+        s["weights"].copy_(torch.from_numpy(s["w"]))
+
+
 def test_sparse_head_backward_equals_dense(F, setup):
     """frcnn_pnet_set_sparse_deltas: the anchor-head backward restricted to the non-zero delta positions must
     give the gradient of the dense backward (same arithmetic on fewer pixels; fp32 summation order differs)."""
