@@ -1379,6 +1379,8 @@ int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, co
   double flops = 2.0 * O * Cin * k * k * (double)a.Ho * a.Wo;
   int klass = k == 3 ? KC_CONV_WGRAD_K3 : KC_CONV_WGRAD_OTHER;
   if (wgrad_is_first(Cin, O, k, a.Wo)) {
+    FR_CHECK((double)O * a.Ho * a.Wo * 4.0 < 4294967295.0 && (double)Cin * H * W * 4.0 < 4294967295.0,
+             "conv_wgrad: first-layer tensors too large for 32-bit buffer resources");
     size_t lds = ((size_t)64 * W1_GP + W1_PATCH) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1406,6 +1408,8 @@ int conv_wgrad_first_pooled(const float* in, int Cin, int H, int W, const float*
                             const float* slope, int O, int pad, float* gw, float* gbias, float* gslope, void* ws, size_t ws_bytes,
                             hipStream_t s) {
   FR_CHECK(conv_wgrad_first_pooled_eligible(Cin, O, 3, W + 2 * pad - 2) && slope, "conv_wgrad_first_pooled: not a first-layer shape");
+  FR_CHECK((double)O * (H + 2 * pad - 2) * (W + 2 * pad - 2) * 4.0 < 4294967295.0 && (double)Cin * H * W * 4.0 < 4294967295.0,
+           "conv_wgrad_first_pooled: tensors too large for 32-bit buffer resources");
   WgradArgs a;
   a.in = in; a.in_slope = nullptr; a.in_scale = nullptr; a.g = nullptr;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
