@@ -15,18 +15,23 @@ namespace frcnn {
 // for the 1024-wide layer (64 features per block left 240 of the 256 CUs idle: 18-20 us per launch).
 #define BN_CB 16
 #define BN_RG 64
+template <int CB = BN_CB, int RG = BN_RG>
 __device__ __forceinline__ double bn_reduce(double v, double* sh, int tx, int ty) {
-  sh[ty * BN_CB + tx] = v;
+  sh[ty * CB + tx] = v;
   __syncthreads();
   // tree over the row groups, same order for every feature
-  for (int stride = BN_RG / 2; stride > 0; stride >>= 1) {
-    if (ty < stride) sh[ty * BN_CB + tx] += sh[(ty + stride) * BN_CB + tx];
+  for (int stride = RG / 2; stride > 0; stride >>= 1) {
+    if (ty < stride) sh[ty * CB + tx] += sh[(ty + stride) * CB + tx];
     __syncthreads();
   }
   const double s = sh[tx];
   __syncthreads();
   return s;
 }
+// the fused kernels: 4 features x 256 row groups per block -- 256 blocks for the 1024-wide layer, two or three rows per thread
+// (with 16 x 64 the 64 blocks of the fused forward took 42 us: nine rows per thread, three dependent passes)
+#define FB_CB 4
+#define FB_RG 256
 
 __global__ __launch_bounds__(1024) void bn_forward_kernel(const float* __restrict__ x, int R, int n,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -107,6 +112,205 @@ int bn_backward(const float* gy, const float* xhat, const float* invstd, const f
                 int n, int training, float* gx, float* ggamma, float* gbeta, hipStream_t s) {
   FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 16.0, s, bn_backward_kernel, dim3(cdiv(n, BN_CB)), dim3(BN_CB, BN_RG), 0, gy,
             xhat, invstd, gamma, R, n, training, gx, ggamma, gbeta);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused forms (round 4)
+// Every launch of this chain costs ~10 us of the step (measured: six of them removed -> 2.945 to 2.86 ms): the fold of the
+// product's split-K slabs, the batch normalisation and the activation are one kernel, same arithmetic in the same order as the
+// separate ones (bit-identical results; FRCNN_CNET_FUSE=0 runs those).
+__device__ __forceinline__ float fold_value(const float* __restrict__ x, const GemmFold& src, size_t total, size_t idx, int j) {
+  if (src.nSplit == 0) return x[idx];
+  float v = src.bias ? src.bias[j] : 0.f;
+  for (int sI = 0; sI < src.nSplit; ++sI) v += src.slab[(size_t)sI * total + idx];
+  return v;
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(1024) void cnet_act_forward_kernel(const float* __restrict__ x, GemmFold src, int R, int n,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running, int training, float* __restrict__ lin,
+                                                                float* __restrict__ xhat, float* __restrict__ invstd,
+                                                                float* __restrict__ pre, const float* slope, float* __restrict__ mask,
+                                                                float inv_keep, float p, unsigned long long seed,
+                                                                float* __restrict__ post) {
+  __shared__ double sh[FB_RG * FB_CB];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int j = blockIdx.x * FB_CB + tx;
+  const bool ok = j < n;
+  const size_t total = (size_t)R * n;
+  const bool bn = gamma != nullptr;
+  // pass 0: the folded product (each thread re-reads only what it wrote itself)
+  const float* v = src.nSplit ? lin : x;
+  double s0 = 0.0;
+  if (ok && (src.nSplit || (bn && training)))
+    for (int r = ty; r < R; r += FB_RG) {
+      const size_t idx = (size_t)r * n + j;
+      const float t = fold_value(x, src, total, idx, j);
+      if (src.nSplit) lin[idx] = t;
+      s0 += t;
+    }
+  double mean = 0.0, is = 1.0, g = 1.0, b = 0.0;
+  if (bn) {
+    double var;
+    if (training) {
+      mean = bn_reduce<FB_CB, FB_RG>(s0, sh, tx, ty) / R;
+      double q = 0.0;
+      if (ok) for (int r = ty; r < R; r += FB_RG) { double d = v[(size_t)r * n + j] - mean; q += d * d; }
+      var = bn_reduce<FB_CB, FB_RG>(q, sh, tx, ty);
+      const double unb = R > 1 ? var / (R - 1) : var / R;
+      var /= R;
+      if (running && ok && ty == 0) {
+        running[j] = (float)((1.0 - BN_MOM) * running[j] + BN_MOM * mean);
+        running[n + j] = (float)((1.0 - BN_MOM) * running[n + j] + BN_MOM * unb);
+      }
+    } else {
+      mean = ok ? running[j] : 0.0;
+      var = ok ? running[n + j] : 1.0;
+    }
+    if (!ok) return;
+    is = 1.0 / sqrt(var + BN_EPS);
+    if (ty == 0) invstd[j] = (float)is;
+    g = gamma[j]; b = beta[j];
+  }
+  if (!ok) return;
+  const float a = *slope;
+  for (int r = ty; r < R; r += FB_RG) {
+    const size_t idx = (size_t)r * n + j;
+    float y = v[idx];
+    if (bn) {
+      const double xh = ((double)y - mean) * is;
+      xhat[idx] = (float)xh;
+      y = (float)(xh * g + b);
+      pre[idx] = y;
+    }
+    y = y > 0.f ? y : a * y;
+    if (GEN) {
+      const float mk = frcnn_keep_mask(seed, (unsigned long long)idx, p);
+      mask[idx] = mk;
+      y = y * (mk * inv_keep);
+    } else if (mask) {
+      y = y * (mask[idx] * inv_keep);
+    }
+    post[idx] = y;
+  }
+}
+// (no batch normalisation: nothing couples the rows -- a plain element-wise pass, coalesced along the features)
+template <bool GEN>
+__global__ void cnet_act_forward_flat_kernel(const float* __restrict__ x, GemmFold src, long total, int n, float* __restrict__ lin,
+                                             const float* slope, float* __restrict__ mask, float inv_keep, float p,
+                                             unsigned long long seed, float* __restrict__ post) {
+  const float a = *slope;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float y = fold_value(x, src, (size_t)total, (size_t)i, (int)(i % n));
+    if (src.nSplit) lin[i] = y;
+    y = y > 0.f ? y : a * y;
+    if (GEN) {
+      const float mk = frcnn_keep_mask(seed, (unsigned long long)i, p);
+      mask[i] = mk;
+      y = y * (mk * inv_keep);
+    } else if (mask) {
+      y = y * (mask[i] * inv_keep);
+    }
+    post[i] = y;
+  }
+}
+int cnet_act_forward(const float* x, GemmFold src, int R, int n, const float* gamma, const float* beta, float* running,
+                     int training, float* lin, float* xhat, float* invstd, float* pre, const float* slope, float* mask, bool gen,
+                     float inv_keep, float p, unsigned long long seed, float* post, hipStream_t s) {
+  FR_CHECK(!gamma || training || running, "cnet_act_forward: evaluate mode needs running statistics");
+  if (!gamma) {
+    const long total = (long)R * n;
+    const int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 2048);
+    if (gen)
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 16.0, s, cnet_act_forward_flat_kernel<true>, dim3(grid), dim3(256), 0, x, src, total, n, lin, slope,
+                mask, inv_keep, p, seed, post);
+    else
+      FR_LAUNCH(KC_ELEMWISE, 0, total * 16.0, s, cnet_act_forward_flat_kernel<false>, dim3(grid), dim3(256), 0, x, src, total, n, lin, slope,
+                mask, inv_keep, p, seed, post);
+    FR_LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
+  if (gen)
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 20.0, s, cnet_act_forward_kernel<true>, dim3(cdiv(n, FB_CB)), dim3(FB_CB, FB_RG), 0, x,
+              src, R, n, gamma, beta, running, training, lin, xhat, invstd, pre, slope, mask, inv_keep, p, seed, post);
+  else
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 20.0, s, cnet_act_forward_kernel<false>, dim3(cdiv(n, FB_CB)), dim3(FB_CB, FB_RG), 0, x,
+              src, R, n, gamma, beta, running, training, lin, xhat, invstd, pre, slope, mask, inv_keep, p, seed, post);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// gx = BN'( PReLU'(pre) * mask/keep * gy ): prelu_dropout_backward + bn_backward in one launch.  The intermediate gradient
+// is parked in gx between the two passes (each thread re-reads what it wrote); the slope gradient leaves through one atomic
+// per block (deterministic mode: per-block partials folded in block order).
+__global__ __launch_bounds__(1024) void cnet_act_bn_backward_kernel(const float* __restrict__ gy, GemmFold src,
+                                                                    const float* __restrict__ pre, const float* __restrict__ xhat,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                    const float* slope, const float* __restrict__ mask, float inv_keep,
+                                                                    int R, int n, int training, float* __restrict__ gx, float* ggamma,
+                                                                    float* gbeta, float* gslope, float* part) {
+  __shared__ double sh[FB_RG * FB_CB];
+  __shared__ float shs[16];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int j = blockIdx.x * FB_CB + tx;
+  const bool ok = j < n;
+  const size_t total = (size_t)R * n;
+  const float a = *slope;
+  double sg = 0.0, sgx = 0.0;
+  float sa = 0.f;
+  if (ok)
+    for (int r = ty; r < R; r += FB_RG) {
+      const size_t idx = (size_t)r * n + j;
+      float g = fold_value(gy, src, total, idx, j);
+      if (mask) g = g * (mask[idx] * inv_keep);
+      const float xv = pre[idx];
+      float t = g;
+      if (!(xv > 0.f)) { t = a * g; sa += xv * g; }
+      gx[idx] = t;
+      sg += t;
+      sgx += (double)t * xhat[idx];
+    }
+  sg = bn_reduce<FB_CB, FB_RG>(sg, sh, tx, ty);
+  sgx = bn_reduce<FB_CB, FB_RG>(sgx, sh, tx, ty);
+  // slope gradient: one number per block
+  {
+    const int tid = ty * FB_CB + tx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_down(sa, o, 64);
+    if ((tid & 63) == 0) shs[tid >> 6] = sa;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int i = 0; i < 16; ++i) t += shs[i];
+      if (part) part[blockIdx.x] = t; else unsafeAtomicAdd(gslope, t);
+    }
+  }
+  if (!ok) return;
+  if (ty == 0) {
+    ggamma[j] = (float)((double)ggamma[j] + sgx);
+    gbeta[j] = (float)((double)gbeta[j] + sg);
+  }
+  const double is = invstd[j], gm = gamma[j];
+  for (int r = ty; r < R; r += FB_RG) {
+    const size_t idx = (size_t)r * n + j;
+    const double g = gx[idx];
+    const double xh = xhat[idx];
+    const double v = training ? (g - sg / R - xh * sgx / R) * gm * is : g * gm * is;
+    gx[idx] = (float)v;
+  }
+}
+__global__ void slope_fold_kernel(const float* __restrict__ part, int n, float* gslope);
+int cnet_act_bn_backward(const float* gy, GemmFold src, const float* pre, const float* xhat, const float* invstd,
+                         const float* gamma, const float* slope, const float* mask, float inv_keep, int R, int n, int training,
+                         float* gx, float* ggamma, float* gbeta, float* gslope, hipStream_t s) {
+  const int grid = cdiv(n, FB_CB);
+  float* part = nullptr;
+  if (deterministic()) FR_TRY(det_workspace(s, (size_t)grid, &part));
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 28.0, s, cnet_act_bn_backward_kernel, dim3(grid), dim3(FB_CB, FB_RG), 0, gy, src, pre, xhat,
+            invstd, gamma, slope, mask, inv_keep, R, n, training, gx, ggamma, gbeta, gslope, part);
+  if (part) FR_LAUNCH(KC_ELEMWISE, 0, grid * 4.0, s, slope_fold_kernel, dim3(1), dim3(1), 0, (const float*)part, grid, gslope);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -202,6 +406,36 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
   return v;
 }
+// (fold variant: the logits are a deferred product -- folded once into `x`'s buffer by the row's own wave, then read back)
+__global__ void log_softmax_rows_fold_kernel(float* __restrict__ x, GemmFold src, int R, int n, float* __restrict__ y,
+                                             float* __restrict__ y2) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float* xr = x + (size_t)r * n;
+  const size_t total = (size_t)R * n;
+  if (src.nSplit)
+    for (int i = lane; i < n; i += 64) xr[i] = fold_value(x, src, total, (size_t)r * n + i, i);
+  double m = -1.0e300;
+  for (int i = lane; i < n; i += 64) m = xr[i] > m ? (double)xr[i] : m;
+  m = wave_max_f64(m);
+  double s = 0.0;
+  for (int i = lane; i < n; i += 64) s += exp((double)xr[i] - m);
+  s = wave_sum_f64(s);
+  const double lse = m + log(s);
+  for (int i = lane; i < n; i += 64) {
+    const float v = (float)((double)xr[i] - lse);
+    y[(size_t)r * n + i] = v;
+    if (y2) y2[(size_t)r * n + i] = v;
+  }
+}
+int log_softmax_rows_fold(const float* x, GemmFold src, int R, int n, float* y, float* y2, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * n * 8.0, s, log_softmax_rows_fold_kernel, dim3(cdiv(R, 4)), dim3(256), 0, const_cast<float*>(x),
+            src, R, n, y, y2);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 __global__ void log_softmax_rows_kernel(const float* __restrict__ x, int R, int n, float* __restrict__ y) {
   const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;

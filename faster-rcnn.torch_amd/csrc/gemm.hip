@@ -345,7 +345,8 @@ int gemm_reduce_slabs(const float* slab, int nSplit, int M, int N, const float* 
 }
 
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
-             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot) {
+             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot, GemmFold* defer) {
+  if (defer) *defer = GemmFold{};
   if (M <= 0 || N <= 0) return FRCNN_OK;
   GemmArgs p;
   p.A = A; p.sAm = sAm; p.sAk = sAk; p.B = B; p.sBk = sBk; p.sBn = sBn; p.C = C; p.ldc = ldc;
@@ -443,7 +444,9 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
 #undef GEMM_CASE
 #undef GEMM_LAUNCH
   }
-  if (splitK > 1) {
+  if (splitK > 1 && splitK <= 8 && defer && out_mode == OUT_STORE && ldc == N) {   // the consumer folds (see GemmFold; many slabs: the fold launch reads them coalesced)
+    defer->slab = p.C; defer->nSplit = splitK; defer->bias = bias_n;
+  } else if (splitK > 1) {
     long total = (long)M * N;
     int rgrid = (int)std::min<long>(cdivl(total, 256), 2048);
     FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (splitK + 1), s, gemm_reduce_kernel, dim3(rgrid), dim3(256), 0, (const float*)p.C,

@@ -427,7 +427,9 @@ static int launch_gx_tm(int TM, GxArgs& a, dim3 grid, double flops, double bytes
   }
 }
 
-static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const float* bias, int out_mode, hipStream_t s, int ws_slot) {
+static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const float* bias, int out_mode, hipStream_t s, int ws_slot,
+                  GemmFold* defer = nullptr) {
+  if (defer) *defer = GemmFold{};
   FR_CHECK(a.K % 16 == 0, "gemm_planes: K = %d must be a multiple of 16", a.K);
   int TM = 128, splitK = 1;
   gx_plan(a.M, a.N, a.K, bmode, splitK_max, &TM, &splitK);
@@ -447,28 +449,34 @@ static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const flo
   const int rc = bmode == 0 ? launch_gx_tm<0>(TM, a, grid, flops, bytes, s) : bmode == 1 ? launch_gx_tm<1>(TM, a, grid, flops, bytes, s)
                                                                                          : launch_gx_tm<2>(TM, a, grid, flops, bytes, s);
   FR_TRY(rc);
-  if (splitK > 1) FR_TRY(gemm_reduce_slabs(a.C, splitK, a.M, a.N, bias, user_C, a.ldc, out_mode == OUT_ADD, s));
+  if (splitK > 1 && splitK <= 8 && defer && out_mode == OUT_STORE && a.ldc == a.N) {   // the consumer folds (kernels.h: GemmFold; many slabs: the fold launch reads them coalesced)
+    defer->slab = a.C; defer->nSplit = splitK; defer->bias = bias;
+  } else if (splitK > 1) {
+    FR_TRY(gemm_reduce_slabs(a.C, splitK, a.M, a.N, bias, user_C, a.ldc, out_mode == OUT_ADD, s));
+  }
   return FRCNN_OK;
 }
 
 // Y[R][O] = X W^T + b ; Xp = planes of X, [3][I/8][R][8]
-int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot) {
+int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot,
+                     GemmFold* defer) {
   FR_CHECK(((uintptr_t)W & 3) == 0 && I % 16 == 0, "linear_x_forward: operand alignment");
   GxArgs a;
   a.Ap = (const unsigned short*)Xp; a.aPlane = (long)R * I; a.aLd = R;
   a.B = W; a.bPlane = 0; a.bLd = I;
   a.ldc = O; a.M = R; a.N = O; a.K = I;
-  return gx_run(a, 1, 32, y, bias, OUT_STORE, s, ws_slot);
+  return gx_run(a, 1, 32, y, bias, OUT_STORE, s, ws_slot, defer);
 }
 
 // gX[R][I] (= | +=) gY W ; Gp = planes of gY, [3][O/8][R][8]
-int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot) {
+int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot,
+                   GemmFold* defer) {
   FR_CHECK(((uintptr_t)W & 3) == 0 && I % 4 == 0 && O % 16 == 0, "linear_x_dgrad: operand alignment");
   GxArgs a;
   a.Ap = (const unsigned short*)Gp; a.aPlane = (long)R * O; a.aLd = R;
   a.B = W; a.bPlane = 0; a.bLd = I;
   a.ldc = I; a.M = R; a.N = I; a.K = O;
-  return gx_run(a, 2, 4, gx, nullptr, out_mode, s, ws_slot);
+  return gx_run(a, 2, 4, gx, nullptr, out_mode, s, ws_slot, defer);
 }
 
 // gW[O][I] += gY^T X ; GpT = planes of gY^T [3][Rp/8][O][8], XpT = planes of X^T [3][Rp/8][I][8] (k = r; r >= R zero)

@@ -125,10 +125,21 @@ int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, fl
                  bool scale_first, hipStream_t s, const double* gcount_dev = nullptr);
 
 // ---------------------------------------------------------------- gemm (gemm.hip)
-// C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.
+// C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.  defer: see GemmFold below.
+struct GemmFold;
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
-             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot = 0);
+             long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot = 0,
+             GemmFold* defer = nullptr);
 int gemm_workspace_get(size_t need, float** out, int slot);
+// A product whose split-K fold is left to its CONSUMER (round 4: the classification net's row-wise layers read the partial sums
+// themselves instead of waiting for a fold launch on the dependent chain): value(r, j) = bias[j] + sum_s slab[s][r * n + j] in
+// split order -- the number gemm_reduce_kernel would have stored -- or, nSplit == 0, what the product stored at its destination.
+// The slabs live in the stream's split-K workspace: the consumer must be the next launch that uses it.
+struct GemmFold {
+  const float* slab = nullptr;
+  int nSplit = 0;
+  const float* bias = nullptr;
+};
 int gemm_reduce_slabs(const float* slab, int nSplit, int M, int N, const float* bias, float* C, long ldc, bool accumulate,
                       hipStream_t s);
 // ---- split-bf16 operand form of the large Linear (gemmx.hip): activation operands as three bf16 planes written once
@@ -139,8 +150,10 @@ bool linear_x_eligible(int role, int R, int I, int O);   // role: 1 forward, 2 i
 int linear_x_rows_padded(int R);                       // rows of the transposed planes (R rounded up to 16, zero filled)
 int split_planes(const float* src, int R, int C, void* P /* [3][C/8][R][8] bf16 or null */, void* PT /* [3][Rp/8][C][8] or null */,
                  hipStream_t s);
-int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot = 0);
-int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot = 0);
+int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot = 0,
+                     GemmFold* defer = nullptr);
+int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot = 0,
+                   GemmFold* defer = nullptr);
 int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot = 0);
 
 
@@ -193,6 +206,19 @@ int prelu_dropout_forward_gen(const float* x, long n, const float* slope, float*
                               unsigned long long seed, float* y, hipStream_t s);
 int prelu_dropout_backward(const float* gy, const float* x, long n, const float* slope,
                            const float* mask, float inv_keep, float* gx, float* gslope, hipStream_t s);
+// ---- the same layers FUSED, and reading a product's split-K partial sums themselves (GemmFold; src.nSplit == 0: plain x)
+// fold (+ bias) -> [BatchNormalization ->] PReLU -> Dropout in ONE launch.  lin: the folded product (kept: the backward pass
+// of a layer without batch normalisation reads it); gamma == null: no batch normalisation (xhat / invstd / pre unused).
+// mask: given (gen = false; may be null = no dropout) or drawn here into it (gen = true, probability p, stream `seed`).
+int cnet_act_forward(const float* x, GemmFold src, int R, int n, const float* gamma, const float* beta, float* running,
+                     int training, float* lin, float* xhat, float* invstd, float* pre, const float* slope, float* mask, bool gen,
+                     float inv_keep, float p, unsigned long long seed, float* post, hipStream_t s);
+// Dropout -> PReLU -> BatchNormalization backward in ONE launch (gy may be a deferred product: the next layer's input gradient)
+int cnet_act_bn_backward(const float* gy, GemmFold src, const float* pre, const float* xhat, const float* invstd,
+                         const float* gamma, const float* slope, const float* mask, float inv_keep, int R, int n, int training,
+                         float* gx, float* ggamma, float* gbeta, float* gslope, hipStream_t s);
+// nn.LogSoftMax of a (possibly deferred) product, written to one or two destinations
+int log_softmax_rows_fold(const float* x, GemmFold src, int R, int n, float* y, float* y2, hipStream_t s);
 int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s);
 struct DropoutJobs { float* ptr[8]; int C[8]; float p[8]; unsigned long long seed[8]; int n; };
 int dropout_channel_masks(const DropoutJobs& j, hipStream_t s);

@@ -1044,6 +1044,11 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
 }
 
 // ------------------------------------------------------------------------------------ cnet
+// the row-wise layers fused with the folds of the products around them (cnet.hip: "fused forms"); FRCNN_CNET_FUSE=0: one launch each
+static bool cnet_fuse() {
+  const char* e = getenv("FRCNN_CNET_FUSE");   // (read per call: the tests switch it)
+  return !(e && atoi(e) == 0);
+}
 static int ensure_cnet(frcnn_model* m, int R) {
   for (auto& L : m->cls) {
     size_t n = (size_t)R * L.n * 4;
@@ -1082,20 +1087,15 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
   float* bnr = bn_running;
   for (size_t l = 0; l < m->cls.size(); ++l) {
     ClsLayer& L = m->cls[l];
+    GemmFold fold;   // (fused: the layer's row-wise kernel folds the product's split-K slabs itself)
+    GemmFold* defer = cnet_fuse() ? &fold : nullptr;
     if (L.x_form & 1) {   // split-bf16 operand form: the input's planes once
       FR_TRY(split_planes(cur, R, L.in, L.xp.p, nullptr, s));
-      FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s));
+      FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s, 0, defer));
     } else {
-      FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s));
+      FR_TRY(gemm_f32(cur, L.in, 1, w + L.w_off, 1, L.in, L.lin.f(), L.n, R, L.n, L.in, OUT_STORE, w + L.b_off, s, 0, defer));
     }
-    const float* pre = L.lin.f();
-    if (L.bn) {
-      FR_CHECK(training || bnr, "cnet_forward: evaluate mode needs bn_running");
-      FR_TRY(bn_forward(L.lin.f(), R, L.n, w + L.bnw_off, w + L.bnb_off, bnr, training, L.xhat.f(), L.invstd.f(),
-                        L.pre.f(), s));
-      if (bnr) bnr += 2 * L.n;
-      pre = L.pre.f();
-    }
+    if (L.bn) FR_CHECK(training || bnr, "cnet_forward: evaluate mode needs bn_running");
     const float* mask = nullptr;
     float inv_keep = 1.f;
     bool draw = false;
@@ -1107,6 +1107,21 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
         draw = true;   // mask drawn inside the activation kernel
       mask = L.mask.f();
     }
+    if (defer) {   // fold -> [BatchNormalization ->] PReLU -> Dropout: one launch
+      FR_TRY(cnet_act_forward(L.lin.f(), fold, R, L.n, L.bn ? w + L.bnw_off : nullptr, L.bn ? w + L.bnb_off : nullptr, L.bn ? bnr : nullptr,
+                              training, L.lin.f(), L.xhat.f(), L.invstd.f(), L.pre.f(), w + L.a_off, const_cast<float*>(mask), draw,
+                              inv_keep, L.p_drop, seed * 977 + l + 17, L.post.f(), s));
+      if (L.bn && bnr) bnr += 2 * L.n;
+      cur = L.post.f();
+      continue;
+    }
+    const float* pre = L.lin.f();
+    if (L.bn) {
+      FR_TRY(bn_forward(L.lin.f(), R, L.n, w + L.bnw_off, w + L.bnb_off, bnr, training, L.xhat.f(), L.invstd.f(),
+                        L.pre.f(), s));
+      if (bnr) bnr += 2 * L.n;
+      pre = L.pre.f();
+    }
     if (draw)
       FR_TRY(prelu_dropout_forward_gen(pre, (long)R * L.n, w + L.a_off, L.mask.f(), L.p_drop, seed * 977 + l + 17,
                                        L.post.f(), s));
@@ -1117,6 +1132,12 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
   const int nf = m->cls.empty() ? m->D : m->cls.back().n;
   const int nc = m->d.class_count + 1;
   FR_TRY(gemm_f32(cur, nf, 1, w + m->bbox_w_off, 1, nf, bbox_out, 4, R, 4, nf, OUT_STORE, w + m->bbox_b_off, s));
+  if (cnet_fuse()) {   // the class head's fold, nn.LogSoftMax and the copy to the caller's tensor: one launch
+    GemmFold fold;
+    FR_TRY(gemm_f32(cur, nf, 1, w + m->clsw_off, 1, nf, m->logits.f(), nc, R, nc, nf, OUT_STORE, w + m->clsb_off, s, 0, &fold));
+    FR_TRY(log_softmax_rows_fold(m->logits.f(), fold, R, nc, m->lsm.f(), cls_out, s));
+    return FRCNN_OK;
+  }
   FR_TRY(gemm_f32(cur, nf, 1, w + m->clsw_off, 1, nf, m->logits.f(), nc, R, nc, nf, OUT_STORE, w + m->clsb_off, s));
   FR_TRY(log_softmax_rows(m->logits.f(), R, nc, m->lsm.f(), s));
   FR_HIP(hipMemcpyAsync(cls_out, m->lsm.p, (size_t)R * nc * 4, hipMemcpyDeviceToDevice, s));
@@ -1165,15 +1186,26 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
   FR_TRY(gemm_f32(m->glog.f(), 1, nc, feat, nf, 1, grad + m->clsw_off, nf, nc, nf, R, OUT_ADD, nullptr, ws, wslot));
   FR_TRY(channel_sum_cols(m->glog.f(), R, nc, grad + m->clsb_off, ws));
   const float* g = m->feat_g.f();
+  GemmFold gfold;   // (fused: the gradient arriving from the layer above is a product whose slabs this layer's kernel folds)
   for (int l = (int)m->cls.size() - 1; l >= 0; --l) {
     ClsLayer& L = m->cls[l];
     const float* pre = L.bn ? L.pre.f() : L.lin.f();
     const bool drop = m->training && L.p_drop > 0.f;
-    FR_TRY(prelu_dropout_backward(g, pre, (long)R * L.n, w + L.a_off, drop ? L.mask.f() : nullptr,
-                                  drop ? 1.0f / (1.0f - L.p_drop) : 1.f, L.g.f(), grad + L.a_off, s));
-    if (L.bn)
-      FR_TRY(bn_backward(L.g.f(), L.xhat.f(), L.invstd.f(), w + L.bnw_off, R, L.n, m->training, L.g.f(),
-                         grad + L.bnw_off, grad + L.bnb_off, s));
+    if (L.bn && cnet_fuse()) {   // Dropout -> PReLU -> BatchNormalization backward: one launch
+      FR_TRY(cnet_act_bn_backward(g, gfold, pre, L.xhat.f(), L.invstd.f(), w + L.bnw_off, w + L.a_off, drop ? L.mask.f() : nullptr,
+                                  drop ? 1.0f / (1.0f - L.p_drop) : 1.f, R, L.n, m->training, L.g.f(), grad + L.bnw_off,
+                                  grad + L.bnb_off, grad + L.a_off, s));
+    } else {
+      FR_TRY(prelu_dropout_backward(g, pre, (long)R * L.n, w + L.a_off, drop ? L.mask.f() : nullptr,
+                                    drop ? 1.0f / (1.0f - L.p_drop) : 1.f, L.g.f(), grad + L.a_off, s));
+      if (L.bn)
+        FR_TRY(bn_backward(L.g.f(), L.xhat.f(), L.invstd.f(), w + L.bnw_off, R, L.n, m->training, L.g.f(),
+                           grad + L.bnw_off, grad + L.bnb_off, s));
+    }
+    gfold = GemmFold{};
+    // the input gradient of this layer is folded by the layer below when that one runs the fused kernel and nothing else
+    // touches this stream's split-K workspace in between (the weight-gradient products are on their own stream and slot)
+    GemmFold* gdefer = (cnet_fuse() && async && l > 0 && m->cls[l - 1].bn) ? &gfold : nullptr;
     FR_TRY(fork());   // L.g is final
     const float* in = l == 0 ? m->cnet_x : m->cls[l - 1].post.f();
     float* gin = l == 0 ? gx : L.gin.f();
@@ -1181,9 +1213,9 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     // chain: the gradient's planes (row-major orientation) and the input-gradient product
     if (xd) {
       FR_TRY(split_planes(L.g.f(), R, L.n, L.gp.p, nullptr, s));
-      FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s));
+      FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s, 0, gdefer));
     } else if (gin) {
-      FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s));
+      FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s, 0, gdefer));
     }
     // beside it: the weight gradient (planes in the transposed orientation) and the bias sums
     if (xw) {

@@ -349,6 +349,46 @@ def test_detect(F, O, setup):
         s["weights"].copy_(torch.from_numpy(s["w"]))
 
 
+def test_cnet_fused_layers_equal_separate_launches(F, setup, monkeypatch):
+    """Round 4: fold + BatchNormalization + PReLU + Dropout as one launch per layer (and their backward, and the class head's
+    fold + LogSoftMax) against one launch per operation (FRCNN_CNET_FUSE=0): same arithmetic, the fp64 column sums of the
+    batch normalisation meet in a different tree -- outputs, input gradient and the classification net's gradient within 1e-6."""
+    s = setup
+    model = s["model"]
+    cnet, nat = model["cnet"], model["native"]
+    rng = np.random.RandomState(21)
+    import torch
+    bn0 = nat.bn_running.cpu().numpy().copy()
+    for R in (37, 300):   # below / above the row count from which the large Linear takes the split-bf16 form
+        x = F.DeviceTensor.from_numpy(rng.randn(R, 13824).astype(np.float32))
+        masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
+        gb = F.DeviceTensor.from_numpy(rng.randn(R, 4).astype(np.float32))
+        gc = F.DeviceTensor.from_numpy((rng.randn(R, 17) / R).astype(np.float32))
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("FRCNN_CNET_FUSE", mode)
+            nat.bn_running.copy_(torch.from_numpy(bn0))
+            cnet.training()
+            cnet.drop_masks = masks
+            try:
+                bbox, cls = cnet.forward(x)
+                s["gradient"].zero_()
+                gx = cnet.backward(x, [gb, gc])
+                res[mode] = (bbox.numpy().copy(), cls.numpy().copy(), gx.numpy().copy(), s["gradient"].cpu().numpy().copy(),
+                             nat.bn_running.cpu().numpy().copy())
+            finally:
+                cnet.drop_masks = None
+        monkeypatch.delenv("FRCNN_CNET_FUSE", raising=False)
+        a, b = res["1"], res["0"]
+        for i, what in enumerate(("bbox", "log-probabilities", "input gradient")):
+            assert_close(a[i], b[i], 1e-6, "%s (R = %d)" % (what, R))
+        assert_close(a[4], b[4], 1e-6, "bn running statistics")
+        ga, gb_ = a[3][nat.pnet_params:], b[3][nat.pnet_params:]
+        assert np.abs(ga).max() > 0
+        assert np.linalg.norm(ga - gb_) <= 1e-6 * np.linalg.norm(gb_), (R, np.linalg.norm(ga - gb_) / np.linalg.norm(gb_))
+    nat.bn_running.copy_(torch.from_numpy(bn0))
+
+
 def test_detect_first_nms_bound(F, setup):
     """Detector.NMS_FIRST_CAP: the first NMS launch is sized for a bound on the matches; a frame with more matches than
     the bound repeats the pass sized by the count read back.  Same candidates, same winners either way."""
