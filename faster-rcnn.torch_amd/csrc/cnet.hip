@@ -28,10 +28,32 @@ __device__ __forceinline__ double bn_reduce(double v, double* sh, int tx, int ty
   __syncthreads();
   return s;
 }
+// The fused kernels' column sums: lanes = 16 row groups x 4 features, so four lane exchanges add a wave's row groups and the 16
+// waves meet in LDS -- two barriers instead of the nine of the tree above (fixed order: the same sums on every run).
+template <int NV>
+__device__ __forceinline__ void fb_reduce(double (&v)[NV], double* sh, int tx, int ty) {
+  const int tid = ty * 4 + tx, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
+    if (lane < 4) sh[(k * 16 + wave) * 4 + lane] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[(k * 16 + w) * 4 + tx];
+    v[k] = t;
+  }
+  __syncthreads();
+}
 // the fused kernels: 4 features x 256 row groups per block -- 256 blocks for the 1024-wide layer, two or three rows per thread
 // (with 16 x 64 the 64 blocks of the fused forward took 42 us: nine rows per thread, three dependent passes)
-#define FB_CB 4
+#define FB_CB 4   // (fb_reduce is written for 4 features x 256 row groups)
 #define FB_RG 256
+#define FB_KEEP 4   // rows a thread keeps in registers (batches of up to 1024 rows)
 
 __global__ __launch_bounds__(1024) void bn_forward_kernel(const float* __restrict__ x, int R, int n,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -141,24 +163,46 @@ __global__ __launch_bounds__(1024) void cnet_act_forward_kernel(const float* __r
   const bool ok = j < n;
   const size_t total = (size_t)R * n;
   const bool bn = gamma != nullptr;
-  // pass 0: the folded product (each thread re-reads only what it wrote itself)
+  // pass 0: the folded product.  A thread's (up to FB_KEEP) values stay in registers for the passes that follow -- ONE trip to
+  // memory instead of three dependent ones; taller batches re-read what the thread itself wrote.
   const float* v = src.nSplit ? lin : x;
+  const bool keep = R <= FB_RG * FB_KEEP;
+  float xv[FB_KEEP];
   double s0 = 0.0;
-  if (ok && (src.nSplit || (bn && training)))
-    for (int r = ty; r < R; r += FB_RG) {
-      const size_t idx = (size_t)r * n + j;
-      const float t = fold_value(x, src, total, idx, j);
-      if (src.nSplit) lin[idx] = t;
-      s0 += t;
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < FB_KEEP; ++i) {
+      const int r = ty + i * FB_RG;
+      xv[i] = 0.f;
+      if (keep && r < R) {
+        const size_t idx = (size_t)r * n + j;
+        xv[i] = fold_value(x, src, total, idx, j);
+        if (src.nSplit) lin[idx] = xv[i];
+        s0 += xv[i];
+      }
     }
+    if (!keep && (src.nSplit || (bn && training)))
+      for (int r = ty; r < R; r += FB_RG) {
+        const size_t idx = (size_t)r * n + j;
+        const float t = fold_value(x, src, total, idx, j);
+        if (src.nSplit) lin[idx] = t;
+        s0 += t;
+      }
+  }
   double mean = 0.0, is = 1.0, g = 1.0, b = 0.0;
   if (bn) {
     double var;
     if (training) {
-      mean = bn_reduce<FB_CB, FB_RG>(s0, sh, tx, ty) / R;
+      { double t[1] = {s0}; fb_reduce(t, sh, tx, ty); mean = t[0] / R; }
       double q = 0.0;
-      if (ok) for (int r = ty; r < R; r += FB_RG) { double d = v[(size_t)r * n + j] - mean; q += d * d; }
-      var = bn_reduce<FB_CB, FB_RG>(q, sh, tx, ty);
+      if (ok && keep) {
+#pragma unroll
+        for (int i = 0; i < FB_KEEP; ++i)
+          if (ty + i * FB_RG < R) { double d = xv[i] - mean; q += d * d; }
+      } else if (ok) {
+        for (int r = ty; r < R; r += FB_RG) { double d = v[(size_t)r * n + j] - mean; q += d * d; }
+      }
+      { double t[1] = {q}; fb_reduce(t, sh, tx, ty); var = t[0]; }
       const double unb = R > 1 ? var / (R - 1) : var / R;
       var /= R;
       if (running && ok && ty == 0) {
@@ -176,9 +220,7 @@ __global__ __launch_bounds__(1024) void cnet_act_forward_kernel(const float* __r
   }
   if (!ok) return;
   const float a = *slope;
-  for (int r = ty; r < R; r += FB_RG) {
-    const size_t idx = (size_t)r * n + j;
-    float y = v[idx];
+  auto emit = [&](size_t idx, float y) {
     if (bn) {
       const double xh = ((double)y - mean) * is;
       xhat[idx] = (float)xh;
@@ -194,6 +236,13 @@ __global__ __launch_bounds__(1024) void cnet_act_forward_kernel(const float* __r
       y = y * (mask[idx] * inv_keep);
     }
     post[idx] = y;
+  };
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < FB_KEEP; ++i)
+      if (ty + i * FB_RG < R) emit((size_t)(ty + i * FB_RG) * n + j, xv[i]);
+  } else {
+    for (int r = ty; r < R; r += FB_RG) emit((size_t)r * n + j, v[(size_t)r * n + j]);
   }
 }
 // (no batch normalisation: nothing couples the rows -- a plain element-wise pass, coalesced along the features)
@@ -243,8 +292,8 @@ int cnet_act_forward(const float* x, GemmFold src, int R, int n, const float* ga
 }
 
 // gx = BN'( PReLU'(pre) * mask/keep * gy ): prelu_dropout_backward + bn_backward in one launch.  The intermediate gradient
-// is parked in gx between the two passes (each thread re-reads what it wrote); the slope gradient leaves through one atomic
-// per block (deterministic mode: per-block partials folded in block order).
+// stays in registers between the two passes (taller batches: parked in gx, each thread re-reads what it wrote); the slope
+// gradient leaves through one atomic per block (deterministic mode: per-block partials folded in block order).
 __global__ __launch_bounds__(1024) void cnet_act_bn_backward_kernel(const float* __restrict__ gy, GemmFold src,
                                                                     const float* __restrict__ pre, const float* __restrict__ xhat,
                                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -260,20 +309,33 @@ __global__ __launch_bounds__(1024) void cnet_act_bn_backward_kernel(const float*
   const float a = *slope;
   double sg = 0.0, sgx = 0.0;
   float sa = 0.f;
-  if (ok)
+  const bool keep = R <= FB_RG * FB_KEEP;   // (the thread's gradients and xhat values stay in registers: see the forward kernel)
+  float tv[FB_KEEP], xh[FB_KEEP];
+  auto first = [&](size_t idx, float& t, float& xhv) {
+    float g = fold_value(gy, src, total, idx, j);
+    if (mask) g = g * (mask[idx] * inv_keep);
+    const float xv = pre[idx];
+    t = g;
+    if (!(xv > 0.f)) { t = a * g; sa += xv * g; }
+    xhv = xhat[idx];
+    sg += t;
+    sgx += (double)t * xhv;
+  };
+  if (ok && keep) {
+#pragma unroll
+    for (int i = 0; i < FB_KEEP; ++i) {
+      tv[i] = 0.f; xh[i] = 0.f;
+      if (ty + i * FB_RG < R) first((size_t)(ty + i * FB_RG) * n + j, tv[i], xh[i]);
+    }
+  } else if (ok) {
     for (int r = ty; r < R; r += FB_RG) {
       const size_t idx = (size_t)r * n + j;
-      float g = fold_value(gy, src, total, idx, j);
-      if (mask) g = g * (mask[idx] * inv_keep);
-      const float xv = pre[idx];
-      float t = g;
-      if (!(xv > 0.f)) { t = a * g; sa += xv * g; }
-      gx[idx] = t;
-      sg += t;
-      sgx += (double)t * xhat[idx];
+      float t, xhv;
+      first(idx, t, xhv);
+      gx[idx] = t;   // parked for the second pass
     }
-  sg = bn_reduce<FB_CB, FB_RG>(sg, sh, tx, ty);
-  sgx = bn_reduce<FB_CB, FB_RG>(sgx, sh, tx, ty);
+  }
+  { double t[2] = {sg, sgx}; fb_reduce(t, sh, tx, ty); sg = t[0]; sgx = t[1]; }
   // slope gradient: one number per block
   {
     const int tid = ty * FB_CB + tx;
@@ -293,12 +355,19 @@ __global__ __launch_bounds__(1024) void cnet_act_bn_backward_kernel(const float*
     gbeta[j] = (float)((double)gbeta[j] + sg);
   }
   const double is = invstd[j], gm = gamma[j];
-  for (int r = ty; r < R; r += FB_RG) {
-    const size_t idx = (size_t)r * n + j;
-    const double g = gx[idx];
-    const double xh = xhat[idx];
-    const double v = training ? (g - sg / R - xh * sgx / R) * gm * is : g * gm * is;
+  auto second = [&](size_t idx, double g, double xhv) {
+    const double v = training ? (g - sg / R - xhv * sgx / R) * gm * is : g * gm * is;
     gx[idx] = (float)v;
+  };
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < FB_KEEP; ++i)
+      if (ty + i * FB_RG < R) second((size_t)(ty + i * FB_RG) * n + j, tv[i], xh[i]);
+  } else {
+    for (int r = ty; r < R; r += FB_RG) {
+      const size_t idx = (size_t)r * n + j;
+      second(idx, gx[idx], xhat[idx]);
+    }
   }
 }
 __global__ void slope_fold_kernel(const float* __restrict__ part, int n, float* gslope);
