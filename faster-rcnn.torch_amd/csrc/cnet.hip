@@ -526,6 +526,140 @@ int log_softmax_rows(const float* x, int R, int n, float* y, hipStream_t s) {
   return FRCNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------ both heads, one launch each way
+// forward: the two heads' weights (4 + nc <= 32 rows of nf) are staged TRANSPOSED in LDS once per block ([k][33]: conflict-free both
+// ways), then one wave per row: lane = (output n = lane & 31, half h of the features), nf / 2 multiply-adds against LDS, one lane
+// exchange, LogSoftMax across the class lanes.  (A first version let every lane walk its own weight row in global memory with
+// fp64 multiply-adds: 29 us -- no faster than the four launches it replaced.)
+#define HEADS_PITCH 33
+__global__ __launch_bounds__(256) void cnet_heads_forward_kernel(const float* __restrict__ x, int R, int nf, const float* __restrict__ Wb,
+                                                                 const float* __restrict__ bb, const float* __restrict__ Wc,
+                                                                 const float* __restrict__ bc, int nc, float* __restrict__ bbox_out,
+                                                                 float* __restrict__ logits, float* __restrict__ lsm,
+                                                                 float* __restrict__ cls_out) {
+  extern __shared__ float wt[];   // [nf][HEADS_PITCH], then the four waves' rows [4][nf]
+  float* xs = wt + (size_t)nf * HEADS_PITCH + (threadIdx.x >> 6) * nf;
+  const int no = 4 + nc;
+  for (int k = threadIdx.x; k < nf; k += 256) {   // (row by row: coalesced reads, no division, every load independent)
+    float* d = wt + k * HEADS_PITCH;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) d[n] = Wb[(size_t)n * nf + k];
+#pragma unroll 8
+    for (int n = 0; n < nc; ++n) d[4 + n] = Wc[(size_t)n * nf + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+  const bool isb = n < 4, isc = n >= 4 && n < no;
+  const int nn = n < no ? n : 0, kh = nf / 2;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+    // the row comes to LDS in one coalesced sweep (64 dependent global loads per lane in the loop below made it 17 us)
+    for (int k = lane * 4; k < nf; k += 256) *reinterpret_cast<float4*>(xs + k) = *reinterpret_cast<const float4*>(x + (size_t)r * nf + k);
+    __builtin_amdgcn_wave_barrier();
+    const float* xr = xs + h * kh;
+    const float* wk = wt + (size_t)(h * kh) * HEADS_PITCH + nn;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < kh; k += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + k);   // (one address per lane half: an LDS broadcast)
+      a0 = fmaf(xv.x, wk[(k + 0) * HEADS_PITCH], a0); a1 = fmaf(xv.y, wk[(k + 1) * HEADS_PITCH], a1);
+      a2 = fmaf(xv.z, wk[(k + 2) * HEADS_PITCH], a2); a3 = fmaf(xv.w, wk[(k + 3) * HEADS_PITCH], a3);
+    }
+    float v = (a0 + a1) + (a2 + a3);
+    v += __shfl_xor(v, 32, 64);
+    v += isb ? bb[n] : isc ? bc[n - 4] : 0.f;
+    if (isb && h == 0) bbox_out[(size_t)r * 4 + n] = v;
+    // nn.LogSoftMax over the class lanes (max-shifted, fp64: log_softmax_rows_kernel); both halves hold the same values
+    const bool mine = isc && h == 0;
+    double m = mine ? (double)v : -1.0e300;
+    m = wave_max_f64(m);
+    double e = mine ? exp((double)v - m) : 0.0;
+    e = wave_sum_f64(e);
+    const double lse = m + log(e);
+    if (mine) {
+      const size_t o = (size_t)r * nc + n - 4;
+      const float l = (float)((double)v - lse);
+      logits[o] = v; lsm[o] = l;
+      if (cls_out) cls_out[o] = l;
+    }
+  }
+}
+// backward: the weights in LDS as they are ([4 + nc][nf]); one wave per row: lanes compute the LogSoftMax gradient of their class,
+// park the row's 4 + nc gradients in LDS, then lanes = features: gfeat[k] = sum_n g[n] W[n][k]
+__global__ __launch_bounds__(256) void cnet_heads_backward_kernel(const float* __restrict__ g_bbox, const float* __restrict__ g_cls,
+                                                                  const float* __restrict__ lsm, int R, int nf,
+                                                                  const float* __restrict__ Wb, const float* __restrict__ Wc, int nc,
+                                                                  float* __restrict__ glog, float* __restrict__ gfeat) {
+  extern __shared__ float wt[];   // [4 + nc][nf], then the four waves' gradients [4][64]
+  const int no = 4 + nc;
+  for (int k = threadIdx.x; k < nf; k += 256) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) wt[n * nf + k] = Wb[(size_t)n * nf + k];
+#pragma unroll 8
+    for (int n = 0; n < nc; ++n) wt[(4 + n) * nf + k] = Wc[(size_t)n * nf + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sg = wt + (size_t)no * nf + wave * 64;
+  const bool isb = lane < 4, isc = lane >= 4 && lane < no;
+  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+    const size_t o = (size_t)r * nc + (isc ? lane - 4 : 0);
+    const double gy = isc ? (double)g_cls[o] : 0.0;
+    const double sum = wave_sum_f64(gy);
+    float g = 0.f;
+    if (isc) {
+      g = (float)(gy - exp((double)lsm[o]) * sum);   // gx = gy - exp(lsm) * sum_j gy_j
+      glog[o] = g;
+    } else if (isb) {
+      g = g_bbox[(size_t)r * 4 + lane];
+    }
+    sg[lane] = g;
+    __builtin_amdgcn_wave_barrier();   // (a wave reads only what it wrote itself)
+    for (int k = lane; k < nf; k += 64) {
+      float a0 = 0.f, a1 = 0.f;
+      int n = 0;
+      for (; n + 2 <= no; n += 2) {
+        a0 = fmaf(sg[n], wt[n * nf + k], a0);
+        a1 = fmaf(sg[n + 1], wt[(n + 1) * nf + k], a1);
+      }
+      if (n < no) a0 = fmaf(sg[n], wt[n * nf + k], a0);
+      gfeat[(size_t)r * nf + k] = a0 + a1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+bool cnet_heads_fused_eligible(int nf, int nc) { return 4 + nc <= 32 && nf % 8 == 0 && nf <= 1024; }
+int cnet_heads_forward(const float* x, int R, int nf, const float* Wb, const float* bb, const float* Wc, const float* bc, int nc,
+                       float* bbox_out, float* logits, float* lsm, float* cls_out, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_CHECK(cnet_heads_fused_eligible(nf, nc), "cnet_heads_forward: %d classes", nc);
+  FR_CHECK(((uintptr_t)x & 15) == 0, "cnet_heads_forward: input alignment");
+  const size_t lds = ((size_t)nf * HEADS_PITCH + 4 * (size_t)nf) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnet_heads_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * nf * 4.0, s, cnet_heads_forward_kernel, dim3(std::min(cdiv(R, 4), 256)), dim3(256), lds, x, R, nf, Wb,
+            bb, Wc, bc, nc, bbox_out, logits, lsm, cls_out);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+int cnet_heads_backward(const float* g_bbox, const float* g_cls, const float* lsm, int R, int nf, const float* Wb, const float* Wc,
+                        int nc, float* glog, float* gfeat, hipStream_t s) {
+  if (R <= 0) return FRCNN_OK;
+  FR_CHECK(cnet_heads_fused_eligible(nf, nc), "cnet_heads_backward: %d classes", nc);
+  const size_t lds = ((size_t)(4 + nc) * nf + 256) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnet_heads_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * nf * 4.0, s, cnet_heads_backward_kernel, dim3(std::min(cdiv(R, 4), 256)), dim3(256), lds, g_bbox, g_cls,
+            lsm, R, nf, Wb, Wc, nc, glog, gfeat);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 // gx = gy - exp(lsm) * sum_j gy_j
 __global__ void log_softmax_backward_kernel(const float* __restrict__ gy, const float* __restrict__ lsm, int R,
                                             int n, float* __restrict__ gx) {

@@ -217,6 +217,15 @@ int cnet_act_forward(const float* x, GemmFold src, int R, int n, const float* ga
 int cnet_act_bn_backward(const float* gy, GemmFold src, const float* pre, const float* xhat, const float* invstd,
                          const float* gamma, const float* slope, const float* mask, float inv_keep, int R, int n, int training,
                          float* gx, float* ggamma, float* gbeta, float* gslope, hipStream_t s);
+// The two output heads of the classification net in ONE launch each way (4 + nc <= 32 outputs; models/model_utilities.lua:117-124):
+//   forward : bbox = x Wb^T + bb ; logits = x Wc^T + bc ; lsm = LogSoftMax(logits) (also copied to cls_out)
+//   backward: glog = LogSoftMax'(g_cls) ; gfeat = g_bbox Wb + glog Wc   (the weight gradients stay GEMMs on their own stream)
+// fp32 multiply-adds along the features (four partial sums per lane half), LogSoftMax in fp64.
+bool cnet_heads_fused_eligible(int nf, int nc);
+int cnet_heads_forward(const float* x, int R, int nf, const float* Wb, const float* bb, const float* Wc, const float* bc, int nc,
+                       float* bbox_out, float* logits, float* lsm, float* cls_out, hipStream_t s);
+int cnet_heads_backward(const float* g_bbox, const float* g_cls, const float* lsm, int R, int nf, const float* Wb, const float* Wc,
+                        int nc, float* glog, float* gfeat, hipStream_t s);
 // nn.LogSoftMax of a (possibly deferred) product, written to one or two destinations
 int log_softmax_rows_fold(const float* x, GemmFold src, int R, int n, float* y, float* y2, hipStream_t s);
 int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s);

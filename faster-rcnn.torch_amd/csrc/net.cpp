@@ -1131,6 +1131,10 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
   }
   const int nf = m->cls.empty() ? m->D : m->cls.back().n;
   const int nc = m->d.class_count + 1;
+  if (cnet_fuse() && cnet_heads_fused_eligible(nf, nc)) {   // both heads, nn.LogSoftMax and the copy to the caller's tensor: one launch
+    return cnet_heads_forward(cur, R, nf, w + m->bbox_w_off, w + m->bbox_b_off, w + m->clsw_off, w + m->clsb_off, nc, bbox_out,
+                              m->logits.f(), m->lsm.f(), cls_out, s);
+  }
   FR_TRY(gemm_f32(cur, nf, 1, w + m->bbox_w_off, 1, nf, bbox_out, 4, R, 4, nf, OUT_STORE, w + m->bbox_b_off, s));
   if (cnet_fuse()) {   // the class head's fold, nn.LogSoftMax and the copy to the caller's tensor: one launch
     GemmFold fold;
@@ -1177,10 +1181,15 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     return FRCNN_OK;
   };
   // heads: LogSoftMax backward first, then the two input gradients on the chain, the two weight gradients beside it
-  FR_TRY(log_softmax_backward(g_cls, m->lsm.f(), R, nc, m->glog.f(), s));
-  FR_TRY(fork());
-  FR_TRY(gemm_f32(g_bbox, 4, 1, w + m->bbox_w_off, nf, 1, m->feat_g.f(), nf, R, nf, 4, OUT_STORE, nullptr, s));
-  FR_TRY(gemm_f32(m->glog.f(), nc, 1, w + m->clsw_off, nf, 1, m->feat_g.f(), nf, R, nf, nc, OUT_ADD, nullptr, s));
+  if (cnet_fuse() && cnet_heads_fused_eligible(nf, nc)) {   // LogSoftMax backward + both input gradients: one launch
+    FR_TRY(cnet_heads_backward(g_bbox, g_cls, m->lsm.f(), R, nf, w + m->bbox_w_off, w + m->clsw_off, nc, m->glog.f(), m->feat_g.f(), s));
+    FR_TRY(fork());
+  } else {
+    FR_TRY(log_softmax_backward(g_cls, m->lsm.f(), R, nc, m->glog.f(), s));
+    FR_TRY(fork());
+    FR_TRY(gemm_f32(g_bbox, 4, 1, w + m->bbox_w_off, nf, 1, m->feat_g.f(), nf, R, nf, 4, OUT_STORE, nullptr, s));
+    FR_TRY(gemm_f32(m->glog.f(), nc, 1, w + m->clsw_off, nf, 1, m->feat_g.f(), nf, R, nf, nc, OUT_ADD, nullptr, s));
+  }
   FR_TRY(gemm_f32(g_bbox, 1, 4, feat, nf, 1, grad + m->bbox_w_off, nf, 4, nf, R, OUT_ADD, nullptr, ws, wslot));
   FR_TRY(channel_sum_cols(g_bbox, R, 4, grad + m->bbox_b_off, ws));
   FR_TRY(gemm_f32(m->glog.f(), 1, nc, feat, nf, 1, grad + m->clsw_off, nf, nc, nf, R, OUT_ADD, nullptr, ws, wslot));
