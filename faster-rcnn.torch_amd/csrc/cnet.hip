@@ -588,8 +588,11 @@ __global__ __launch_bounds__(256) void cnet_heads_forward_kernel(const float* __
 __global__ __launch_bounds__(256) void cnet_heads_backward_kernel(const float* __restrict__ g_bbox, const float* __restrict__ g_cls,
                                                                   const float* __restrict__ lsm, int R, int nf,
                                                                   const float* __restrict__ Wb, const float* __restrict__ Wc, int nc,
-                                                                  float* __restrict__ glog, float* __restrict__ gfeat) {
+                                                                  float* __restrict__ glog, float* __restrict__ gfeat, HeadsPostAct post) {
   extern __shared__ float wt[];   // [4 + nc][nf], then the four waves' gradients [4][64]
+  __shared__ float shs[4];
+  const float pa = post.pre ? *post.slope : 1.f;
+  float sa = 0.f;   // slope gradient of the layer below (post.pre != null: its Dropout + PReLU backward applied to the stored row)
   const int no = 4 + nc;
   for (int k = threadIdx.x; k < nf; k += 256) {
 #pragma unroll
@@ -622,9 +625,23 @@ __global__ __launch_bounds__(256) void cnet_heads_backward_kernel(const float* _
         a1 = fmaf(sg[n + 1], wt[(n + 1) * nf + k], a1);
       }
       if (n < no) a0 = fmaf(sg[n], wt[n * nf + k], a0);
-      gfeat[(size_t)r * nf + k] = a0 + a1;
+      float g = a0 + a1;
+      if (post.pre) {   // prelu_dropout_backward_kernel's arithmetic
+        const size_t idx = (size_t)r * nf + k;
+        if (post.mask) g = g * (post.mask[idx] * post.inv_keep);
+        const float xv = post.pre[idx];
+        if (!(xv > 0.f)) { sa += xv * g; g = pa * g; }
+      }
+      gfeat[(size_t)r * nf + k] = g;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (post.pre) {   // one atomic per block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sa += __shfl_down(sa, o, 64);
+    if (lane == 0) shs[wave] = sa;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(post.gslope, (shs[0] + shs[1]) + (shs[2] + shs[3]));
   }
 }
 bool cnet_heads_fused_eligible(int nf, int nc) { return 4 + nc <= 32 && nf % 8 == 0 && nf <= 1024; }
@@ -645,17 +662,17 @@ int cnet_heads_forward(const float* x, int R, int nf, const float* Wb, const flo
   return FRCNN_OK;
 }
 int cnet_heads_backward(const float* g_bbox, const float* g_cls, const float* lsm, int R, int nf, const float* Wb, const float* Wc,
-                        int nc, float* glog, float* gfeat, hipStream_t s) {
+                        int nc, float* glog, float* gfeat, hipStream_t s, const HeadsPostAct* post) {
   if (R <= 0) return FRCNN_OK;
   FR_CHECK(cnet_heads_fused_eligible(nf, nc), "cnet_heads_backward: %d classes", nc);
   const size_t lds = ((size_t)(4 + nc) * nf + 256) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnet_heads_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  static size_t attr_lds = 0;   // (the kernel also has a few bytes of static LDS: ask for what the launch needs, not for the CU's 160 KB)
+  if (lds > attr_lds) {
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cnet_heads_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
   }
   FR_LAUNCH(KC_ELEMWISE, 0, (double)R * nf * 4.0, s, cnet_heads_backward_kernel, dim3(std::min(cdiv(R, 4), 256)), dim3(256), lds, g_bbox, g_cls,
-            lsm, R, nf, Wb, Wc, nc, glog, gfeat);
+            lsm, R, nf, Wb, Wc, nc, glog, gfeat, post ? *post : HeadsPostAct{});
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -224,8 +224,17 @@ int cnet_act_bn_backward(const float* gy, GemmFold src, const float* pre, const 
 bool cnet_heads_fused_eligible(int nf, int nc);
 int cnet_heads_forward(const float* x, int R, int nf, const float* Wb, const float* bb, const float* Wc, const float* bc, int nc,
                        float* bbox_out, float* logits, float* lsm, float* cls_out, hipStream_t s);
+// post: the Dropout + PReLU backward of the layer below applied to the stored gradient (gfeat is then that layer's gradient; the
+// slope sum leaves through one atomic per block -- not in deterministic mode)
+struct HeadsPostAct {
+  const float* pre = nullptr;    // [R][nf] the layer's pre-activation values
+  const float* mask = nullptr;   // [R][nf] keep mask or null
+  float inv_keep = 1.f;
+  const float* slope = nullptr;  // device scalar
+  float* gslope = nullptr;       // device scalar, accumulated
+};
 int cnet_heads_backward(const float* g_bbox, const float* g_cls, const float* lsm, int R, int nf, const float* Wb, const float* Wc,
-                        int nc, float* glog, float* gfeat, hipStream_t s);
+                        int nc, float* glog, float* gfeat, hipStream_t s, const HeadsPostAct* post = nullptr);
 // nn.LogSoftMax of a (possibly deferred) product, written to one or two destinations
 int log_softmax_rows_fold(const float* x, GemmFold src, int R, int n, float* y, float* y2, hipStream_t s);
 int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStream_t s);

@@ -1181,8 +1181,20 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     return FRCNN_OK;
   };
   // heads: LogSoftMax backward first, then the two input gradients on the chain, the two weight gradients beside it
+  bool top_act_done = false;   // the last hidden layer's Dropout + PReLU backward was applied by the heads' launch (L.g is final)
   if (cnet_fuse() && cnet_heads_fused_eligible(nf, nc)) {   // LogSoftMax backward + both input gradients: one launch
-    FR_TRY(cnet_heads_backward(g_bbox, g_cls, m->lsm.f(), R, nf, w + m->bbox_w_off, w + m->clsw_off, nc, m->glog.f(), m->feat_g.f(), s));
+    HeadsPostAct post;
+    float* dst = m->feat_g.f();
+    if (!m->cls.empty() && !m->cls.back().bn && !deterministic()) {
+      ClsLayer& T = m->cls.back();
+      const bool drop = m->training && T.p_drop > 0.f;
+      post.pre = T.lin.f(); post.mask = drop ? T.mask.f() : nullptr; post.inv_keep = drop ? 1.0f / (1.0f - T.p_drop) : 1.f;
+      post.slope = w + T.a_off; post.gslope = grad + T.a_off;
+      dst = T.g.f();
+      top_act_done = true;
+    }
+    FR_TRY(cnet_heads_backward(g_bbox, g_cls, m->lsm.f(), R, nf, w + m->bbox_w_off, w + m->clsw_off, nc, m->glog.f(), dst, s,
+                               top_act_done ? &post : nullptr));
     FR_TRY(fork());
   } else {
     FR_TRY(log_softmax_backward(g_cls, m->lsm.f(), R, nc, m->glog.f(), s));
@@ -1200,7 +1212,9 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     ClsLayer& L = m->cls[l];
     const float* pre = L.bn ? L.pre.f() : L.lin.f();
     const bool drop = m->training && L.p_drop > 0.f;
-    if (L.bn && cnet_fuse()) {   // Dropout -> PReLU -> BatchNormalization backward: one launch
+    if (top_act_done && l == (int)m->cls.size() - 1) {
+      // (nothing: the heads' launch stored L.g)
+    } else if (L.bn && cnet_fuse()) {   // Dropout -> PReLU -> BatchNormalization backward: one launch
       FR_TRY(cnet_act_bn_backward(g, gfold, pre, L.xhat.f(), L.invstd.f(), w + L.bnw_off, w + L.a_off, drop ? L.mask.f() : nullptr,
                                   drop ? 1.0f / (1.0f - L.p_drop) : 1.f, R, L.n, m->training, L.g.f(), grad + L.bnw_off,
                                   grad + L.bnb_off, grad + L.a_off, s));
