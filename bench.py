@@ -470,7 +470,9 @@ def main():
     f = F.create_objective(model, weights, gradient, it, stats)
     state = dict(learningRate=1e-4, alpha=0.9)  # main.lua:122
 
-    user_stream = torch.cuda.Stream() if os.environ.get("FRCNN_BENCH_STREAM") else None   # (experiment: not the NULL stream)
+    # (experiments: FRCNN_BENCH_STREAM=1 a stream of the caller's own instead of the NULL stream, =hi the same with high priority)
+    user_stream = (torch.cuda.Stream(priority=-1) if os.environ.get("FRCNN_BENCH_STREAM") == "hi"
+                   else torch.cuda.Stream() if os.environ.get("FRCNN_BENCH_STREAM") else None)
 
     def step():
         if user_stream is not None:
