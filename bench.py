@@ -17,10 +17,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying
                     of 3) and with one thread on a 1/16-area frame (BASELINE.md section 4);
   "parity"       -- the GPU step on the oracle's inputs against the oracle's loss and gradient (the run
                     exits non-zero when they differ);
-  "other_legs"   -- BASELINE config 2 (Detector:detect, images/sec) and nms() alone at n = 300 ... 26 544,
-                    each with its CPU-restatement time and its id parity, measured after the timed region.
+  "other_legs"   -- BASELINE config 2 (Detector:detect, images/sec, with its own roofline / glue-time split) and nms()
+                    alone at n = 300 ... 26 544, each with its CPU-restatement time and its id parity, and BASELINE
+                    config 5's one-GPU workload (vgg_large), measured after the timed region;
+  "sustained"    -- the same metric over 1000 back-to-back steps (steady clocks; not `value`);
+  "roofline_hbm" -- the HBM-bound kernel classes of the step (RMSprop, ROI pooling, element-wise passes): algorithmic
+                    bytes / HIP-event time against the 8 TB/s peak.
   --comm native  -- the exchange step through the library's own communicator (frcnn_comm_*, the calls a LuaJIT
-                    host makes) instead of torch.distributed.
+                    host makes) instead of torch.distributed (the default since round 5: N > 1 has never run on
+                    hardware, and the torch.distributed path is the one the world-size-2 tests exercise).
 """
 import argparse
 import ctypes as C
@@ -39,6 +44,36 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # ... v_mfma_f32_32x32x16_bf16: 256 CUs x 4 SIMD
 SPLIT_PRODUCTS = 6              # bf16 x bf16 partial products per fp32 product in the split-operand kernels (convx.hip)
 CONV_CLASSES = ("conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "conv_x3", "conv_wgradx")
 FULL_H, FULL_W = 450, 800
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s is what a float4 copy reaches
+SUSTAINED_STEPS = 1000
+
+
+def csrc_sha256():
+    """Hash of the kernel sources + the ABI header: profiles/pmc_traffic.json records it when the PMC passes are taken, and
+    roofline.traffic is only printed while it still matches (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "faster-rcnn.torch_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "frcnn_hip.h")])
+    for fn in files:
+        if os.path.isfile(fn) and fn.rsplit(".", 1)[-1] in ("hip", "cpp", "h"):
+            h.update(os.path.basename(fn).encode()); h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def hbm_rows(F, launches, ms, by, names, steps):
+    """HBM-bound kernels of the step (RMSprop, ROI pooling, the element-wise passes): algorithmic bytes of the
+    class's launches (the library's own counters: what each launch must read and write) / their HIP-event durations,
+    against the 8 TB/s HBM peak."""
+    rows = []
+    for name in names:
+        i = F._lib.KC_NAMES.index(name)
+        if launches[i] and ms[i] > 0:
+            gbs = by[i] / 1e9 / (ms[i] / 1e3)
+            rows.append(dict(bound="hbm", kernel_class=name, launches_per_step=round(launches[i] / steps, 2), ms_per_step=round(ms[i] / steps, 4),
+                             algorithmic_mb_per_step=round(by[i] / 1e6 / steps, 2), achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(gbs / HBM_PEAK_GBS, 4)))
+    return rows
 
 
 def conv_flops_per_image(model, H, W):
@@ -209,6 +244,28 @@ def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
     out = dict(metric="images/sec (vgg_small 800x450 inference: Detector:detect)", value=round(1.0 / dt, 2), ms_per_image=round(dt * 1e3, 3),
                frames=n, matches=int(d.last_scan["n"]), candidates=int(len(d.last_pick)), winners=len(r),
                note="head logits amplified x30 (random weights would pass no anchor at p > 0.95)")
+    # where a frame's time goes: 8 more frames with every kernel class bracketed by HIP events (outside the timed frames)
+    nk = len(F._lib.KC_NAMES)
+    sink = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+    F._lib.call("frcnn_prof_collect", *sink)
+    F._lib.call("frcnn_prof_enable", (1 << nk) - 1)
+    for i in range(8):
+        d.detect(imgs[i % 4])
+    torch.cuda.synchronize()
+    F._lib.call("frcnn_prof_enable", 0)
+    la, ms, fl, by = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+    F._lib.call("frcnn_prof_collect", la, ms, fl, by)
+    k = F._lib.KC_NAMES.index("conv_x3")
+    if ms[k] > 0:
+        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        ach = (fl[k] / 1e12) / (ms[k] / 1e3)
+        conv_ms = sum(ms[F._lib.KC_NAMES.index(c)] for c in CONV_CLASSES) / 8.0
+        out["roofline"] = dict(bound="mfma", kernel="conv_x3_kernel (3x3 forward launches of the frame)", achieved=round(ach, 2), peak=round(peak, 1),
+                               unit="TFLOP/s", frac=round(ach / peak, 4), launches_per_frame=la[k] / 8.0, avg_launch_ms=round(ms[k] / max(la[k], 1), 4))
+        out["kernel_ms_per_frame"] = {name: round(ms[i] / 8.0, 4) for i, name in enumerate(F._lib.KC_NAMES) if la[i]}
+        out["conv_ms_per_frame"] = round(conv_ms, 4)
+        out["glue_ms_per_frame"] = round(dt * 1e3 - conv_ms, 4)   # scan, NMS, ROI pooling, classification net, read-backs, host
+        out["roofline_hbm"] = hbm_rows(F, la, ms, by, ("roi", "nms", "rpn"), 8)
     if with_cpu:
         O, oracle_model, _ = _oracle()
         om = oracle_model(O, cfg)
@@ -282,6 +339,9 @@ def large_leg(F, with_cpu, steps=12):
                roofline=dict(bound="mfma", kernel="conv_x3_kernel", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
                              frac=round(ach / peak, 4), launches_per_step=launches[k] / max(sampled, 1),
                              avg_launch_ms=round(ms[k] / max(launches[k], 1), 4)))
+    out["kernel_classes"] = {name: dict(launches_per_step=launches[i] / max(sampled, 1), ms_per_step=round(ms[i] / max(sampled, 1), 4),
+                                        tflops=round((fl[i] / 1e12) / (ms[i] / 1e3), 2) if fl[i] > 0 and ms[i] > 0 else None)
+                             for i, name in enumerate(F._lib.KC_NAMES) if launches[i]}
     if with_cpu:
         O, oracle_model, oracle_tables = _oracle()
         om = oracle_model(O, cfg, model["layers"], model["anchor_nets"], model["class_layers"])
@@ -396,9 +456,11 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
     ap.add_argument("--no-other-legs", action="store_true", help="skip the inference / nms legs")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the PCIe-inclusive pass (frames uploaded every step)")
-    ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "native"), choices=["torch", "native"],
-                    help="exchange back end at N > 1: the C ABI's frcnn_comm_* (RCCL; what a LuaJIT host calls) or "
-                         "torch.distributed ('nccl' = RCCL)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the %d-step sustained pass" % SUSTAINED_STEPS)
+    ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "torch"), choices=["torch", "native"],
+                    help="exchange back end at N > 1: torch.distributed ('nccl' = RCCL; the default -- the multi-rank path the "
+                         "world-size-2 tests cover) or the C ABI's own frcnn_comm_* (RCCL bound by the library; what a LuaJIT "
+                         "host calls)")
     args = ap.parse_args()
     if args.gpus < 1:
         _fail("--gpus must be >= 1")
@@ -522,6 +584,36 @@ def main():
     nk = len(F._lib.KC_NAMES)
     launches = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
     F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
+    # The same metric over SUSTAINED_STEPS steps (about three seconds of back-to-back steps, nothing bracketed): clocks and
+    # thermals are steady by then and an external SMI sampler sees the device busy.  `value` stays the K timed steps above.
+    sustained = None
+    if not args.no_sustained:
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(SUSTAINED_STEPS):
+            step()
+        barrier()
+        ts = time.perf_counter() - ts
+        if native_comm is not None:
+            ts = native_comm.gather_max(ts)
+        elif world > 1:
+            tmx = torch.tensor([ts], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            ts = float(tmx.item())
+        sustained = dict(steps=SUSTAINED_STEPS, value=round(world * SUSTAINED_STEPS / ts, 3), unit="images/sec",
+                         ms_per_step=round(1e3 * ts / SUSTAINED_STEPS, 3), seconds=round(ts, 2))
+    # HBM-bound kernels of the live step: four more steps with those classes bracketed
+    hbm = None
+    if world == 1:
+        hbm_names = ("optim", "roi", "elemwise")
+        F._lib.call("frcnn_prof_enable", sum(1 << F._lib.KC_NAMES.index(n) for n in hbm_names))
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        F._lib.call("frcnn_prof_enable", 0)
+        lh = (C.c_longlong * nk)(); mh = (C.c_double * nk)(); fh = (C.c_double * nk)(); bh = (C.c_double * nk)()
+        F._lib.call("frcnn_prof_collect", lh, mh, fh, bh)
+        hbm = hbm_rows(F, lh, mh, bh, hbm_names, 4)
     # Second, untimed pass with the library's side stream off: in the timed region the 3x3 input-gradient
     # launches share the CUs with the weight-gradient launches of the side stream, so their live duration
     # (roofline.achieved, as prescribed) is longer than the kernel needs when it has the GPU to itself.
@@ -591,7 +683,12 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("%s_bytes_per_launch" % F._lib.KC_NAMES[k])
-                traffic_taken = tj.get("taken")    # {git, date}: which tree the PMC passes measured (a stale table shows here)
+                traffic_taken = tj.get("taken")    # {git, date, csrc_sha256}: which tree the PMC passes measured
+                # a table taken from other kernel sources than the ones that just ran is not evidence about them: refuse it
+                if not traffic_taken or traffic_taken.get("csrc_sha256") != csrc_sha256():
+                    traffic_taken = dict(traffic_taken or {}, stale="the PMC table was taken from other kernel sources (csrc hash %s now): "
+                                                                    "roofline.traffic withheld; tools/refresh_round.sh renews it" % csrc_sha256())
+                    traffic = None
             except Exception:
                 traffic = None
         classes = {}
@@ -641,6 +738,8 @@ def main():
                           sampled_steps=sampled, launches_per_step=launches[k] / sampled, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),
+            roofline_hbm=hbm,
+            sustained=sustained,
         )
         out["config"]["exchange"] = dict(
             backend=("frcnn_comm (RCCL through the C ABI: frcnn_comm_init_rank_file / frcnn_allreduce_f32 / _f64)" if native_comm is not None

@@ -35,10 +35,7 @@ struct Rccl {
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
-  // optional (RCCL >= 2.14): the non-blocking initialisation the watchdog of frcnn_comm_init_rank_timeout uses
-  ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;
-  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
-  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional (RCCL >= 2.14): see settle()
   std::string err;
 };
 
@@ -70,9 +67,7 @@ bool rccl_load() {
   FR_SYM(CommUserRank, "ncclCommUserRank")
   FR_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef FR_SYM
-  *(void**)(&g_rccl.CommInitRankConfig) = dlsym(so, "ncclCommInitRankConfig");
   *(void**)(&g_rccl.CommGetAsyncError) = dlsym(so, "ncclCommGetAsyncError");
-  *(void**)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
   g_rccl.so = so;
   return true;
 }
@@ -85,6 +80,19 @@ bool rccl_load() {
       return FRCNN_ERR_HIP;                                                                        \
     }                                                                                              \
   } while (0)
+
+// A collective on a communicator that was made non-blocking behind our back (NCCL_COMM_BLOCKING=0 in the environment)
+// may answer ncclInProgress: the operation counts as enqueued only when the communicator's state has left that value.
+ncclResult_t settle(ncclComm_t comm, ncclResult_t r) {
+  while (r == ncclInProgress && g_rccl.CommGetAsyncError) {
+    ncclResult_t st = ncclSuccess;
+    ncclResult_t q = g_rccl.CommGetAsyncError(comm, &st);
+    if (q != ncclSuccess) return q;
+    r = st;
+    if (r == ncclInProgress) usleep(50);
+  }
+  return r;
+}
 
 double now_ms() {
   timespec ts;
@@ -187,10 +195,12 @@ int frcnn_comm_exchange_id_file(const char* path, int rank, void* id_host, int t
 }
 
 // ncclCommInitRank is a collective: a rank whose peer died between the rendezvous and this call would wait forever.
-// timeout_ms > 0 puts a watchdog on it.  With an RCCL that has the non-blocking initialisation (ncclCommInitRankConfig,
-// blocking = 0) the call returns at once, ncclCommGetAsyncError is polled until the communicator is ready, and on expiry
-// ncclCommAbort tears the half-built communicator down.  Otherwise the blocking call runs on a helper thread the caller
-// waits for with a deadline; on expiry the thread is abandoned (it owns nothing the caller touches again).
+// timeout_ms > 0 puts a watchdog on it: the BLOCKING call runs on a helper thread the caller waits for with a deadline; on
+// expiry the thread is abandoned (it owns nothing the caller touches again) and the caller gets an error.  The communicator
+// itself is always a blocking one -- the ordinary kind, whose collectives have been enqueued on the caller's stream when the
+// call returns.  (Round 4 built it with ncclCommInitRankConfig(blocking = 0) so that an expired initialisation could be
+// aborted; but such a communicator stays non-blocking for life: its collectives may return ncclInProgress and enqueue their
+// kernel later from a helper thread -- after the events the caller records behind the call.  ADVICE r4, high.)
 // FRCNN_COMM_CHANNELS=n caps the channels (= CUs) RCCL's kernels take: a throughput-bound training step shares the CUs
 // with the all-reduce of the previous bucket (NCCL_MAX_NCHANNELS, read by RCCL when the communicator is built).
 // FRCNN_COMM_FAULT=hang_init (tests): the initialisation never returns, as with a dead peer.
@@ -205,29 +215,10 @@ static int comm_init(frcnn_comm** out_host, int nranks, int rank, const void* id
   memcpy(&id, id_host, sizeof(id));
   int device = 0;
   if (!hang && hipGetDevice(&device) != hipSuccess) { frcnn::set_error("frcnn_comm_init_rank: no HIP device"); return FRCNN_ERR_HIP; }
-  const double t0 = now_ms();
   ncclComm_t comm = nullptr;
   ncclResult_t r = ncclSuccess;
   if (timeout_ms <= 0 && !hang) {
     r = g_rccl.CommInitRank(&comm, nranks, id, rank);   // collective: every rank of the job calls it
-  } else if (!hang && g_rccl.CommInitRankConfig && g_rccl.CommGetAsyncError && g_rccl.CommAbort) {
-    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-    cfg.blocking = 0;
-    r = g_rccl.CommInitRankConfig(&comm, nranks, id, rank, &cfg);
-    while (r == ncclSuccess || r == ncclInProgress) {
-      ncclResult_t st = ncclSuccess;
-      r = g_rccl.CommGetAsyncError(comm, &st);
-      if (r != ncclSuccess) break;
-      r = st;
-      if (st != ncclInProgress) break;
-      if (now_ms() - t0 > timeout_ms) {
-        g_rccl.CommAbort(comm);
-        frcnn::set_error("ncclCommInitRank(rank %d of %d) did not complete within %d ms: a peer is missing or dead "
-                         "(communicator aborted)", rank, nranks, timeout_ms);
-        return FRCNN_ERR_STATE;
-      }
-      usleep(1000);
-    }
   } else {
     struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclComm_t comm = nullptr; ncclResult_t r = ncclSuccess; };
     std::shared_ptr<Job> job = std::make_shared<Job>();
@@ -284,6 +275,7 @@ int frcnn_comm_init_rank_file(frcnn_comm** out_host, int nranks, int rank, const
 int frcnn_comm_destroy(frcnn_comm* c) {
   if (!c) return FRCNN_OK;
   ncclResult_t r = g_rccl.CommDestroy(c->comm);
+  if (r == ncclInProgress) r = ncclSuccess;   // (a non-blocking communicator finishes its teardown in the background)
   delete c;
   if (r != ncclSuccess) { frcnn::set_error("ncclCommDestroy failed: %s", g_rccl.GetErrorString(r)); return FRCNN_ERR_HIP; }
   return FRCNN_OK;
@@ -307,21 +299,21 @@ int frcnn_comm_query(const frcnn_comm* c, int* count_host, int* user_rank_host, 
 int frcnn_allreduce_f32(frcnn_comm* c, float* buf, long long n, void* stream) {
   FR_CHECK(c && (buf || n == 0) && n >= 0, "frcnn_allreduce_f32: bad arguments");
   if (n == 0) return FRCNN_OK;
-  FR_RCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, frcnn::S(stream)));
+  FR_RCCL(settle(c->comm, g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, frcnn::S(stream))));
   return FRCNN_OK;
 }
 
 int frcnn_allreduce_f64(frcnn_comm* c, double* buf, long long n, void* stream) {
   FR_CHECK(c && (buf || n == 0) && n >= 0, "frcnn_allreduce_f64: bad arguments");
   if (n == 0) return FRCNN_OK;
-  FR_RCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, c->comm, frcnn::S(stream)));
+  FR_RCCL(settle(c->comm, g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, c->comm, frcnn::S(stream))));
   return FRCNN_OK;
 }
 
 int frcnn_broadcast_f32(frcnn_comm* c, float* buf, long long n, int root, void* stream) {
   FR_CHECK(c && (buf || n == 0) && n >= 0 && root >= 0 && root < c->nranks, "frcnn_broadcast_f32: bad arguments");
   if (n == 0) return FRCNN_OK;
-  FR_RCCL(g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, c->comm, frcnn::S(stream)));
+  FR_RCCL(settle(c->comm, g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, c->comm, frcnn::S(stream))));
   return FRCNN_OK;
 }
 

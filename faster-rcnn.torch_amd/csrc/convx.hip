@@ -23,6 +23,10 @@
 
 #include "kernels.h"
 #include <type_traits>
+#ifdef CX_TRACE
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace frcnn {
 
@@ -221,6 +225,11 @@ struct CxArgs {
   int TH, TW, tilesX, tilesY, mTiles;
   int nChunks, splitK, chunksPerSplit;
   int out_mode;           // 0 store, 1 add, 3 split-K slab
+#ifdef CX_TRACE
+  unsigned long long* trace;   // [block][64] timestamps (s_memrealtime, 100 MHz) -- tools/x3_trace.py
+#endif
+  int prio;               // 1: static wave priority by dispatch round (blockIdx / 256): gang scheduling of the CU's co-resident blocks
+  int wide;               // 1: the epilogue goes through LDS and stores 16 bytes per lane (Wo % 4 == 0, TW % 4 == 0, aligned tensors)
   X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
 
@@ -236,8 +245,30 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CX_TRACE
+  auto stamp = [&](int slot) {
+    if (p.trace && tid == 0) {
+      p.trace[(size_t)blockIdx.x * 64 + slot] = __builtin_amdgcn_s_memrealtime();
+      p.trace[(size_t)blockIdx.x * 64 + 32 + slot] = __builtin_amdgcn_s_memtime();   // shader clock
+    }
+  };
+  stamp(0);
+  if (p.trace && tid == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.trace[(size_t)blockIdx.x * 64 + 7] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#else
+  auto stamp = [&](int) {};
+#endif
   const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
   const int h = lane >> 5, li = lane & 31;
+  if (p.prio) {
+    const int round = blockIdx.x >> 8;
+    if (p.prio == 1) { if (round == 0) __builtin_amdgcn_s_setprio(2); else if (round == 1) __builtin_amdgcn_s_setprio(1); }
+    else { if (round == 0) __builtin_amdgcn_s_setprio(0); else if (round == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+  }
 
   // XCD-aware order (see conv.hip): consecutive virtual indices of one XCD are the M tiles of one pixel tile
   const int nT = p.tilesX * p.tilesY;
@@ -391,10 +422,14 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   load_patch(cbeg);
   dma_stage(0, 0);
   store_patch(Bs);
+  stamp(1);
   bool more = false;
   int stage = 0;
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int par = KK % 2 == 0 ? 0 : (chunk - cbeg) & 1;   // A ring slot of the chunk's first tap
+#ifdef CX_TRACE
+    if (chunk - cbeg < 24) stamp(8 + chunk - cbeg);
+#endif
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap, ++stage) {
       // stage's A image (requested one stage ago) has landed in every wave's part; right after a chunk's first tap the
@@ -421,9 +456,88 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   // lane's rows are loaded in one batch before the stores, and the accumulate mode reads the 16 old values of a tile in one
   // batch (pixel clamped, not branched around): with a test, a bias load and an old-value load PER ELEMENT the compiler
   // emitted load - wait - add - store 64 times in a row -- 64 serialized memory round trips at the end of every block.
+  stamp(2);
   const long HoWo = (long)p.Ho * p.Wo;
   const bool add_bias = p.bias != nullptr && split == 0;
   const int mrow0 = m0 + wm * 64 + 4 * h;
+  // ---- wide epilogue.  The accumulator layout gives a lane ONE pixel of 16 filter rows: 64 dword stores per lane, each
+  // wave instruction two 128-byte pieces -- an issue-bound tail in a launch whose blocks all finish together.  Instead the
+  // wave turns its tile over in LDS (the A ring and the patch are dead by now): per 32-pixel column group the 64 x 32 tile is
+  // written as [filter][pixel] with ds_write_b32 (a wave instruction = two rows of 32 consecutive dwords: conflict-free) and
+  // read back as 16-byte pieces of four consecutive pixels (lane = (row & 7, pixel group); with a 32-dword pitch the four
+  // 16-lane groups of a ds_read_b128 touch 64 distinct banks), so a lane stores four pixels of one filter and a wave
+  // instruction writes eight filter rows of 128 bytes: 16 dwordx4 stores per lane instead of 64 dword stores, and x / the
+  // old values of the accumulate mode are read the same way.  Needs Wo % 4 == 0 and TW % 4 == 0 (a group of four pixels then
+  // never straddles a tile row or the map's edge and is 16-byte aligned); the launcher sets `wide` when that holds.
+  if (p.wide) {
+    __syncthreads();   // every wave is done with the last stage's fragments
+    float* const T = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+    const int rr = lane >> 3, pg = lane & 7;
+    const float pa = EPI == 1 ? *p.post.slope : 0.f;
+    float sa = 0.f;
+    float* const obase = p.out + (p.out_mode == 3 ? (size_t)split * p.M * HoWo : (size_t)0);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + li] = acc[mt][nt][r];
+      const int q = wn * (32 * NTW) + nt * 32 + 4 * pg;
+      const int ty = q / p.TW, tx = q - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      const bool ok = q < NT && oy < p.Ho && ox < p.Wo;
+      const size_t colo = ok ? (size_t)oy * p.Wo + ox : (size_t)0;
+      // two batches of four rows groups: 4 LDS reads + 4 global reads in flight, then 4 stores (16 + 16 registers)
+      const size_t rowo = (size_t)(m0 + wm * 64 + rr) * HoWo + colo;
+#pragma unroll
+      for (int ib = 0; ib < 8; ib += 4) {
+        float4 v[4], o[4];
+        float bsc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = m0 + wm * 64 + (ib + i) * 8 + rr;
+          const size_t off = rowo + (size_t)(ib + i) * 8 * HoWo;
+          v[i] = *reinterpret_cast<const float4*>(T + ((ib + i) * 8 + rr) * 32 + 4 * pg);
+          if (EPI == 1) {
+            o[i] = *reinterpret_cast<const float4*>(p.post.x + off);
+            bsc[i] = p.post.scale ? p.post.scale[f] : 1.f;
+          } else {
+            if (p.out_mode == 1) o[i] = *reinterpret_cast<const float4*>(obase + off);
+            bsc[i] = add_bias ? p.bias[f] : 0.f;
+          }
+        }
+        if (ok) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const size_t off = rowo + (size_t)(ib + i) * 8 * HoWo;
+            float4 w = v[i];
+            if (EPI == 1) {
+              float g;
+              g = w.x * bsc[i]; if (o[i].x > 0.f) w.x = g; else { sa += o[i].x * g; w.x = pa * g; }
+              g = w.y * bsc[i]; if (o[i].y > 0.f) w.y = g; else { sa += o[i].y * g; w.y = pa * g; }
+              g = w.z * bsc[i]; if (o[i].z > 0.f) w.z = g; else { sa += o[i].z * g; w.z = pa * g; }
+              g = w.w * bsc[i]; if (o[i].w > 0.f) w.w = g; else { sa += o[i].w * g; w.w = pa * g; }
+            } else {
+              w.x += bsc[i]; w.y += bsc[i]; w.z += bsc[i]; w.w += bsc[i];
+              if (p.out_mode == 1) { w.x += o[i].x; w.y += o[i].y; w.z += o[i].z; w.w += o[i].w; }
+            }
+            *reinterpret_cast<float4*>(obase + off) = w;
+          }
+        }
+      }
+    }
+    if (EPI == 1) {
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) sa += __shfl_xor(sa, o2);
+      if (lane == 0 && p.post.gslope) unsafeAtomicAdd(p.post.gslope, sa);
+    }
+#ifdef CX_TRACE
+    stamp(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(4);
+#endif
+    return;
+  }
   float bv[2][16];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -494,6 +608,11 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
   else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
   else store_tile(std::integral_constant<int, 3>{});
+#ifdef CX_TRACE
+  stamp(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(4);
+#endif
 }
 
 // out[m][p] (= | +=) bias[m] + sum_s slab[s][m][p]
@@ -564,11 +683,29 @@ static int x3_workspace(size_t need, float** out, int slot) {
 }
 
 // output tile TH x TW <= 128 pixels with a patch plane <= CX_PP that wastes the least work
+// FRCNN_X3_WIDE=0: the scalar epilogue everywhere (and tile widths of any size)
+static int x3_wide_enabled() {
+  static const int on = getenv("FRCNN_X3_WIDE") ? atoi(getenv("FRCNN_X3_WIDE")) : 1;
+  return on;
+}
 static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
+  static int fth = 0, ftw = 0;   // FRCNN_X3_TILE=THxTW (experiments)
+  static bool parsed = false;
+  if (!parsed) {
+    parsed = true;
+    if (const char* e = getenv("FRCNN_X3_TILE")) sscanf(e, "%dx%d", &fth, &ftw);
+  }
+  if (fth > 0 && ftw > 0 && k == 3 && fth * ftw <= CX_NTMAX && (fth + k - 1) * (ftw + k - 1) <= CX_PP) {
+    *TH = std::min(fth, Ho); *TW = std::min(ftw, Wo);
+    return;
+  }
+  // the wide epilogue stores groups of four pixels: tile widths that are multiples of 4 where the map's width is one
+  const int mult = (x3_wide_enabled() && Wo % 4 == 0) ? 4 : 1;
   long best = -1;
   int bth = 1, btw = 1;
   for (int tw = 1; tw <= std::min(Wo, CX_NTMAX); ++tw) {
     if (tw < 8 && Wo >= 8) continue;
+    if (tw % mult != 0) continue;
     int th = std::min(CX_NTMAX / tw, Ho);
     while (th > 1 && (th + k - 1) * (tw + k - 1) > CX_PP) --th;
     if (th < 1 || (th + k - 1) * (tw + k - 1) > CX_PP) continue;
@@ -588,10 +725,34 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
+#ifdef CX_TRACE
+  static unsigned long long* tbuf = nullptr;
+  const char* tfile = getenv("FRCNN_X3_TRACE");
+  if (tfile && !tbuf) FR_HIP(hipMalloc(&tbuf, 8192 * 512));
+  a.trace = tfile && grid <= 8192 ? tbuf : nullptr;
+  if (a.trace) FR_HIP(hipMemsetAsync(tbuf, 0, (size_t)grid * 512, s));
+#endif
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
-  const size_t lds = (size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * CX_BBUF;
+  // (the wide epilogue turns four 64 x 32 fp32 tiles over in LDS: 32 KB)
+  static const size_t lds_min = getenv("FRCNN_X3_LDS_MIN") ? (size_t)atol(getenv("FRCNN_X3_LDS_MIN")) : 0;   // (experiments: fewer blocks per CU)
+  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * CX_BBUF, a.wide ? 4 * 64 * 32 * 4 : 0));
   FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
+#ifdef CX_TRACE
+  if (a.trace) {   // the last launch's stamps, one line per block
+    FR_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hst((size_t)grid * 64);
+    FR_HIP(hipMemcpy(hst.data(), tbuf, hst.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(tfile, "w")) {
+      fprintf(f, "# grid %d M %d Cin %d Ho %d Wo %d TH %d TW %d splitK %d wide %d WM %d EPI %d\n", grid, a.M, a.Cin, a.Ho, a.Wo, a.TH, a.TW, a.splitK, a.wide, WM, EPI);
+      for (int b = 0; b < grid; ++b) {
+        for (int j = 0; j < 64; ++j) fprintf(f, "%llu ", hst[(size_t)b * 64 + j]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return FRCNN_OK;
 }
 
@@ -620,6 +781,9 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
   a.post = post ? *post : X3PostAct{nullptr, nullptr, nullptr, nullptr};
+  static const int prio_env = getenv("FRCNN_X3_PRIO") ? atoi(getenv("FRCNN_X3_PRIO")) : 0;
+  a.prio = prio_env;
+  a.wide = 0;   // decided below, once the destination (tensor or slab) is known
   FR_CHECK(!post || (k == 3 && out_mode == OUT_STORE && !in_slope && !in_scale && !bias && post->x && post->slope),
            "conv_x3: the fused activation backward belongs to a storing 3x3 input-gradient launch");
   bool slab = false;
@@ -628,6 +792,8 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
+  a.wide = x3_wide_enabled() && a.Wo % 4 == 0 && a.TW % 4 == 0 && ((uintptr_t)a.out & 15) == 0 &&
+           (!post || ((uintptr_t)post->x & 15) == 0);
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);

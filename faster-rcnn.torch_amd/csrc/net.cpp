@@ -501,8 +501,10 @@ static int ensure_side(frcnn_model* m) {
     // the classification net's weight gradients off its chain as well (g_cnet_wgrad_async) the step goes from 3.11 to
     // 3.02 ms, with either change alone it stays at 3.11.  On by default since then.
     static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 1;
+    size_t hi = 0;
     for (auto& h : m->heads) {
-      if (head_streams) FR_HIP(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+      // (five workspace slots for streams of their own, head_slot(): a sixth anchor net shares the side stream and its slot)
+      if (head_streams && hi++ < 5) FR_HIP(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
       FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
     }
   }
@@ -510,7 +512,9 @@ static int ensure_side(frcnn_model* m) {
 }
 
 static hipStream_t head_stream(frcnn_model* m, size_t i) { return m->heads[i].stream ? m->heads[i].stream : m->side; }
-static int head_slot(frcnn_model* m, size_t i) { return m->heads[i].stream ? 2 + (int)(i % 6) : 1; }   // split-K workspace slot
+// split-K workspace slot of anchor net i: 2..6 (slot 7 belongs to the classification net's weight-gradient stream, 0 / 1 to the
+// caller's and the side stream); build_layout gives streams of their own to at most five anchor nets
+static int head_slot(frcnn_model* m, size_t i) { return m->heads[i].stream ? 2 + (int)(i % 5) : 1; }
 
 // the caller's stream waits for everything queued on the side stream so far
 static int join_heads(frcnn_model* m, hipStream_t s) {

@@ -473,21 +473,14 @@ static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s
   return FRCNN_OK;
 }
 
-// does the allocation `p` lives in extend at least `slack` bytes past p + bytes?  (hipMemGetAddressRange; answers are cached per
-// allocation base: the model's tensors are allocated once per image size)
+// does the allocation `p` lives in extend at least `slack` bytes past p + bytes?  Asked of the runtime at every launch that
+// needs it (a host-side table look-up; only widths that are no multiple of 4 come here): a cached answer would outlive a
+// free + smaller re-allocation at the same base and approve a read past the new end.
 static bool readable_past_end(const void* p, size_t bytes, size_t slack) {
-  struct Range { uintptr_t base, end; };
-  static Range cache[16];
-  static int ncache = 0;
-  const uintptr_t a = (uintptr_t)p;
-  for (int i = 0; i < ncache; ++i)
-    if (a >= cache[i].base && a < cache[i].end) return a + bytes + slack <= cache[i].end;
   hipDeviceptr_t base = nullptr;
   size_t size = 0;
   if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const Range r{(uintptr_t)base, (uintptr_t)base + size};
-  cache[ncache < 16 ? ncache++ : (ncache = 1, 0)] = r;
-  return a + bytes + slack <= r.end;
+  return (uintptr_t)p + bytes + slack <= (uintptr_t)base + size;
 }
 
 template <bool SLOPE, bool SCALE>

@@ -232,6 +232,7 @@ class ClassificationNet(object):
         self.drop_masks = None
         self.output = None
         self._bufs = {}
+        self._pending = None
 
     def _buf(self, name, shape):
         """Module-owned output / gradInput buffers, reused by the next call like nn.Module's (hipMalloc /
@@ -273,7 +274,15 @@ class ClassificationNet(object):
         gx = self._buf("gx", (R, D))
         _lib.call("frcnn_cnet_backward", nat.h, ptr(nat.weights), ptr(grad_outputs[0]), ptr(grad_outputs[1]), ptr(gx),
                   ptr(nat.gradient), stream_ptr())
+        # the library's weight-gradient stream reads these until the join (include/frcnn_hip.h, LIFETIME): keep them
+        # alive -- and out of the caching allocator's hands -- until the next forward / join replaces the references
+        self._pending = (self._input, grad_outputs[0], grad_outputs[1])
         return gx
+
+    def join_backward(self):
+        """frcnn_cnet_backward_join on the current stream; the buffers held for the asynchronous part are released."""
+        _lib.call("frcnn_cnet_backward_join", self.native.h, stream_ptr())
+        self._pending = None
 
     def parameters(self):
         return _param_views(self.native, self.native.pnet_params, self.native.total_params)

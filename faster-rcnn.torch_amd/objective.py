@@ -224,7 +224,8 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         return [e for e in examples
                 if not (e[0].index[1] > outputs[e[0].layer - 1].shape[1] or e[0].index[2] > outputs[e[0].layer - 1].shape[2])]
 
-    prepared = {}   # id(batch entry) -> tables packed ahead of the pass (finish(), while the host waits for the device)
+    prepared = {}   # id(batch entry) -> (the entry itself, tables packed ahead of the pass: finish(), while the host waits for
+                    # the device); the entry is held so that its id cannot be re-used by another object while the tables wait
 
     def map_sizes(H, W):
         """Sizes of the anchor nets' outputs and of the last pooled map for an H x W image (ceil-mode pooling,
@@ -314,10 +315,12 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
             # the example tables are host work that needs no device result (the map sizes follow from the image size): they
             # were packed while the host waited for the previous step (finish()), or are packed now -- before the forward
             # pass is queued, not between it and the stage that consumes them, where the device would run dry
-            prep = prepared.pop(id(x), None) or prepare_examples(x)
+            held = prepared.pop(id(x), None)
+            prep = held[1] if held is not None and held[0] is x else prepare_examples(x)
             img = to_device(x["img"])  # :66
             outputs = pnet.forward(img, async_heads=True)  # :71 (the anchor nets stay in flight beside the cnet stage)
-            assert prep["sizes"] == [tuple(o.shape[1:]) for o in outputs[:len(prep["sizes"])]] and prep["fm"] == tuple(outputs[-1].shape[1:])
+            if prep["sizes"] != [tuple(o.shape[1:]) for o in outputs[:len(prep["sizes"])]] or prep["fm"] != tuple(outputs[-1].shape[1:]):
+                raise _lib.FrcnnError("lossAndGradient: the example tables were packed for other map sizes than this image's")
             p, n = prep["p"], prep["n"]  # :74-75
             delta_outputs = pnet.delta_outputs(zero=True)  # :78-84
             npos, nneg = len(p), len(n)
@@ -450,7 +453,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 next_batch[0] = batch_iterator.nextTraining()
                 prepared.clear()
                 for xb in next_batch[0]:   # ... and its example tables are packed (host work with no device input)
-                    prepared[id(xb)] = prepare_examples(xb)
+                    prepared[id(xb)] = (xb, prepare_examples(xb))
             acc_event.synchronize()
             a = acc_pin.numpy().copy()
         if counts is None:   # device tail: the (all-reduced) counts sit in the slots the kernels leave alone

@@ -347,7 +347,12 @@ int frcnn_cnet_forward(frcnn_model *, const float *weights, const float *x, int 
 /* cnet:backward.  The input gradient gx is final on `stream` in stream order; the weight gradients and bias sums it adds to
  * `grad` are queued on a library-owned stream beside that chain (option "cnet_wgrad_async", default 1) and are final on
  * `stream` after frcnn_pnet_backward, the next frcnn_cnet_forward, or frcnn_cnet_backward_join -- or after a device-wide
- * synchronisation. */
+ * synchronisation.
+ * LIFETIME: until one of those joins has been queued, the library-owned stream still READS caller-owned memory -- g_bbox,
+ * g_cls, the `x` that was passed to frcnn_cnet_forward (first layer's weight gradient) -- and WRITES `grad`.  The caller
+ * must neither modify nor free those buffers, nor let a stream-ordered allocator hand them out again, before the join
+ * is queued on the stream that does so (a caching allocator: record the join's stream on the tensors, or hold references
+ * until then).  frcnn_set_option("cnet_wgrad_async", 0) keeps everything on `stream` for a caller that cannot promise it. */
 int frcnn_cnet_backward_join(frcnn_model *, void *stream);
 int frcnn_cnet_backward(frcnn_model *, const float *weights, const float *g_bbox,
                         const float *g_cls, float *gx, float *grad, void *stream);

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for r in 1 2 3; do
   for mode in base knob; do
     if [ "$mode" = knob ]; then export "$knob"; else unset "${knob%%=*}"; fi
-    python bench.py --steps "$steps" --warmup 15 2>/dev/null | python -c "
+    python bench.py --steps "$steps" --warmup 15 --no-sustained 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

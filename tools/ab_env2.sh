@@ -2,7 +2,7 @@
 # like ab_env.sh for several knobs against one baseline: tools/ab_env2.sh steps KNOB=V [KNOB=V ...]
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 steps="$1"; shift
-run() { python bench.py --steps "$steps" --warmup 15 --no-cpu-baseline --no-upload-leg 2>/dev/null | python -c "
+run() { python bench.py --steps "$steps" --warmup 15 --no-cpu-baseline --no-upload-leg --no-sustained 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -5,7 +5,7 @@ other="$1"; steps="${2:-60}"
 for r in 1 2 3; do
   for mode in base other; do
     if [ "$mode" = other ]; then export FRCNN_LIB_PATH="$PWD/$other"; else unset FRCNN_LIB_PATH; fi
-    python bench.py --steps "$steps" --warmup 15 2>/dev/null | python -c "
+    python bench.py --steps "$steps" --warmup 15 --no-sustained 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

@@ -26,9 +26,17 @@ def run(kind, name, reps=5):
     Cin, H, W, O, k, pad = LAYERS[name]
     Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
     rng = np.random.RandomState(0)
-    x = F.DeviceTensor.from_numpy(rng.randn(Cin, H, W).astype(np.float32))
-    g = F.DeviceTensor.from_numpy(rng.randn(O, Ho, Wo).astype(np.float32))
-    w = F.DeviceTensor.from_numpy((rng.randn(O, Cin, k, k) * 0.05).astype(np.float32))
+    # DATA=zero | bf16 (values with 8 significant bits: the m and l planes of the split are zero) | default: normal deviates
+    mode = os.environ.get("DATA", "randn")
+    def data(*shape, s=1.0):
+        v = (rng.randn(*shape) * s).astype(np.float32)
+        if mode == "zero": v[:] = 0
+        if mode == "bf16": v = (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        if mode == "sparse": v = np.maximum(v, 0) * (rng.rand(shape[0], 1, 1) > 0.4)   # PReLU-like outputs behind a SpatialDropout
+        return np.ascontiguousarray(v, dtype=np.float32)
+    x = F.DeviceTensor.from_numpy(data(Cin, H, W))
+    g = F.DeviceTensor.from_numpy(data(O, Ho, Wo))
+    w = F.DeviceTensor.from_numpy(data(O, Cin, k, k, s=0.05))
     gw = F.DeviceTensor.zeros((O, Cin, k, k)); out = F.DeviceTensor.empty((O, Ho, Wo)); gin = F.DeviceTensor.empty((Cin, H, W))
     act = bool(os.environ.get("WITH_ACT"))   # fused PReLU + dropout scale of the producing layer on the input
     slope = F.DeviceTensor.from_numpy(np.array([0.25], np.float32)); scale = F.DeviceTensor.from_numpy((rng.rand(Cin) > 0.4).astype(np.float32))

@@ -42,7 +42,9 @@ if not git:
         git = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
     except Exception:
         git = "unknown (no .git on the GPU box: set FRCNN_GIT_HASH)"
-out["taken"] = dict(git=git, date=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import csrc_sha256   # the hash bench.py compares before it prints roofline.traffic
+out["taken"] = dict(git=git, date=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), csrc_sha256=csrc_sha256())
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("bytes/launch: conv_x3", out.get("conv_x3_bytes_per_launch"), " conv_wgradx", out.get("conv_wgradx_bytes_per_launch"),
       " conv_igemm_k3", out.get("conv_igemm_k3_bytes_per_launch"), " rmsprop:", out.get("calibration_rmsprop"))

@@ -4,7 +4,7 @@
 TAG=${1:-r04}
 export FRCNN_GIT_HASH=${2:-${FRCNN_GIT_HASH:-unknown}}   # the tree the measurements belong to (the GPU box has no .git): pass `git rev-parse --short HEAD`
 R=/root/repo; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-upload-leg"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-upload-leg --no-sustained"
 # 1. PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1
@@ -28,7 +28,7 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 PY
 # 2. kernel stats of the bench command (rocprofv3 --kernel-trace --stats) and the step timeline of the same trace
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-upload-leg > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-upload-leg --no-sustained > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
 cd $R
 cp $O/stats/*/*kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv 2>/dev/null
 python tools/timeline.py $O/stats 12 > $O/${TAG}_step_timeline.txt 2>&1
@@ -51,11 +51,11 @@ python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
   timeout 60 tools/bin/lds_dma_probe 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
   for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0" "FRCNN_GEMM_X=0" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=0" "FRCNN_CNET_WGRAD_ASYNC=0" "FRCNN_FUSE_ACT=0" "FRCNN_FIRST_POOLED=0"; do
-    echo -n "$e: "; env $e python bench.py --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
+    echo -n "$e: "; env $e python bench.py --no-cpu-baseline --no-sustained --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
   done
   echo "# config 5 shapes on one GPU -- python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline"
   for e in "FRCNN_SPLIT_BF16=1" "FRCNN_SPLIT_BF16=0"; do
-    echo -n "$e: "; env $e python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'images/s', d['ms_per_step'], 'ms/step; conv_igemm 3x3', r['achieved'], 'TFLOP/s live,', r['isolated']['achieved'], 'alone')"
+    echo -n "$e: "; env $e python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline --no-sustained 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'images/s', d['ms_per_step'], 'ms/step; conv_igemm 3x3', r['achieved'], 'TFLOP/s live,', r['isolated']['achieved'], 'alone')"
   done
   echo "# the cnet's Linear(13824,1024) in its three roles, split-bf16 form and (FRCNN_GEMM_X=0) fp32 matrix-core kernels -- python tools/bench_gemm.py"
   python tools/bench_gemm.py 2>/dev/null | grep "I=13824"; FRCNN_GEMM_X=0 python tools/bench_gemm.py 2>/dev/null | grep "I=13824"
