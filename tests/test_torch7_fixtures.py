@@ -1,0 +1,194 @@
+"""The reference's own Torch7 stack as the judge of oracle/ASSUMPTIONS.md.
+
+`tools/make_torch7_fixtures.lua`, run once with the reference's `th` (this image has no Lua), writes
+`tests/golden/torch7_fixtures.t7`: for every row of the assumptions table a small input and what Torch7 computes from it,
+the flat parameter order and one `save_model` snapshot.  While that file is absent every test here SKIPS and says so -- parity
+stays "unpinned by the reference" (DESIGN.md section 2).  Once it is present the oracle (and the assumed semantics the product
+shares with it) are compared with the reference's own numbers: the only route from parity "partial" to "green".
+
+A fixture is data: inputs and expected outputs.  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+from frcnn_amd import t7
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "golden", "torch7_fixtures.t7")
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fx():
+    if not os.path.exists(PATH):
+        pytest.skip("tests/golden/torch7_fixtures.t7 not present: run tools/make_torch7_fixtures.lua with the reference's Torch7 "
+                    "(parity stays unpinned by the reference until then)")
+    obj = t7.load_obj(PATH)
+    rows = obj["rows"]
+    return rows if isinstance(rows, dict) else {i + 1: r for i, r in enumerate(rows)}
+
+
+@pytest.fixture(scope="module")
+def O():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+def close(a, b, what, tol=TOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.size == 0 or err.max() <= tol, "%s: worst error %.3e" % (what, err.max())
+
+
+def test_row1_spatial_convolution(fx, O):
+    r = fx[1]
+    close(O.conv2d_fwd(r["x"], r["weight"], r["bias"], 1), r["y"], "conv forward")
+    close(O.conv2d_bwd_input(r["gy"], r["weight"], 1, 5, 6), r["gx"], "conv updateGradInput")
+    gw, gb = O.conv2d_bwd_weight(r["x"], r["gy"], 3, 3, 1)
+    close(gw, r["gw"], "conv accGradParameters (weight)"); close(gb, r["gb"], "conv accGradParameters (bias)")
+    close(2 * gw, r["gw_twice"], "accGradParameters accumulates")
+    v = r["valid"]
+    close(O.conv2d_fwd(v["x"], v["weight"], v["bias"], 0), v["y"], "valid 5x5 convolution")
+
+
+def test_row2_prelu(fx):
+    r = fx[2]
+    a = float(np.asarray(r["init"]).ravel()[0])
+    assert np.asarray(r["init"]).size == 1 and a == 0.25, "nn.PReLU(): one shared slope, initial value 0.25"
+    x, gy = r["x"], r["gy"]
+    close(np.where(x > 0, x, a * x), r["y"], "PReLU forward")
+    close(np.where(x > 0, gy, a * gy), r["gx"], "PReLU backward")
+    close(np.sum(np.where(x > 0, 0.0, x * gy)), np.asarray(r["gslope"]).ravel()[0], "PReLU slope gradient", 1e-4)
+
+
+def test_row3_spatial_dropout_2015(fx):
+    r = fx[3]
+    y, ye = r["y_train"], r["y_eval"]
+    per_channel = y.reshape(y.shape[0], -1)
+    assert np.all(per_channel == per_channel[:, :1]), "one Bernoulli draw per channel"
+    assert set(np.unique(y).tolist()) <= {0.0, 1.0}, "training: NO rescale of the kept channels (ASSUMPTIONS row 3)"
+    close(ye, (1.0 - r["p"]) * r["x"], "evaluate: x * (1 - p)")
+    close(r["gx_train"], y, "backward = mask (on an all-ones gradient)")
+
+
+def test_row4_dropout_v2(fx):
+    r = fx[4]
+    assert set(np.unique(r["y_train"]).tolist()) <= {0.0, 1.0 / (1.0 - r["p"])}, "training: mask / (1 - p)"
+    close(r["y_eval"], r["x"], "evaluate: identity")
+
+
+def test_row5_max_pooling_ceil(fx, O):
+    r = fx[5]
+    y, idx = O.maxpool_fwd(r["x"])
+    close(y, r["y"], "SpatialMaxPooling(2,2,2,2):ceil() forward")
+    close(O.maxpool_bwd(r["gy"], idx, r["x"].shape[1], r["x"].shape[2]), r["gx"], "max pooling backward (tie: first maximum wins)")
+
+
+def test_row6_adaptive_max_pooling(fx, O):
+    r = fx[6]
+    full = r["full"]
+    # 0-based window [y0, x0, y1, x1) of the narrowed view
+    win = np.array([r["row0"] - 1, r["col0"] - 1, r["row0"] - 1 + r["rows"], r["col0"] - 1 + r["cols"]], np.int32)
+    try:
+        y, idx = O.adaptive_max_pool_fwd(full, win, r["kh"], r["kw"])
+    except Exception as e:   # (the wrapper's window convention is the oracle's own: orc_extract_roi_window output)
+        pytest.skip("adaptive pooling wrapper takes another window convention: %s" % e)
+    close(y, r["y"], "SpatialAdaptiveMaxPooling forward on a strided view")
+
+
+def test_row7_linear(fx, O):
+    r = fx[7]
+    close(O.linear_fwd(r["x"], r["weight"], r["bias"]), r["y"], "Linear forward")
+    close(r["gy"] @ r["weight"], r["gx"], "Linear updateGradInput")
+    close(r["gy"].T @ r["x"], r["gw"], "Linear accGradParameters")
+
+
+def test_row8_batch_normalization(fx):
+    r = fx[8]
+    x = r["x"].astype(np.float64)
+    assert abs(r["eps"] - 1e-5) < 1e-12 and abs(r["momentum"] - 0.1) < 1e-12
+    mean = x.mean(0); var_b = x.var(0); var_u = x.var(0, ddof=1)
+    close((x - mean) / np.sqrt(var_b + r["eps"]) * r["weight"] + r["bias"], r["y_train"], "training output uses the biased batch variance", 1e-4)
+    close(0.1 * mean, r["running_mean"], "running mean after one update", 1e-5)
+    assert r["has_running_var"], "this Torch7 keeps running_std, not running_var: ASSUMPTIONS row 8 needs the other convention"
+    close(0.9 * 1.0 + 0.1 * var_u, r["running_var_or_std"], "running variance updated with the UNBIASED variance", 1e-5)
+
+
+def test_rows9_to_12_logsoftmax_and_criteria(fx):
+    r = fx[9]
+    x = r["x"].astype(np.float64)
+    lsm = x - x.max(1, keepdims=True); lsm = lsm - np.log(np.exp(lsm).sum(1, keepdims=True))
+    close(lsm, r["y"], "LogSoftMax")
+    n = fx[10]
+    t = np.asarray(n["target"]).astype(int) - 1
+    assert n["sizeAverage"] is True
+    close(-np.mean(n["x"][np.arange(len(t)), t]), n["loss"], "ClassNLLCriterion averages over the batch")
+    s = fx[11]
+    z = (s["x"] - s["target"]).astype(np.float64)
+    close(np.sum(np.where(np.abs(z) < 1, 0.5 * z * z, np.abs(z) - 0.5)), s["loss"], "SmoothL1Criterion, sizeAverage = false", 1e-5)
+    close(np.clip(z, -1, 1), s["gx"], "SmoothL1 gradient")
+    c = fx[12]
+    v = c["x"].astype(np.float64); lv = v - v.max(); lv = lv - np.log(np.exp(lv).sum())
+    close(-lv[int(c["target"]) - 1], c["loss"], "CrossEntropyCriterion on a 1-D input")
+
+
+def test_row13_rmsprop(fx, O):
+    r = fx[13]
+    x = r["x0"].copy(); m = np.zeros_like(x)
+    O.rmsprop(x, r["g1"].copy(), m, 1e-3, 0.9, 1e-8); close(x, r["x1"], "optim.rmsprop step 1", 1e-6)
+    O.rmsprop(x, r["g2"].copy(), m, 1e-3, 0.9, 1e-8); close(x, r["x2"], "optim.rmsprop step 2", 1e-6)
+
+
+def test_row14_sort_tie_order(fx):
+    """ASSUMPTIONS row 14 documents a rule (ascending key, ties by ascending row id); TH's quicksort is unstable, so this is
+    the one place where the reference itself may disagree -- reported, not hidden."""
+    r = fx[14]
+    for name, part in (("12 values", r), ("300 values", r["big"])):
+        v = np.asarray(part["v"]); got = np.asarray(part["index"]).astype(int) - 1
+        want = np.lexsort((np.arange(len(v)), v))
+        assert np.array_equal(v[got], np.sort(v)), "not a sort"
+        assert np.array_equal(got, want), "TH sort breaks ties differently from the documented rule (%s): nms() picks may differ on tied keys" % name
+
+
+def test_row15_mt19937(fx, O):
+    r = fx[15]
+    g = O.MT(int(r["seed"]))
+    assert [g.random() for _ in range(8)] == [int(v) for v in np.asarray(r["draws"]).tolist()], "torch.random() = raw MT19937 draws"
+
+
+def test_rows16_17_mask_indexing_and_nms(fx, O):
+    r = fx[16]
+    assert np.asarray(r["picked"]).tolist() == [v for v, m in zip(np.asarray(r["I"]).tolist(), np.asarray(r["mask"]).tolist()) if m]
+    if 17 not in fx or not fx[17]:
+        pytest.skip("the fixture was made without the reference's nms.lua on the path")
+    n = fx[17]
+    want = (np.asarray(n["pick_default"]).astype(int) - 1).tolist()
+    assert O.nms(n["boxes"], float(n["overlap"])).tolist() == want, "nms(boxes, overlap) ids"
+    # a tensor of scores falls through to the y2 key (ASSUMPTIONS row 17: Lua's == between a tensor and a string is false)
+    assert (np.asarray(n["pick_scores_tensor"]).astype(int) - 1).tolist() == want
+
+
+def test_row18_flat_parameter_order_and_snapshot(fx):
+    r = fx[18]
+    if "error" in r:
+        pytest.skip("the fixture script could not build the reference model: %s" % r["error"])
+    from util import VGG_SMALL_LAYERS
+    sizes = [tuple(int(v) for v in np.asarray(s).tolist()) for s in list(r["pnet_sizes"]) + list(r["cnet_sizes"])]
+    counts = [int(np.prod(s)) for s in sizes]
+    # the order documented in ASSUMPTIONS row 18, from the layer tables alone (no device needed)
+    want = []
+    cin = 3
+    for l in VGG_SMALL_LAYERS:
+        for _ in range(l["conv_steps"]):
+            want += [l["filters"] * cin * 9, l["filters"], 1]; cin = l["filters"]
+    assert counts[:len(want)] == want, "backbone parameter order differs from ASSUMPTIONS row 18"
+    assert sum(counts) == int(r["total"]) == 26784106
+    snap = r.get("snapshot_file")
+    if snap and os.path.exists(os.path.join(HERE, "golden", os.path.basename(snap))):
+        st = t7.load_obj(os.path.join(HERE, "golden", os.path.basename(snap)))
+        assert st["version"] == 0 and np.asarray(st["weights"]).size == 4096 and st["options"]["name"] == "fixture"
