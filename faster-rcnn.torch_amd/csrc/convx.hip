@@ -228,7 +228,6 @@ struct CxArgs {
 #ifdef CX_TRACE
   unsigned long long* trace;   // [block][64] timestamps (s_memrealtime, 100 MHz) -- tools/x3_trace.py
 #endif
-  int prio;               // 1: static wave priority by dispatch round (blockIdx / 256): gang scheduling of the CU's co-resident blocks
   int wide;               // 1: the epilogue goes through LDS and stores 16 bytes per lane (Wo % 4 == 0, TW % 4 == 0, aligned tensors)
   X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
@@ -264,11 +263,6 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 #endif
   const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
   const int h = lane >> 5, li = lane & 31;
-  if (p.prio) {
-    const int round = blockIdx.x >> 8;
-    if (p.prio == 1) { if (round == 0) __builtin_amdgcn_s_setprio(2); else if (round == 1) __builtin_amdgcn_s_setprio(1); }
-    else { if (round == 0) __builtin_amdgcn_s_setprio(0); else if (round == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
-  }
 
   // XCD-aware order (see conv.hip): consecutive virtual indices of one XCD are the M tiles of one pixel tile
   const int nT = p.tilesX * p.tilesY;
@@ -330,39 +324,47 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 
   const int cbeg = split * p.chunksPerSplit;
   const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
-  const int nStages = (cend - cbeg) * KK;
 
   char* const As = smem;
   char* const Bs = smem + CX_NA * AST;
 
-  // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves
-  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * AST + lane * 16;
+  // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves.  Buffer
+  // form: one descriptor over this (m tile, K split)'s stages in SGPRs, the lane's 16 bytes as the 32-bit vector offset, the
+  // stage as the scalar offset -- no 64-bit lane addresses to compute or keep (the packed image of a launch is < 4 GB).
+  const size_t wbase = ((size_t)mt_id * p.nChunks + cbeg) * KK * AST;
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.wp) + wbase), 0, (int)((size_t)(cend - cbeg) * KK * AST), 0x00020000);
+  const unsigned wlane = (unsigned)lane * 16u;
   auto dma_stage = [&](int stage, int buf) {
-    const char* src = wsrc + (size_t)stage * AST;
+    const unsigned so = (unsigned)stage * (unsigned)AST;
     char* dst = As + buf * AST;
     if (NDMA % 4 == 0) {   // a wave's instructions cover consecutive kilobytes
 #pragma unroll
       for (int i = 0; i < NDMA / 4; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave * (NDMA / 4) + i) * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + (wave * (NDMA / 4) + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + (wave * (NDMA / 4) + i) * 1024), 16, wlane,
+                                                 so + (unsigned)(wave * (NDMA / 4) + i) * 1024u, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < (NDMA + 3) / 4; ++i)
         if (wave + 4 * i < NDMA)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * i) * 1024),
-                                           (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, wlane,
+                                                   so + (unsigned)(wave + 4 * i) * 1024u, 0, 0);
     }
   };
 
   float vb[2][8];
   int patch_chunk = 0;
+  // patch loads: buffer form too (the channel plane is the scalar offset, the lane's position a 32-bit offset)
+  const __amdgpu_buffer_rsrc_t in_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((size_t)p.Cin * hw_bytes), 0x00020000);
   auto load_patch = [&](int chunk) {
-    const char* srcB = reinterpret_cast<const char*>(p.in) + (size_t)chunk * CX_CH * hw_bytes;
+    const unsigned so = (unsigned)chunk * CX_CH * (unsigned)hw_bytes;
     patch_chunk = chunk;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vb[it][j] = *reinterpret_cast<const float*>(srcB + j * hw_bytes + gofs[it]);
+      for (int j = 0; j < 8; ++j)
+        vb[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, gofs[it], so + (unsigned)j * (unsigned)hw_bytes, 0));
   };
   auto store_patch = [&](char* Bb) {
 #pragma unroll
@@ -392,39 +394,52 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     }
   };
 
-  // one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + 2 B)), 24 MFMAs
-  auto compute = [&](const char* Ab, const char* Bb, int tapoff) {
-    bf16x8 a[2][3], b[NTW][3];
+  // ---- one stage = one tap of one chunk: 12 fragment reads (3 planes x (2 A + NTW B)) and 6 partial products of 2 x NTW
+  // MFMAs each: (l,h) (h,l) (m,h) (m,m) (h,m) (h,h) -- the small ones first; plane index 0 = h, 1 = m, 2 = l.
+  // Left to the compiler a stage reads 6 + 3 + 3 fragments with a full LDS round trip exposed in front of each group
+  // (tools/x3_trace.sh: a block alone on its CU needs 1 690 cycles per stage for 768 cycles of MFMAs, and three resident
+  // blocks only fill 71 % of the pipe).  So the order is fixed by hand (sched_barrier fences), software-pipelined inside the
+  // wave: every group of reads is issued one or two products before its first use, the (h,h) product of a stage is carried
+  // over the barrier into the next stage -- it needs registers only -- where it covers the first reads of the new stage and the
+  // issue of the A-ring DMA.  Ten fragments are live at most (as in the compiler's own schedule).
+  auto readA = [&](const char* Ab, int pl, bf16x8 (&f)[2]) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        a[mt][pl] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * BMK + mt * 32) * 16);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-        b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
-    }
-    // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[t]], b[nt][PB[t]], acc[mt][nt], 0, 0, 0);
+    for (int mt = 0; mt < 2; ++mt) f[mt] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * BMK + mt * 32) * 16);
   };
+  auto readB = [&](const char* Bb, int tapoff, int pl, bf16x8 (&f)[NTW]) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) f[nt] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
+  };
+  auto mm = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NTW]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  };
+#define CX_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-  // Three blocks per CU (44 KB of LDS, <= 168 registers): A ring of two stages -- stage s+1 is requested right after the
-  // barrier of stage s, into the slot stage s-1 was read from -- and ONE patch buffer: at a chunk boundary every wave
-  // has passed the barrier of the new chunk's first stage before the new patch (in registers since the old chunk's first
-  // tap) is split and written, and a second barrier publishes it.
+  const int nC = cend - cbeg;
+  bf16x8 pAH[2], pBH[NTW];   // the (h,h) operands of the previous stage (zeros before the first: the product adds nothing)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pAH[i][j] = (__bf16)0.f;
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pBH[i][j] = (__bf16)0.f;
+
+  // Three blocks per CU (44 KB of LDS, <= 168 registers): A ring of two stages -- stage s+1 is requested behind the barrier
+  // of stage s, into the slot stage s-1 was read from -- and ONE patch buffer: at a chunk boundary every wave has passed
+  // the barrier of the new chunk's first stage before the new patch (in registers since the old chunk's first tap) is split
+  // and written, and a second barrier publishes it.
   load_patch(cbeg);
   dma_stage(0, 0);
   store_patch(Bs);
   stamp(1);
   bool more = false;
   int stage = 0;
+  const int nStages = nC * KK;
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int par = KK % 2 == 0 ? 0 : (chunk - cbeg) & 1;   // A ring slot of the chunk's first tap
 #ifdef CX_TRACE
@@ -432,24 +447,59 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 #endif
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap, ++stage) {
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const char* const Ab = As + ((tap + par) & 1) * AST;
+      const int tapoff = (ky * PW + kx) * 16;
+      bf16x8 aL[2], aM[2], aH[2], bL[NTW], bM[NTW], bH[NTW];
       // stage's A image (requested one stage ago) has landed in every wave's part; right after a chunk's first tap the
       // patch loads issued behind it may still be in flight
       if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (stage + 1 < nStages) dma_stage(stage + 1, (tap + 1 + par) & 1);
+      // (no accumulator is touched inside a conditional: a branch around MFMAs makes the register allocator keep two copies
+      // of the 64 accumulator registers.  The ring DMA is unconditional -- behind the last stage it re-requests that stage
+      // into the idle slot -- so that a stage is one basic block and the LDS waits are counted ones.)
+      const int nxt = stage + 1 < nStages ? stage + 1 : stage;
       if (tap == 0) {
-        if (chunk > cbeg) {   // the patch of this chunk: every wave is done with the previous one
-          store_patch(Bs);
-          __syncthreads();
-        }
+        // a chunk's first tap: the carried product covers the split of the new patch, a second barrier publishes it
+        mm(pAH, pBH);
+        CX_FENCE();
+        if (chunk > cbeg) store_patch(Bs);   // (the first chunk's patch was written before the loop)
+        dma_stage(nxt, (tap + 1 + par) & 1);
+        __syncthreads();
         more = chunk + 1 < cend;
         if (more) load_patch(chunk + 1);
+        readA(Ab, 2, aL); readB(Bs, tapoff, 0, bH);
+        readA(Ab, 0, aH); readB(Bs, tapoff, 2, bL);
+      } else {
+        readA(Ab, 2, aL); readB(Bs, tapoff, 0, bH);
+        CX_FENCE();
+        mm(pAH, pBH);
+        CX_FENCE();
+        readA(Ab, 0, aH); readB(Bs, tapoff, 2, bL);
+        dma_stage(nxt, (tap + 1 + par) & 1);
       }
-      const int ky = tap / KS, kx = tap - ky * KS;
-      compute(As + ((tap + par) & 1) * AST, Bs, (ky * PW + kx) * 16);
+      CX_FENCE();
+      mm(aL, bH);
+      CX_FENCE();
+      readA(Ab, 1, aM);
+      CX_FENCE();
+      mm(aH, bL);
+      CX_FENCE();
+      readB(Bs, tapoff, 1, bM);
+      CX_FENCE();
+      mm(aM, bH);
+      mm(aM, bM);
+      mm(aH, bM);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pAH[i] = aH[i];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) pBH[i] = bH[i];
     }
   }
+  mm(pAH, pBH);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the idle slot's last request)
+#undef CX_FENCE
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter).  Every filter row of the
   // block exists (M is a multiple of the block's filter count), so only the pixel is predicated.  The 32 bias values of the
@@ -781,8 +831,6 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);
   a.out_mode = out_mode;
   a.post = post ? *post : X3PostAct{nullptr, nullptr, nullptr, nullptr};
-  static const int prio_env = getenv("FRCNN_X3_PRIO") ? atoi(getenv("FRCNN_X3_PRIO")) : 0;
-  a.prio = prio_env;
   a.wide = 0;   // decided below, once the destination (tensor or slab) is known
   FR_CHECK(!post || (k == 3 && out_mode == OUT_STORE && !in_slope && !in_scale && !bias && post->x && post->slope),
            "conv_x3: the fused activation backward belongs to a storing 3x3 input-gradient launch");
