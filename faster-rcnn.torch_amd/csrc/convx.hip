@@ -328,27 +328,25 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   char* const As = smem;
   char* const Bs = smem + CX_NA * AST;
 
-  // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves.  Buffer
-  // form: one descriptor over this (m tile, K split)'s stages in SGPRs, the lane's 16 bytes as the 32-bit vector offset, the
-  // stage as the scalar offset -- no 64-bit lane addresses to compute or keep (the packed image of a launch is < 4 GB).
-  const size_t wbase = ((size_t)mt_id * p.nChunks + cbeg) * KK * AST;
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.wp) + wbase), 0, (int)((size_t)(cend - cbeg) * KK * AST), 0x00020000);
-  const unsigned wlane = (unsigned)lane * 16u;
+  // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves.
+  // (global_load_lds, not the buffer form: with BOTH the ring DMA and the patch loads below on buffer resources the
+  // kernels that also fetch a dropout scale computed wrong results at full size -- each form alone is right, cause not
+  // found; tools/x3_check.py is the test that caught it.)
+  const char* const wsrc = reinterpret_cast<const char*>(p.wp) + ((size_t)mt_id * p.nChunks + cbeg) * KK * AST + lane * 16;
   auto dma_stage = [&](int stage, int buf) {
-    const unsigned so = (unsigned)stage * (unsigned)AST;
+    const char* src = wsrc + (size_t)stage * AST;
     char* dst = As + buf * AST;
     if (NDMA % 4 == 0) {   // a wave's instructions cover consecutive kilobytes
 #pragma unroll
       for (int i = 0; i < NDMA / 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + (wave * (NDMA / 4) + i) * 1024), 16, wlane,
-                                                 so + (unsigned)(wave * (NDMA / 4) + i) * 1024u, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave * (NDMA / 4) + i) * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave * (NDMA / 4) + i) * 1024), 16, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < (NDMA + 3) / 4; ++i)
         if (wave + 4 * i < NDMA)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, wlane,
-                                                   so + (unsigned)(wave + 4 * i) * 1024u, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * i) * 1024),
+                                           (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
     }
   };
 
@@ -379,8 +377,17 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = vb[it][j];
-        if (SLOPE) t = t > 0.f ? t : slope * t;
-        if (SCALE) t *= sc[j];
+        // (scalar multiplies, by hand: left alone, LLVM's SLP pass packs the eight of them into v_pk_mul_f32 with op_sel
+        // swizzles, and in the kernels that apply BOTH slope and scale that sequence produced wrong products for a quarter
+        // wave at a time at full size -- timing dependent, never in the small shapes; tools/x3_check.py and
+        // tests/test_gpu_convx.py::test_model_layer_shapes_full_size are the checks that caught it.  Cause not established
+        // (the packed form beside in-flight VMEM returns is the suspect); packed fp32 is no faster beside MFMAs anyway.)
+        if (SLOPE) {
+          float ts;
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ts) : "v"(slope), "v"(t));
+          t = t > 0.f ? t : ts;
+        }
+        if (SCALE) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(sc[j]));
         x[j] = gok[it] ? t : 0.f;
       }
       uint4 H, Mi, L;

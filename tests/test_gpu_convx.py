@@ -251,3 +251,45 @@ def test_anchor_net_kernel_sizes(F, O, both_forms, C_, H, W, O_, k):
         s2, d2 = both_forms(bwd)
         assert not np.array_equal(s2, d2)
         assert_close(s2, gwant, 1e-4, "split-bf16 %dx%d conv dgrad" % (k, k))
+
+
+MODEL_LAYERS = [  # name, Cin, H, W, Cout, pad -- the 3x3 launches of a vgg_small 800x450 step (both block shapes, split-K, valid)
+    ("b2c1", 64, 225, 400, 128, 1), ("b2c2", 128, 225, 400, 128, 1), ("b3c1", 128, 113, 200, 256, 1),
+    ("b3c2", 256, 113, 200, 256, 1), ("b4c1", 256, 57, 100, 384, 1), ("b4c2", 384, 57, 100, 384, 1),
+    ("a1", 256, 57, 100, 256, 0), ("a2", 384, 29, 50, 256, 0),
+]
+
+
+@pytest.mark.parametrize("name,C_,H,W,O_,pad", MODEL_LAYERS)
+def test_model_layer_shapes_full_size(F, name, C_, H, W, O_, pad):
+    """Every 3x3 launch shape of the benchmarked step at FULL size -- forward without and with the fused input activation
+    (PReLU slope + dropout scale: the <SLOPE, SCALE> instantiations), and the input gradient -- against the fp32 matrix-core
+    kernel on the same inputs, three times each.  The small shapes above did not catch a timing-dependent fault of the
+    activation path that only showed with hundreds of blocks in flight (round 5: packed multiplies, convx.hip store_patch);
+    the oracle is too slow for these sizes, the fp32 kernel (itself oracle-checked above and in test_gpu_conv.py) is not."""
+    rng = np.random.RandomState(1)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x, g = _dev(F, rng.randn(C_, H, W).astype(np.float32)), _dev(F, rng.randn(O_, Ho, Wo).astype(np.float32))
+    w, b = _dev(F, (rng.randn(O_, C_, 3, 3) * 0.05).astype(np.float32)), _dev(F, rng.randn(O_).astype(np.float32))
+    slope, scale = _dev(F, [np.float32(0.25)]), _dev(F, (rng.rand(C_) > 0.4).astype(np.float32))
+    s = F.stream_ptr()
+
+    def fwd(act):
+        out = F.DeviceTensor.empty((O_, Ho, Wo))
+        F._lib.call("frcnn_conv2d_forward", F.ptr(x), C_, H, W, F.ptr(slope) if act else None, F.ptr(scale) if act else None,
+                    F.ptr(w), F.ptr(b), O_, 3, pad, F.ptr(out), s)
+        return out.numpy()
+
+    def dgrad():
+        gin = F.DeviceTensor.empty((C_, H, W))
+        F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O_, Ho, Wo, F.ptr(w), C_, 3, pad, F.ptr(gin), 0, s)
+        return gin.numpy()
+    before = _option(F, "split_bf16", 0)
+    try:
+        want = [fwd(0), fwd(1), dgrad()]
+        _option(F, "split_bf16", 1)
+        for _ in range(3):
+            for got, ref, what in zip([fwd(0), fwd(1), dgrad()], want, ("forward", "forward + fused activation", "input gradient")):
+                assert_close(got, ref, 2e-4, "%s %s, split form vs fp32 matrix-core kernel" % (name, what))
+    finally:
+        _option(F, "split_bf16", before)
