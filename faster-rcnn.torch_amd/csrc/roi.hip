@@ -57,6 +57,32 @@ __global__ __launch_bounds__(256) void roi_pool_forward_cells_kernel(const float
   const int xs = (j * w) / kw, xe = ((j + 1) * w + kw - 1) / kw;
   const int HW = H * W;
   const int base = (r0 + ys) * W + c0 + xs, nx = xe - xs, ny = ye - ys;
+  // The kernel is bound by the number of scattered load instructions (every lane another address), not by bytes: a row of
+  // a cell is read in pieces of FOUR consecutive columns (one unaligned 16-byte load; the last piece of a plane is pulled
+  // back so that it ends with the plane, elements outside the cell are masked, and an element seen twice cannot win
+  // twice: the comparison is strict) instead of one dword per column.
+  if (HW >= 4) {
+    for (int c = blockIdx.y * groups + cg; c < C; c += gridDim.y * groups) {
+      const float* ip = fmap + (size_t)c * HW;
+      float best = -3.402823466e+38f;
+      int bi = -1;
+      for (int y = 0, o = base; y < ny; ++y, o += W)
+        for (int x = 0; x < nx; x += 4) {
+          const int q = min(o + x, HW - 4);
+          float v[4];
+          __builtin_memcpy(v, ip + q, 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int at = q + e;
+            if (at >= o && at < o + nx && v[e] > best) { best = v[e]; bi = at; }
+          }
+        }
+      const size_t t = ((size_t)r * C + c) * cells + cell;
+      out[t] = best;
+      if (idx) idx[t] = bi;
+    }
+    return;
+  }
   for (int c = blockIdx.y * groups + cg; c < C; c += gridDim.y * groups) {
     const float* ip = fmap + (size_t)c * HW;
     float best = -3.402823466e+38f;
