@@ -38,13 +38,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CX_BM 128                       // filters per block
 #define CX_CH 16                        // channels per chunk (one MFMA K step per tap)
 #define CX_OCC 3                        // blocks per CU the kernel is laid out for
-#define CX_PP 204                       // patch positions per (plane, half) in LDS (pitch); patch plane <= CX_PP
+#define CX_PP 204                       // patch positions per (plane, half) in LDS (pitch) of the 3x3 kernels; patch plane <= CX_PP
+// the 5x5 / 7x7 instantiations take the patch of an 8 x 16-pixel tile: 12 x 20 / 14 x 22 positions (two blocks per CU)
+constexpr int cx_pp(int k) { return k == 3 ? CX_PP : k == 5 ? 240 : 308; }
 #define CX_NA 2                         // A ring slots
 #define CX_NB 1                         // patch buffers
 #define CX_NTMAX 128                    // pixels per block
 #define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage of a 128-filter block: [plane 3][half 2][128 filters][8 bf16]
-#define CX_BBUF (6 * CX_PP * 16)        // bytes of one B buffer: [plane 3][half 2][CX_PP positions][8 bf16]
-#define CX_LDS (CX_NA * CX_ASTAGE + CX_NB * CX_BBUF)
 
 static int g_splitbf16 = -1;   // -1: not decided yet (environment FRCNN_SPLIT_BF16, default on)
 void set_split_bf16(int on) { g_splitbf16 = on ? 1 : 0; }
@@ -238,8 +238,8 @@ struct CxArgs {
 // EPI = 1 (input-gradient launches that store, out_mode 0): the stored tile goes through the backward of the activation
 // that follows in the chain (X3PostAct) -- one read of x per element instead of act_backward's read + read + write pass.
 template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0>
-__global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
-  constexpr int KK = KS * KS;
+__global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxArgs p) {
+  constexpr int KK = KS * KS, PP = cx_pp(KS), NIT = (2 * PP + 255) / 256;   // staging items per thread
   constexpr int BMK = 64 * WM, NTW = WM, AST = 6 * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -284,12 +284,12 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   const size_t hw_bytes = (size_t)HW * 4;
 
   // ---- this thread's two staging items: (half g, patch position): 8 channels each
-  unsigned gofs[2];      // byte offset inside the chunk's first channel plane (includes the 8 g channels)
-  bool gok[2];
-  unsigned sdst[2];      // LDS byte offset of the item's 16-byte entry inside plane 0 of a B buffer
-  int gsel[2];
+  unsigned gofs[NIT];    // byte offset inside the chunk's first channel plane (includes the 8 g channels)
+  bool gok[NIT];
+  unsigned sdst[NIT];    // LDS byte offset of the item's 16-byte entry inside plane 0 of a B buffer
+  int gsel[NIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int e = tid + 256 * it;
     const int g = e >= plane ? 1 : 0;
     const int pos = e - g * plane;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     const bool valid = e < 2 * plane;
     gok[it] = valid && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     gofs[it] = (gok[it] ? (unsigned)(gy * p.W + gx) * 4u : 0u) + (unsigned)g * 8u * (unsigned)hw_bytes;
-    sdst[it] = valid ? (unsigned)((g * CX_PP + pos) * 16) : 0xFFFFFFFFu;
+    sdst[it] = valid ? (unsigned)((g * PP + pos) * 16) : 0xFFFFFFFFu;
     gsel[it] = g;
   }
   const float slope = SLOPE ? *p.in_slope : 1.f;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     int q = wn * (32 * NTW) + nt * 32 + li;
     q = q < NT ? q : NT - 1;
     const int ty = q / p.TW, tx = q - ty * p.TW;
-    boff[nt] = (unsigned)((h * CX_PP + ty * PW + tx) * 16);
+    boff[nt] = (unsigned)((h * PP + ty * PW + tx) * 16);
   }
 
   f32x16 acc[2][NTW];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     }
   };
 
-  float vb[2][8];
+  float vb[NIT][8];
   int patch_chunk = 0;
   // patch loads: buffer form too (the channel plane is the scalar offset, the lane's position a 32-bit offset)
   const __amdgpu_buffer_rsrc_t in_rsrc =
@@ -359,14 +359,14 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
     const unsigned so = (unsigned)chunk * CX_CH * (unsigned)hw_bytes;
     patch_chunk = chunk;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         vb[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, gofs[it], so + (unsigned)j * (unsigned)hw_bytes, 0));
   };
   auto store_patch = [&](char* Bb) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       float sc[8];
       if (SCALE) {   // (L1 / L2 hits; fetched here rather than held in registers since the patch was requested)
         const float4* sp = reinterpret_cast<const float4*>(p.in_scale + patch_chunk * CX_CH + 8 * gsel[it]);
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
       if (sdst[it] != 0xFFFFFFFFu) {
         char* d = Bb + sdst[it];
         *reinterpret_cast<uint4*>(d) = H;
-        *reinterpret_cast<uint4*>(d + 2 * CX_PP * 16) = Mi;
-        *reinterpret_cast<uint4*>(d + 4 * CX_PP * 16) = L;
+        *reinterpret_cast<uint4*>(d + 2 * PP * 16) = Mi;
+        *reinterpret_cast<uint4*>(d + 4 * PP * 16) = L;
       }
     }
   };
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
   };
   auto readB = [&](const char* Bb, int tapoff, int pl, bf16x8 (&f)[NTW]) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) f[nt] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * CX_PP * 16);
+    for (int nt = 0; nt < NTW; ++nt) f[nt] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * PP * 16);
   };
   auto mm = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NTW]) {
 #pragma unroll
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, CX_OCC) void conv_x3_kernel(CxArgs p) {
       bf16x8 aL[2], aM[2], aH[2], bL[NTW], bM[NTW], bH[NTW];
       // stage's A image (requested one stage ago) has landed in every wave's part; right after a chunk's first tap the
       // patch loads issued behind it may still be in flight
-      if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NIT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       // (no accumulator is touched inside a conditional: a branch around MFMAs makes the register allocator keep two copies
@@ -752,7 +752,7 @@ static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
     parsed = true;
     if (const char* e = getenv("FRCNN_X3_TILE")) sscanf(e, "%dx%d", &fth, &ftw);
   }
-  if (fth > 0 && ftw > 0 && k == 3 && fth * ftw <= CX_NTMAX && (fth + k - 1) * (ftw + k - 1) <= CX_PP) {
+  if (fth > 0 && ftw > 0 && k == 3 && fth * ftw <= CX_NTMAX && (fth + k - 1) * (ftw + k - 1) <= cx_pp(k)) {
     *TH = std::min(fth, Ho); *TW = std::min(ftw, Wo);
     return;
   }
@@ -764,8 +764,8 @@ static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
     if (tw < 8 && Wo >= 8) continue;
     if (tw % mult != 0) continue;
     int th = std::min(CX_NTMAX / tw, Ho);
-    while (th > 1 && (th + k - 1) * (tw + k - 1) > CX_PP) --th;
-    if (th < 1 || (th + k - 1) * (tw + k - 1) > CX_PP) continue;
+    while (th > 1 && (th + k - 1) * (tw + k - 1) > cx_pp(k)) --th;
+    if (th < 1 || (th + k - 1) * (tw + k - 1) > cx_pp(k)) continue;
     long tiles = (long)cdiv(Ho, th) * cdiv(Wo, tw);
     long cost = tiles * CX_NTMAX * 64 + tiles * (th + k - 1) * (tw + k - 1);  // MFMA slots + halo traffic
     if (best < 0 || cost < best || (cost == best && tw > btw)) { best = cost; bth = th; btw = tw; }
@@ -792,7 +792,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   // (the wide epilogue turns four 64 x 32 fp32 tiles over in LDS: 32 KB)
   static const size_t lds_min = getenv("FRCNN_X3_LDS_MIN") ? (size_t)atol(getenv("FRCNN_X3_LDS_MIN")) : 0;   // (experiments: fewer blocks per CU)
-  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * CX_BBUF, a.wide ? 4 * 64 * 32 * 4 : 0));
+  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * (6 * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
   FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
 #ifdef CX_TRACE
@@ -832,7 +832,9 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   const long blocks = (long)a.tilesX * a.tilesY * a.mTiles;
   // split K until one round of blocks fills the CX_OCC x 256 resident slots, keeping >= 36 stages (4 chunks of a 3x3) per split
   const int min_chunks = cdiv(36, k * k);
-  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, (256 * CX_OCC) / blocks), 16), std::max(1, a.nChunks / min_chunks));
+  // (the 5x5 / 7x7 kernels hold two blocks per CU and have 25 / 49 stages per chunk: up to 24 splits of one chunk each)
+  const long slots = 256 * (k == 3 ? CX_OCC : 2);
+  int splitK = (int)std::min<long>(std::min<long>(std::max<long>(1, slots / blocks), k == 3 ? 16 : 24), std::max(1, a.nChunks / min_chunks));
   if (const char* e = getenv("FRCNN_X3_SPLITK")) splitK = std::max(1, std::min(a.nChunks, atoi(e)));
   a.chunksPerSplit = cdiv(a.nChunks, splitK);
   a.splitK = cdiv(a.nChunks, a.chunksPerSplit);

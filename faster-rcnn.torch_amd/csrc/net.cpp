@@ -231,12 +231,13 @@ static int ensure_conv(Conv& c, int H, int W, bool need_dgrad) {
     FR_TRY(c.wd.ensure(conv_pack_floats(c.Cout, c.Cin, c.k) * 4));
     FR_HIP(hipMemset(c.wd.p, 0, c.wd.bytes));
   }
-  // 3x3 launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time
-  // (the 5x5 / 7x7 anchor nets keep the fp32 kernel.  Round 2: on their 25x46 / 23x44 maps the split form's 8x10-pixel tiles fill
-  // 63 % of an MFMA tile and its 7.2 M weights have to be split every step -- 3.59 ms/step with them against 3.38.  Round 3,
-  // with a 240 / 308-position patch buffer so that they get 8x16-pixel tiles, and up to 24 K splits: 18 tiles x 12..24 splits
-  // of 49-tap stages on two blocks per CU -- 3.14 ms/step against 3.11)
-  c.x_f = c.k == 3 && conv_x3_eligible(c.Cin, c.Cout, c.k);
+  // Launches whose shape fits take the split-bf16 operand form (convx.hip): fp32 results at 6/16 of the matrix-pipe time.  The 3x3
+  // layers since round 2; the 5x5 / 7x7 anchor nets since round 5: rounds 2 and 3 had measured them slower in that form (8x10-pixel
+  // tiles under the 204-position patch limit; then 8x16 tiles but a stage loop that needed three resident blocks to hide its LDS
+  // round trips: 3.14 against 3.11 ms/step).  With the stage pipelined inside the wave (convx.hip) two blocks per CU suffice: the 7x7
+  // net 118.8 -> 63.8 us alone, the 5x5 net 67.4 -> 56.8, the step 2.918 -> 2.834 ms.  FRCNN_X3_ANCHOR_K=3 restores the fp32 kernels.
+  static const int x3_anchor_k = getenv("FRCNN_X3_ANCHOR_K") ? atoi(getenv("FRCNN_X3_ANCHOR_K")) : 7;
+  c.x_f = (c.k == 3 || (c.block < 0 && c.k <= x3_anchor_k)) && conv_x3_eligible(c.Cin, c.Cout, c.k);
   c.x_d = c.block >= 0 && need_dgrad && conv_x3_eligible(c.Cout, c.Cin, c.k);
   if (c.x_f) FR_TRY(c.wx.ensure(conv_x3_pack_bytes(c.Cin, c.Cout, c.k)));
   if (c.x_d) FR_TRY(c.wxd.ensure(conv_x3_pack_bytes(c.Cout, c.Cin, c.k)));
