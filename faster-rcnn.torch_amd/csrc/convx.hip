@@ -228,9 +228,6 @@ struct CxArgs {
 #ifdef CX_TRACE
   unsigned long long* trace;   // [block][64] timestamps (s_memrealtime, 100 MHz) -- tools/x3_trace.py
 #endif
-  // split-K launches that fold their slabs themselves (the block that completes a tile's last slab sums them): ticket per
-  // output tile (zero between launches), the final destination, its bias, store / add
-  int* fold_tickets; float* fold_out; const float* fold_bias; int fold_add;
   int wide;               // 1: the epilogue goes through LDS and stores 16 bytes per lane (Wo % 4 == 0, TW % 4 == 0, aligned tensors)
   X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
@@ -529,113 +526,6 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   // instruction writes eight filter rows of 128 bytes: 16 dwordx4 stores per lane instead of 64 dword stores, and x / the
   // old values of the accumulate mode are read the same way.  Needs Wo % 4 == 0 and TW % 4 == 0 (a group of four pixels then
   // never straddles a tile row or the map's edge and is 16-byte aligned); the launcher sets `wide` when that holds.
-  // ---- split-K with the fold inside the launch.  Every block writes its partial tile to its slab WRITE-THROUGH (16-byte sc1
-  // stores: no release fence, MI355X_MICROARCH.md "publish-large"), drains its stores, and takes a ticket of the output tile
-  // (one agent-scope atomic by one lane).  The block that draws the last ticket -- every slab of the tile is in memory by then --
-  // does one agent-scope acquire (this CU's L1 never saw these lines, the acquire makes that a guarantee) and sums the slabs in
-  // split order, bias first: the same additions in the same order as x3_splitk_reduce_kernel, so the result is the same bits.
-  // It applies X3PostAct, stores or adds into the destination, and puts the ticket back to zero for the next launch.  Blocks
-  // of a launch drain one after the other (tools/x3_trace.sh), so the folding block works while the CU's other blocks multiply;
-  // the separate fold launch on the dependent chain is gone.
-  if (p.wide && p.fold_tickets) {
-    __syncthreads();
-    float* const T = reinterpret_cast<float*>(smem) + wave * (64 * 32);
-    int* const flag = reinterpret_cast<int*>(smem + 4 * 64 * 32 * 4);   // (dynamic LDS: a static __shared__ would shift the base)
-    const int rr = lane >> 3, pg = lane & 7;
-    const size_t slab_elems = (size_t)p.M * HoWo;
-    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)split * slab_elems, 0, (int)(slab_elems * 4), 0x00020000);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    size_t rowo_nt[NTW];
-    bool ok_nt[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + li] = acc[mt][nt][r];
-      const int q = wn * (32 * NTW) + nt * 32 + 4 * pg;
-      const int ty = q / p.TW, tx = q - ty * p.TW;
-      const int oy = ty0 + ty, ox = tx0 + tx;
-      ok_nt[nt] = q < NT && oy < p.Ho && ox < p.Wo;
-      rowo_nt[nt] = (size_t)(m0 + wm * 64 + rr) * HoWo + (ok_nt[nt] ? (size_t)oy * p.Wo + ox : (size_t)0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(T + (i * 8 + rr) * 32 + 4 * pg);
-        if (ok_nt[nt]) {
-          u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(u, s_rsrc, (unsigned)((rowo_nt[nt] + (size_t)i * 8 * HoWo) * 4), 0, 16);   // aux 16 = sc1
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
-    __syncthreads();
-    if (tid == 0) {
-      int* const t = p.fold_tickets + (mt_id + p.mTiles * nt_id);
-      const int old = __hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == p.splitK - 1;
-      if (last) {
-        __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    const float pa = p.post.x ? *p.post.slope : 0.f;
-    float sa = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      if (!ok_nt[nt]) continue;
-#pragma unroll
-      for (int ib = 0; ib < 8; ib += 4) {
-        float4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float b = p.fold_bias ? p.fold_bias[m0 + wm * 64 + (ib + i) * 8 + rr] : 0.f;
-          v[i] = make_float4(b, b, b, b);
-        }
-        for (int s0 = 0; s0 < p.splitK; s0 += 2) {   // two slabs x four rows in flight
-          float4 x[2][4];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              x[j][i] = s0 + j < p.splitK ? *reinterpret_cast<const float4*>(p.out + (size_t)(s0 + j) * slab_elems + rowo_nt[nt] + (size_t)(ib + i) * 8 * HoWo)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (s0 + j < p.splitK) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) { v[i].x += x[j][i].x; v[i].y += x[j][i].y; v[i].z += x[j][i].z; v[i].w += x[j][i].w; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int f = m0 + wm * 64 + (ib + i) * 8 + rr;
-          const size_t off = rowo_nt[nt] + (size_t)(ib + i) * 8 * HoWo;
-          float4 w = v[i];
-          if (p.post.x) {
-            const float4 xv = *reinterpret_cast<const float4*>(p.post.x + off);
-            const float sc = p.post.scale ? p.post.scale[f] : 1.f;
-            float g;
-            g = w.x * sc; if (xv.x > 0.f) w.x = g; else { sa += xv.x * g; w.x = pa * g; }
-            g = w.y * sc; if (xv.y > 0.f) w.y = g; else { sa += xv.y * g; w.y = pa * g; }
-            g = w.z * sc; if (xv.z > 0.f) w.z = g; else { sa += xv.z * g; w.z = pa * g; }
-            g = w.w * sc; if (xv.w > 0.f) w.w = g; else { sa += xv.w * g; w.w = pa * g; }
-          }
-          float4* const dst = reinterpret_cast<float4*>(p.fold_out + off);
-          if (p.fold_add) { const float4 o = *dst; w.x += o.x; w.y += o.y; w.z += o.z; w.w += o.w; }
-          *dst = w;
-        }
-      }
-    }
-    if (p.post.x) {
-#pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) sa += __shfl_xor(sa, o2);
-      if (lane == 0 && p.post.gslope) unsafeAtomicAdd(p.post.gslope, sa);
-    }
-    return;
-  }
   if (p.wide) {
     __syncthreads();   // every wave is done with the last stage's fragments
     float* const T = reinterpret_cast<float*>(smem) + wave * (64 * 32);
@@ -838,20 +728,14 @@ __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __re
 
 static void* g_x3_ws[8] = {};
 static size_t g_x3_ws_bytes[8] = {};
-// slab workspace of a stream slot; behind it X3_TICKETS ints, zero whenever no launch is in flight (the in-launch fold's tickets)
-#define X3_TICKETS 4096
-static int x3_workspace(size_t need, float** out, int slot, int** tickets = nullptr) {
-  need = (need + 255) / 256 * 256;
-  const size_t total = need + X3_TICKETS * sizeof(int);
-  if (total > g_x3_ws_bytes[slot]) {
+static int x3_workspace(size_t need, float** out, int slot) {
+  if (need > g_x3_ws_bytes[slot]) {
     if (g_x3_ws[slot]) FR_HIP(hipFree(g_x3_ws[slot]));
     g_x3_ws[slot] = nullptr; g_x3_ws_bytes[slot] = 0;
-    FR_HIP(hipMalloc(&g_x3_ws[slot], total));
-    g_x3_ws_bytes[slot] = total;
-    FR_HIP(hipMemset((char*)g_x3_ws[slot] + total - X3_TICKETS * sizeof(int), 0, X3_TICKETS * sizeof(int)));
+    FR_HIP(hipMalloc(&g_x3_ws[slot], need));
+    g_x3_ws_bytes[slot] = need;
   }
   *out = (float*)g_x3_ws[slot];
-  if (tickets) *tickets = (int*)((char*)g_x3_ws[slot] + g_x3_ws_bytes[slot] - X3_TICKETS * sizeof(int));
   return FRCNN_OK;
 }
 
@@ -908,7 +792,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   // (the wide epilogue turns four 64 x 32 fp32 tiles over in LDS: 32 KB)
   static const size_t lds_min = getenv("FRCNN_X3_LDS_MIN") ? (size_t)atol(getenv("FRCNN_X3_LDS_MIN")) : 0;   // (experiments: fewer blocks per CU)
-  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * (6 * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 + 64 : 0));
+  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * (6 * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
   FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
 #ifdef CX_TRACE
@@ -960,23 +844,16 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   FR_CHECK(!post || (k == 3 && out_mode == OUT_STORE && !in_slope && !in_scale && !bias && post->x && post->slope),
            "conv_x3: the fused activation backward belongs to a storing 3x3 input-gradient launch");
   bool slab = false;
-  a.fold_tickets = nullptr; a.fold_out = nullptr; a.fold_bias = nullptr; a.fold_add = 0;
-  int* tickets = nullptr;
   if (a.splitK > 1) {
+    // (the fold stays a launch of its own: folding inside the launch -- write-through slabs, a ticket per output tile, the last
+    // arriver sums -- was built in round 5, bit-identical, and measured slower: b4c1 91 -> 112 us, the step 2.85 -> 2.985 ms;
+    // EXPERIMENTS.md, commit 3b8a58d)
     float* ws = nullptr;
-    FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7, &tickets));
+    FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
   }
   a.wide = x3_wide_enabled() && a.Wo % 4 == 0 && a.TW % 4 == 0 && ((uintptr_t)a.out & 15) == 0 &&
            (!post || ((uintptr_t)post->x & 15) == 0);
-  // the fold inside the launch (FRCNN_X3_INFOLD=0: the separate fold launch; deterministic mode keeps it too: the slope sum
-  // of a fused activation backward meets in an atomic)
-  static const int infold = getenv("FRCNN_X3_INFOLD") ? atoi(getenv("FRCNN_X3_INFOLD")) : 0;   // measured slower: off
-  if (slab && infold && a.wide && ((uintptr_t)out & 15) == 0 && (long)a.tilesX * a.tilesY * a.mTiles <= X3_TICKETS &&
-      (double)M * a.Ho * a.Wo * 4.0 < 2147483647.0 && !(post && deterministic())) {
-    a.fold_tickets = tickets; a.fold_out = out; a.fold_bias = bias; a.fold_add = out_mode == OUT_ADD ? 1 : 0;
-    slab = false;   // nothing left to fold behind the launch
-  }
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
