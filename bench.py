@@ -588,9 +588,12 @@ def main():
     # thermals are steady by then and an external SMI sampler sees the device busy.  `value` stays the K timed steps above.
     sustained = None
     if not args.no_sustained:
+        # (1000 steps at the speed just measured, but never more than ~8 s of them: a debug back end that takes hundreds of
+        # milliseconds per step must not turn this pass into minutes)
+        n_sus = max(20, min(SUSTAINED_STEPS, int(8.0 / max(dt / args.steps, 1e-4))))
         barrier()
         ts = time.perf_counter()
-        for _ in range(SUSTAINED_STEPS):
+        for _ in range(n_sus):
             step()
         barrier()
         ts = time.perf_counter() - ts
@@ -600,8 +603,8 @@ def main():
             tmx = torch.tensor([ts], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
             ts = float(tmx.item())
-        sustained = dict(steps=SUSTAINED_STEPS, value=round(world * SUSTAINED_STEPS / ts, 3), unit="images/sec",
-                         ms_per_step=round(1e3 * ts / SUSTAINED_STEPS, 3), seconds=round(ts, 2))
+        sustained = dict(steps=n_sus, value=round(world * n_sus / ts, 3), unit="images/sec",
+                         ms_per_step=round(1e3 * ts / n_sus, 3), seconds=round(ts, 2))
     # HBM-bound kernels of the live step: four more steps with those classes bracketed
     hbm = None
     if world == 1:
