@@ -576,6 +576,12 @@ def main():
             F._lib.call("frcnn_prof_enable", 0)
     barrier()
     dt = time.perf_counter() - t0
+    if native_comm is not None:      # the job's time is the slowest rank's (every rank gets the same number: it also sizes
+        dt = native_comm.gather_max(dt)   # the sustained pass, which is a sequence of collectives)
+    elif world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     host_t = state.pop("_timing")
     bucket_times = None
     if native_comm is not None:
@@ -666,13 +672,6 @@ def main():
                           bytes_per_frame=int(3 * H * W * 4),
                           note="same step with the frame uploaded from page-locked host memory every step (objective.lua:66 "
                                "x.img:cuda()), asynchronously on a copy stream one step ahead; not the headline value")
-    if native_comm is not None:
-        dt = native_comm.gather_max(dt)
-    elif world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
     if rank == 0:
         fwd_flops, train_flops = conv_flops_per_image(model, H, W)
         split_on = launches[F._lib.KC_NAMES.index("conv_x3")] > 0
