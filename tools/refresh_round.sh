@@ -67,6 +67,11 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/detect -- python $R/tools/bench_detect.py 30 > $O/detect.log 2>&1
 cd $R
 cp $O/detect/*/*kernel_stats.csv $O/${TAG}_detect_kernel_stats.csv 2>/dev/null
+# 5b. BASELINE config 5's one-GPU workload (vgg_large 3x600x1000) under rocprofv3: kernel stats of its training step
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/large -- python $R/bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline --no-upload-leg --no-sustained > $O/large.log 2>&1
+cd $R
+cp $O/large/*/*kernel_stats.csv $O/${TAG}_vgg_large_kernel_stats.csv 2>/dev/null
 # 6. the weight-gradient kernel by itself: per-launch durations of kernel and fold, and the PMC groups behind the LDS / matrix-pipe figures
 {
   echo "# conv_wgradx_kernel + wgrad_reduce4_kernel per layer -- bash tools/ktrace.sh wgrad -- python tools/bench_conv.py wgrad <layers>"
