@@ -293,3 +293,30 @@ def test_model_layer_shapes_full_size(F, name, C_, H, W, O_, pad):
                 assert_close(got, ref, 2e-4, "%s %s, split form vs fp32 matrix-core kernel" % (name, what))
     finally:
         _option(F, "split_bf16", before)
+
+
+@pytest.mark.parametrize("k", [5, 7])
+def test_anchor_net_shapes_full_size(F, k):
+    """The 5x5 / 7x7 anchor nets of vgg_small at the benchmarked size (384 -> 256 on the 29x50 map, valid): since round 5 their
+    forward pass takes the split form by default (8x16-pixel tiles, 240 / 308-position patch, up to 24 K splits + fold).
+    Against the fp32 matrix-core kernel, three runs."""
+    rng = np.random.RandomState(k)
+    C_, H, W, O_ = 384, 29, 50, 256
+    Ho, Wo = H - k + 1, W - k + 1
+    x = _dev(F, rng.randn(C_, H, W).astype(np.float32))
+    w, b = _dev(F, (rng.randn(O_, C_, k, k) * 0.03).astype(np.float32)), _dev(F, rng.randn(O_).astype(np.float32))
+
+    def fwd():
+        out = F.DeviceTensor.empty((O_, Ho, Wo))
+        F._lib.call("frcnn_conv2d_forward", F.ptr(x), C_, H, W, None, None, F.ptr(w), F.ptr(b), O_, k, 0, F.ptr(out), F.stream_ptr())
+        return out.numpy()
+    before = _option(F, "split_bf16", 0)
+    try:
+        want = fwd()
+        _option(F, "split_bf16", 1)
+        for _ in range(3):
+            got = fwd()
+            assert not np.array_equal(got, want), "the option did not switch the kernel"
+            assert_close(got, want, 2e-4, "%dx%d anchor net, split form vs fp32 matrix-core kernel" % (k, k))
+    finally:
+        _option(F, "split_bf16", before)
