@@ -177,7 +177,13 @@ int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope,
 // gx[c][y][x] = (argmax of window == this position ? gpool : 0) * scale[c] * prelu'(x)
 // One block per (channel, slab of rows): the bias-gradient and slope-gradient partial sums are
 // reduced in the block and leave through one atomic each.
-#define ACT_BWD_THREADS 1024
+// 512 threads: two waves per SIMD at 40 registers.  In the backward phase this pass runs beside conv_wgradx, whose one block per CU
+// holds 392 of a SIMD's 512 registers: a 1024-thread block (4 x 40 registers per SIMD) does not fit beside it and waited for
+// weight-gradient blocks to retire -- 60-70 us live for a 15-us pass on the dependent chain (profiles/r05_step_timeline.txt).
+// Same-box A/B of the step: 2.824 (1024) / 2.799 (768) / 2.796 ms (512).
+#ifndef ACT_BWD_THREADS
+#define ACT_BWD_THREADS 512
+#endif
 template <bool POOLED, bool VEC>
 __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
                                     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
