@@ -7,7 +7,8 @@ normalisation of the luminance channel), so the frame is never touched by the ho
 Differences that are stated rather than hidden:
   * decoding stays on the host: `load_image(fn)` is a callable that returns the DECODED float RGB frame [3][H][W] in
     0..1 (what image.load(fn, 3, 'float') returns); the default decodes with Pillow (`.npy` arrays are read as they
-    are).  Only color_space 'yuv' (both shipped configs) and 'rgb' are implemented.
+    are).  color_space 'yuv' (both shipped configs) is fused into the scaling pass; 'lab' and 'hsv' are converted at
+    full resolution first (frcnn_image_rgb2lab / _rgb2hsv), decode-ahead frames included; anything else stays RGB.
   * `math.random` is LuaJIT's own PRNG (not reproducible outside LuaJIT): every draw comes from the MT19937
     stream also used for torch.random / torch.randperm (same substitution as Anchors.sampleNegative).
 The sequence of draws follows the reference line by line (BatchIterator.lua:112-143, :7-25)."""
@@ -401,26 +402,22 @@ class BatchIterator(object):
     def load_image(self, fn, materialize=False, what="examples"):
         """what: 'examples' (cfg.examples_base_path) or 'background' (cfg.background_base_path, BatchIterator.lua:255)."""
         base = self.base_of[what]
-        if self.ahead is not None and not materialize:
-            cs = self.cfg.get("color_space", "rgb")
-            if cs not in ("yuv", "rgb"):
-                raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
+        cs = self.cfg.get("color_space", "rgb")
+        full_frame = cs in ("lab", "hsv")   # not fused into the scaling pass: converted at full resolution, as load_image does
+        if self.ahead is not None and not materialize and not full_frame:
             return self.ahead.get(fn, base)
         if self.ahead is not None:
             self.ahead.forget(fn, base)   # loaded here instead: its prefetched decode (if any) is not kept around
         img = to_device(self.load_image_fn(fn) if self._custom_loader else self.load_image_fn(fn, base))
         if len(img.shape) != 3 or img.shape[0] != 3:
             return img   # the caller reports the unexpected channel count (:185-188)
-        cs = self.cfg.get("color_space", "rgb")
-        if cs == "yuv":
-            if not materialize:
-                return _RgbFrame(img)   # converted inside processImage's first pass
+        if cs == "yuv" and not materialize:
+            return _RgbFrame(img)   # converted inside processImage's first pass
+        if cs in ("yuv", "lab", "hsv"):   # utilities.lua:210-216
             out = _PooledTensor(self.pool, tuple(img.shape))
-            _lib.call("frcnn_image_rgb2yuv", ptr(img), ptr(out), img.shape[1], img.shape[2], stream_ptr())
+            _lib.call("frcnn_image_rgb2" + cs, ptr(img), ptr(out), img.shape[1], img.shape[2], stream_ptr())
             return out
-        if cs != "rgb":
-            raise _lib.FrcnnError("color_space '%s' is not implemented (yuv / rgb only)" % cs)
-        return img
+        return img   # 'rgb', and (as in the reference) any other string: the frame stays RGB
 
     # ---- BatchIterator.lua:101-164
     def processImage(self, img, rois=None):

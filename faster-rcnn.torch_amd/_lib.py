@@ -118,6 +118,8 @@ _SIGS = {
     "frcnn_allreduce_f64": ([vp, vp, C.c_longlong, vp], C.c_int),
     "frcnn_broadcast_f32": ([vp, vp, C.c_longlong, C.c_int, vp], C.c_int),
     "frcnn_image_rgb2yuv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
+    "frcnn_image_rgb2hsv": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
+    "frcnn_image_rgb2lab": ([vp, vp, C.c_int, C.c_int, vp], C.c_int),
     "frcnn_image_scale": ([vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
     "frcnn_image_scale_u8": ([vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp], C.c_int),
     "frcnn_image_crop_flip": ([vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),

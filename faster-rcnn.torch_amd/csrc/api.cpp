@@ -384,6 +384,14 @@ int frcnn_image_rgb2yuv(const float* rgb, float* yuv, int H, int W, void* stream
   FR_CHECK(rgb != yuv, "image_rgb2yuv: in-place conversion is not supported");
   return image_rgb2yuv(rgb, yuv, H, W, S(stream));
 }
+int frcnn_image_rgb2hsv(const float* rgb, float* hsv, int H, int W, void* stream) {
+  FR_CHECK(rgb != hsv, "image_rgb2hsv: in-place conversion is not supported");
+  return image_rgb2hsv(rgb, hsv, H, W, S(stream));
+}
+int frcnn_image_rgb2lab(const float* rgb, float* lab, int H, int W, void* stream) {
+  FR_CHECK(rgb != lab, "image_rgb2lab: in-place conversion is not supported");
+  return image_rgb2lab(rgb, lab, H, W, S(stream));
+}
 int frcnn_image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
                       void* stream) {
   return image_scale(src, C, H, W, dst, dH, dW, tmp, rgb2yuv, S(stream));

@@ -35,6 +35,63 @@ int image_rgb2yuv(const float* rgb, float* yuv, int H, int W, hipStream_t s) {
   return FRCNN_OK;
 }
 
+// ---------------------------------------------------------------- rgb2hsv / rgb2lab
+// The other two conversions load_image offers (utilities.lua:212-215).  image/generic/image.c does them per pixel in `real`
+// (float) with the C library's double pow(); here pow() is double too, so the two agree to the rounding of the final cast.
+__global__ void rgb2hsv_kernel(const float* __restrict__ rgb, float* __restrict__ hsv, long hw) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    const float r = rgb[i], g = rgb[hw + i], b = rgb[2 * hw + i];
+    const float mx = fmaxf(fmaxf(r, g), b), mn = fminf(fminf(r, g), b);
+    float h = 0.f, sat = 0.f;
+    if (mx != mn) {   // (achromatic pixels keep h = s = 0)
+      const float d = mx - mn;
+      if (mx == r) h = (g - b) / d + (g < b ? 6.f : 0.f);
+      else if (mx == g) h = (b - r) / d + 2.f;
+      else h = (r - g) / d + 4.f;
+      h /= 6.f;
+      sat = d / mx;
+    }
+    hsv[i] = h; hsv[hw + i] = sat; hsv[2 * hw + i] = mx;
+  }
+}
+__device__ __forceinline__ float srgb_expand(float c) {
+  return c <= 0.04045f ? (float)((double)c / 12.92) : (float)pow(((double)c + 0.055) / 1.055, 2.4);
+}
+__device__ __forceinline__ double lab_f(double t) {
+  const double eps = 216.0 / 24389.0, kappa = 24389.0 / 27.0;
+  return t > eps ? pow(t, 1.0 / 3.0) : (kappa * t + 16.0) / 116.0;
+}
+__global__ void rgb2lab_kernel(const float* __restrict__ rgb, float* __restrict__ lab, long hw) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+    // (the expanded channels are `real`; X, Y, Z and the three cube roots stay double until the final stores)
+    const float r = srgb_expand(rgb[i]), g = srgb_expand(rgb[hw + i]), b = srgb_expand(rgb[2 * hw + i]);
+    double x = 0.412453 * r + 0.357580 * g + 0.180423 * b;   // linear sRGB -> XYZ
+    const double y = 0.212671 * r + 0.715160 * g + 0.072169 * b;
+    double z = 0.019334 * r + 0.119193 * g + 0.950227 * b;
+    x /= 0.950456; z /= 1.088754;                              // D65 white point
+    const double fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
+    lab[i] = (float)(116.0 * fy - 16.0);
+    lab[hw + i] = (float)(500.0 * (fx - fy));
+    lab[2 * hw + i] = (float)(200.0 * (fy - fz));
+  }
+}
+int image_rgb2hsv(const float* rgb, float* hsv, int H, int W, hipStream_t s) {
+  const long hw = (long)H * W;
+  if (hw <= 0) return FRCNN_OK;
+  int grid = (int)std::min<long>(cdivl(hw, 256), 4096);
+  FR_LAUNCH(KC_IMAGE, 0, hw * 24.0, s, rgb2hsv_kernel, dim3(grid), dim3(256), 0, rgb, hsv, hw);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+int image_rgb2lab(const float* rgb, float* lab, int H, int W, hipStream_t s) {
+  const long hw = (long)H * W;
+  if (hw <= 0) return FRCNN_OK;
+  int grid = (int)std::min<long>(cdivl(hw, 256), 4096);
+  FR_LAUNCH(KC_IMAGE, 0, hw * 24.0, s, rgb2lab_kernel, dim3(grid), dim3(256), 0, rgb, lab, hw);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 // ---------------------------------------------------------------- image.scale ('bilinear')
 // One output sample per thread along one axis: src[(o*src_len + s)*inner + i] -> dst[(o*dst_len + d)*inner + i].
 // Up-scaling interpolates with scale (src_len-1)/(dst_len-1) and copies the last sample; down-scaling is a box

@@ -249,6 +249,8 @@ int cnet_decode(const float* cls_lsm, int R, int ncls, int* cls_out, float* conf
 
 // ---------------------------------------------------------------- image (image.hip): BatchIterator:processImage
 int image_rgb2yuv(const float* rgb, float* yuv, int H, int W, hipStream_t s);
+int image_rgb2hsv(const float* rgb, float* hsv, int H, int W, hipStream_t s);
+int image_rgb2lab(const float* rgb, float* lab, int H, int W, hipStream_t s);
 // image.scale 'bilinear': src [C][H][W] -> dst [C][dH][dW]; tmp holds C*H*dW floats
 int image_scale(const float* src, int C, int H, int W, float* dst, int dH, int dW, float* tmp, int rgb2yuv,
                 hipStream_t s);

@@ -369,6 +369,11 @@ int frcnn_cnet_decode(const float *cls_out, int R, int ncls, int *cls, float *co
  * [C][H][W] resident in device memory.  All calls are asynchronous on `stream`. */
 /* image.rgb2yuv (utilities.lua load_image, color_space 'yuv'): rgb, yuv float[3][H][W] (may not alias). */
 int frcnn_image_rgb2yuv(const float *rgb, float *yuv, int H, int W, void *stream);
+/* image.rgb2hsv / image.rgb2lab (utilities.lua:212-215 load_image, color_space 'hsv' / 'lab'; main.lua:174-177): rgb in [0,1],
+ * out float[3][H][W] (may not alias).  hsv: h in [0,1), s, v as image/generic/image.c computes them (h = s = 0 for a grey
+ * pixel).  lab: sRGB gamma expansion, XYZ with the D65 white point, CIE L*a*b* (epsilon 216/24389, kappa 24389/27). */
+int frcnn_image_rgb2hsv(const float *rgb, float *hsv, int H, int W, void *stream);
+int frcnn_image_rgb2lab(const float *rgb, float *lab, int H, int W, void *stream);
 /* image.scale(img, dW, dH), 'bilinear' (BatchIterator.lua:51): rows then columns; up-scaling interpolates
  * linearly, down-scaling averages the covered source interval.  tmp: device float[C*H*dW].
  * rgb2yuv != 0 (C == 3): src is the RGB frame and every source sample goes through image.rgb2yuv on the fly --

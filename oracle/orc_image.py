@@ -2,7 +2,7 @@
 (BatchIterator.lua:101-164).  Imported by tests/ only; the product path never touches it.
 
 PARITY UNPINNED.  processImage is a thin caller of two third-party luarocks that are NOT in /root/reference:
-  * torch `image` (image.scale / hflip / vflip / crop / rgb2yuv / gaussian1D), rockspec image-1.1.alpha
+  * torch `image` (image.scale / hflip / vflip / crop / rgb2yuv / rgb2hsv / rgb2lab / gaussian1D), rockspec image-1.1.alpha
   * torch `nn`    (nn.SpatialContrastiveNormalization = Subtractive + Divisive normalisation), nn scm-1
 Their algorithms are restated here from the published sources (image/generic/image.c `scaleLinear_rowcol`
 + `Main_scaleBilinear`, image/init.lua `gaussian1D` / `rgb2yuv`, nn/SpatialSubtractiveNormalization.lua,
@@ -47,6 +47,43 @@ def rgb2yuv(img):
     u = f32(-0.14713) * r - f32(0.28886) * g + f32(0.436) * b
     v = f32(0.615) * r - f32(0.51499) * g - f32(0.10001) * b
     return np.stack([y, u, v]).astype(f32)
+
+
+# ------------------------------------------------------------------ image.rgb2hsv / image.rgb2lab (image/generic/image.c)
+def rgb2hsv(img):
+    """load_image with color_space 'hsv' (utilities.lua:214-215).  Per pixel, in float: v = max, s = (max-min)/max,
+    h = the sextant formula / 6; a grey pixel (max == min) gets h = s = 0."""
+    r, g, b = img[0].astype(f32), img[1].astype(f32), img[2].astype(f32)
+    mx = np.maximum(np.maximum(r, g), b); mn = np.minimum(np.minimum(r, g), b)
+    d = (mx - mn).astype(f32)
+    grey = mx == mn
+    dd = np.where(grey, f32(1), d)
+    h = np.where(mx == r, (g - b) / dd + np.where(g < b, f32(6), f32(0)),
+                 np.where(mx == g, (b - r) / dd + f32(2), (r - g) / dd + f32(4))).astype(f32)
+    h = (h / f32(6)).astype(f32)
+    s = (d / np.where(grey, f32(1), mx)).astype(f32)
+    return np.stack([np.where(grey, f32(0), h), np.where(grey, f32(0), s), mx]).astype(f32)
+
+
+def _srgb_expand(c):
+    c64 = c.astype(np.float64)
+    return np.where(c <= f32(0.04045), c64 / 12.92, np.power((c64 + 0.055) / 1.055, 2.4)).astype(f32)
+
+
+def rgb2lab(img):
+    """load_image with color_space 'lab' (utilities.lua:212-213).  sRGB gamma expansion (result kept in float), linear
+    sRGB -> XYZ and the D65 white point in double, f(t) = t^(1/3) above epsilon = 216/24389 else (kappa t + 16)/116 with
+    kappa = 24389/27, L = 116 fy - 16, a = 500 (fx - fy), b = 200 (fy - fz), stored as float."""
+    r, g, b = (_srgb_expand(img[k].astype(f32)).astype(np.float64) for k in range(3))
+    x = (0.412453 * r + 0.357580 * g + 0.180423 * b) / 0.950456
+    y = 0.212671 * r + 0.715160 * g + 0.072169 * b
+    z = (0.019334 * r + 0.119193 * g + 0.950227 * b) / 1.088754
+    eps, kappa = 216.0 / 24389.0, 24389.0 / 27.0
+
+    def f(t):
+        return np.where(t > eps, np.cbrt(np.maximum(t, 0.0)), (kappa * t + 16.0) / 116.0)
+    fx, fy, fz = f(x), f(y), f(z)
+    return np.stack([116.0 * fy - 16.0, 500.0 * (fx - fy), 200.0 * (fy - fz)]).astype(f32)
 
 
 # ------------------------------------------------------------------ image.scale, mode 'bilinear' (the default)

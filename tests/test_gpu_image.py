@@ -27,6 +27,26 @@ def test_rgb2yuv(F):
     assert np.array_equal(out.numpy(), OI.rgb2yuv(img))
 
 
+@pytest.mark.parametrize("space", ["hsv", "lab"])
+def test_rgb2hsv_and_rgb2lab(F, space):
+    """The other two colour spaces of load_image (utilities.lua:212-215).  hsv is float arithmetic in a fixed order: bit
+    exact.  lab goes through pow(): 2e-5 absolute on values of magnitude <= 128 (the cube roots differ in the last bits)."""
+    rng = np.random.RandomState(3)
+    img = rng.rand(3, 61, 83).astype(np.float32)
+    img[:, 0, :8] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [0, 0, 0], [.5, .5, .5], [.02, .03, .01], [1, 0, 1]], np.float32).T
+    img[:, 1, :] = img[0, 1, :]   # a grey row
+    out = F.DeviceTensor.empty((3, 61, 83))
+    d = _dev(F, img)
+    F._lib.call("frcnn_image_rgb2" + space, F.ptr(d), F.ptr(out), 61, 83, F.stream_ptr())
+    got, want = out.numpy(), getattr(OI, "rgb2" + space)(img)
+    if space == "hsv":
+        assert np.array_equal(got, want)
+    else:
+        assert np.abs(got - want).max() < 2e-5
+    with pytest.raises(F._lib.FrcnnError):
+        F._lib.call("frcnn_image_rgb2" + space, F.ptr(d), F.ptr(d), 61, 83, F.stream_ptr())
+
+
 @pytest.mark.parametrize("src,dst", [((3, 40, 64), (90, 150)), ((3, 90, 150), (40, 64)), ((3, 108, 192), (45, 80)),
                                      ((3, 50, 70), (50, 33)), ((3, 31, 47), (77, 47)), ((1, 1, 1), (5, 4)),
                                      ((3, 33, 100), (33, 100)), ((2, 64, 3), (7, 200))])
@@ -274,6 +294,15 @@ def test_batch_iterator_decodes_image_files(F, small_cfg, tmp_path):
     a = F.BatchIterator(m2, data).nextValidation(1)[0]["img"].numpy()
     b = F.BatchIterator(m2, data, workers=2).nextValidation(1)[0]["img"].numpy()
     assert np.array_equal(a, b)
+    # 'lab' and 'hsv' (utilities.lua:212-215): converted at full resolution before processImage, with or without the pool
+    rgb01 = (px.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1)
+    for space, tol in (("hsv", 2e-5), ("lab", 2e-4)):
+        cfg_s = dict(cfg); cfg_s["color_space"] = space
+        ms = dict(model); ms["cfg"] = cfg_s
+        a = F.BatchIterator(ms, data).nextValidation(1)[0]["img"].numpy()
+        b = F.BatchIterator(ms, data, workers=2).nextValidation(1)[0]["img"].numpy()
+        assert np.array_equal(a, b)
+        assert_close(a, OI.process_image(getattr(OI, "rgb2" + space)(rgb01), cfg_s), tol, "prepared %s frame" % space)
 
 
 def test_background_base_path_and_many_frame_sizes(F, small_cfg, tmp_path):

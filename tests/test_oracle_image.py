@@ -54,6 +54,23 @@ def test_gaussian_and_yuv_known_answers():
     assert abs(white[0, 0, 0] - 1.0) < 1e-6 and abs(white[1, 0, 0]) < 2e-5 and abs(white[2, 0, 0]) < 2e-5   # (the published coefficients sum to 1e-5)
 
 
+def test_hsv_and_lab_known_answers():
+    """image.rgb2hsv / image.rgb2lab (load_image, utilities.lua:212-215) against values anyone can look up: the hue circle's
+    corners, and the published CIE L*a*b* coordinates (D65) of the sRGB primaries."""
+    def px(fn, r, g, b):
+        return fn(np.array([r, g, b], np.float32).reshape(3, 1, 1)).reshape(3).astype(np.float64)
+    for rgb, hsv in (((1, 0, 0), (0, 1, 1)), ((1, 1, 0), (1 / 6, 1, 1)), ((0, 1, 0), (1 / 3, 1, 1)), ((0, 1, 1), (1 / 2, 1, 1)),
+                     ((0, 0, 1), (2 / 3, 1, 1)), ((1, 0, 1), (5 / 6, 1, 1)), ((0.5, 0.5, 0.5), (0, 0, 0.5)), ((0, 0, 0), (0, 0, 0)),
+                     ((0.5, 0.25, 0.25), (0, 0.5, 0.5)), ((0.2, 0.4, 0.8), (11 / 18, 0.75, 0.8))):
+        assert np.allclose(px(OI.rgb2hsv, *rgb), hsv, atol=1e-6), (rgb, px(OI.rgb2hsv, *rgb))
+    for rgb, lab in (((1, 1, 1), (100, 0, 0)), ((0, 0, 0), (0, 0, 0)), ((1, 0, 0), (53.24, 80.09, 67.20)),
+                     ((0, 1, 0), (87.73, -86.18, 83.18)), ((0, 0, 1), (32.30, 79.19, -107.86)), ((0.5, 0.5, 0.5), (53.39, 0, 0))):
+        assert np.allclose(px(OI.rgb2lab, *rgb), lab, atol=0.02), (rgb, px(OI.rgb2lab, *rgb))
+    # the linear toe of the sRGB curve and of f(t): a very dark grey
+    dark = px(OI.rgb2lab, 0.02, 0.02, 0.02)
+    assert abs(dark[0] - (24389.0 / 27.0) * (0.02 / 12.92)) < 1e-4 and abs(dark[1]) < 1e-4 and abs(dark[2]) < 1e-4
+
+
 def test_center_and_scale_properties():
     rng = np.random.RandomState(0)
     img = (rng.rand(3, 40, 50) * np.array([1, 5, 0.1])[:, None, None] + np.array([3, -2, 0.5])[:, None, None]).astype(np.float32)

@@ -192,3 +192,13 @@ def test_row18_flat_parameter_order_and_snapshot(fx):
     if snap and os.path.exists(os.path.join(HERE, "golden", os.path.basename(snap))):
         st = t7.load_obj(os.path.join(HERE, "golden", os.path.basename(snap)))
         assert st["version"] == 0 and np.asarray(st["weights"]).size == 4096 and st["options"]["name"] == "fixture"
+
+
+def test_row20_colour_spaces(fx):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import orc_image as OI
+    r = fx[20]
+    close(OI.rgb2yuv(r["rgb"]), r["yuv"], "image.rgb2yuv", 1e-6)
+    close(OI.rgb2hsv(r["rgb"]), r["hsv"], "image.rgb2hsv", 1e-6)
+    close(OI.rgb2lab(r["rgb"]), r["lab"], "image.rgb2lab", 1e-5)

@@ -18,6 +18,7 @@ require 'torch'
 require 'nn'
 require 'nngraph'
 require 'optim'
+require 'image'
 
 torch.setdefaulttensortype('torch.FloatTensor')
 local out_path = arg and arg[1] or 'torch7_fixtures.t7'
@@ -259,6 +260,16 @@ do
   local order = {}
   for c, _ in pairs(yclass) do order[#order + 1] = c end
   F.rows[19] = { inserted = torch.Tensor({ 5, 2, 9, 2, 1, 5 }):float(), pairs_order = torch.Tensor(order):float() }
+end
+
+-- row 20: the colour spaces load_image offers beside yuv (utilities.lua:210-216)
+do
+  local rgb = torch.rand(3, 9, 11):float()
+  rgb[{ {}, 1, 1 }] = torch.Tensor({ 1, 0, 0 }):float(); rgb[{ {}, 1, 2 }] = torch.Tensor({ 0, 1, 0 }):float()
+  rgb[{ {}, 1, 3 }] = torch.Tensor({ 0, 0, 1 }):float(); rgb[{ {}, 1, 4 }] = torch.Tensor({ 1, 1, 1 }):float()
+  rgb[{ {}, 1, 5 }] = torch.Tensor({ 0, 0, 0 }):float(); rgb[{ {}, 1, 6 }] = torch.Tensor({ .5, .5, .5 }):float()
+  rgb[{ {}, 1, 7 }] = torch.Tensor({ .02, .03, .01 }):float()
+  F.rows[20] = { rgb = rgb, yuv = image.rgb2yuv(rgb), hsv = image.rgb2hsv(rgb), lab = image.rgb2lab(rgb) }
 end
 
 local f = torch.DiskFile(out_path, 'w')   -- ASCII, as the reference's save_obj writes it

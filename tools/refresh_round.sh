@@ -26,6 +26,10 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         for k, v in rows:
             w.writerow([k, len(v), round(sum(v) / len(v), 1), round(sum(v), 1)])
 PY
+if [ -n "$PMC_ONLY" ]; then   # only the traffic table (after a change under csrc/ that leaves the measured kernels alone)
+  cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json; cp $O/pmc_traffic.json $R/gpurun_out/pmc_traffic.json
+  rm -rf $O/fetch $O/write $O/mfma; exit 0
+fi
 # 2. kernel stats of the bench command (rocprofv3 --kernel-trace --stats) and the step timeline of the same trace
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-upload-leg --no-sustained > $O/${TAG}_bench_under_rocprof.json 2> $O/stats.log
