@@ -34,6 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define CX_BM 128                       // filters per block
 #define CX_CH 16                        // channels per chunk (one MFMA K step per tap)
@@ -98,6 +100,52 @@ __device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint
   L = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// ---- the two-plane fp16 form (experimental, FRCNN_X3_F16): x * 2^e = h + l + eps with h = f16(x 2^e), l = f16(x 2^e - h),
+// |eps| <= 2^-23 |x 2^e| in the normal range; e puts the tensor's largest magnitude into [2^14, 2^15) (x16_exp), so that
+// h never overflows and the residual of every element within 2^-18 of the maximum is a normal fp16 number.  A product is
+// formed from THREE exact partial products h*h' + h*l' + l*h' (11 x 11 significand bits; the dropped l*l' is <= 2^-22).
+__device__ __forceinline__ unsigned cvt2h(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 r = __builtin_convertvector(v, f16x2);   // round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split8h(const float* v, uint4& H, uint4& L) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    h[j] = cvt2h(x0, x1);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h[j]);
+    l[j] = cvt2h(x0 - (float)hv[0], x1 - (float)hv[1]);
+  }
+  H = make_uint4(h[0], h[1], h[2], h[3]);
+  L = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// exponent e with amax * 2^e in [2^top, 2^(top+1)); 0 for an all-zero tensor
+__device__ __forceinline__ int x16_exp(float amax, int top) {
+  const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
+  if (be == 0) return 0;
+  const int e = top - (be - 127);
+  return e < -100 ? -100 : e > 100 ? 100 : e;
+}
+__device__ __forceinline__ float x16_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+// largest magnitude of a tensor, as the bit pattern of a non-negative float (atomicMax on the unsigned image)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+int tensor_absmax(const float* x, long n, float* out, hipStream_t s) {
+  FR_HIP(hipMemsetAsync(out, 0, 4, s));
+  if (n <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 4.0, s, absmax_kernel, dim3((int)std::min<long>(cdivl(n, 256), 2048)), dim3(256), 0, x, n, (unsigned*)out);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------ weight packing
 // dst, per (m tile, chunk, tap): one A stage [plane][half][128][8] -- exactly the LDS image.
 //  mode 0 (fwd):   A[m][kc][tap] = W[m][kc][tap]            (W is [O][C][3][3]: M = O, K channels = C)
@@ -109,13 +157,14 @@ __device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint
 // pairs of a vgg_small step are ONE round on the 1024 slots (with 128 rows / 74 KB / two per CU they were 1.05 rounds of 512:
 // the launch took two block times, 50 us at the head of every step)
 #define PX_FLOATS (64 * 145)
-template <int KS, int ROWS>
+template <int KS, int ROWS, int NP = 3>
 __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
   constexpr int KK = KS * KS, PITCH = CX_CH * KK + 1;   // odd pitch: the stride-KK reads of a lane's 8 channels spread over the banks
   static_assert(ROWS * PITCH <= PX_FLOATS, "pack tile does not fit");
   const float* __restrict__ w = weights + j.w_off;
   const int M = j.mode == 0 ? j.O : j.C, KC = j.mode == 0 ? j.C : j.O;
-  const int BM = j.bm, AST = 6 * BM * 16;
+  const int BM = j.bm, AST = 2 * NP * BM * 16;
+  const float wmul = NP == 2 ? x16_pow2(x16_exp(*j.amax, 14)) : 1.f;
   const int nCh = KC / CX_CH, pairs = (M / BM) * nCh;
   const int tid = threadIdx.x;
   const int groups = BM / ROWS;   // work unit = ROWS filter rows of one pair: equal units, one per block (conv_x3_pack_assign_blocks)
@@ -146,18 +195,27 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = tile[r * PITCH + (8 * h + i) * KK + st];
         uint4 H, Mi, L;
-        split8(v, H, Mi, L);
         char* stage = base + (size_t)tap * AST;
-        *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * BM + r0 + r) * 16) = H;
-        *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * BM + r0 + r) * 16) = Mi;
-        *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * BM + r0 + r) * 16) = L;
+        if (NP == 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] *= wmul;
+          split8h(v, H, L);
+          *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * BM + r0 + r) * 16) = H;
+          *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * BM + r0 + r) * 16) = L;
+        } else {
+          split8(v, H, Mi, L);
+          *reinterpret_cast<uint4*>(stage + ((0 * 2 + h) * BM + r0 + r) * 16) = H;
+          *reinterpret_cast<uint4*>(stage + ((1 * 2 + h) * BM + r0 + r) * 16) = Mi;
+          *reinterpret_cast<uint4*>(stage + ((2 * 2 + h) * BM + r0 + r) * 16) = L;
+        }
       }
       __syncthreads();
     }
   }
 }
 __device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
-  if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
+  if (j.k == 3 && j.amax) pack_x_job<3, 64, 2>(weights, j, blk, nblk, tile);
+  else if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
   else if (j.k == 5) pack_x_job<5, 16>(weights, j, blk, nblk, tile);
   else pack_x_job<7, 8>(weights, j, blk, nblk, tile);
 }
@@ -182,6 +240,7 @@ PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, 
   j.bm = conv_x3_bm(mode == 0 ? O : C, Ho, Wo, k);
   j.total = (long)O * C * k * k;
   j.blk_begin = 0; j.nblk = 1;
+  j.amax = nullptr;
   return j;
 }
 
@@ -205,8 +264,9 @@ int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs
 }
 
 // one pack by itself (op-level entry points and tests)
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo) {
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo, const float* amax_w) {
   PackXJob j = conv_x3_pack_job(0, O, C, k, mode, dst, Ho, Wo);
+  j.amax = amax_w;   // non-null: the two-plane fp16 form, scaled by the weight tensor's largest magnitude
   int grid = conv_x3_pack_assign_blocks(&j, 1);
   FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_kernel, dim3(grid), dim3(256), 0, w, j);
   FR_LAUNCH_CHECK();
@@ -228,6 +288,8 @@ struct CxArgs {
 #ifdef CX_TRACE
   unsigned long long* trace;   // [block][64] timestamps (s_memrealtime, 100 MHz) -- tools/x3_trace.py
 #endif
+  const float* amax_in;   // NP = 2 only: largest magnitude of the input tensor / of the weight tensor (device scalars)
+  const float* amax_w;
   int wide;               // 1: the epilogue goes through LDS and stores 16 bytes per lane (Wo % 4 == 0, TW % 4 == 0, aligned tensors)
   X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
@@ -237,10 +299,11 @@ struct CxArgs {
 // not a multiple of 128 (the 64-channel input gradients).
 // EPI = 1 (input-gradient launches that store, out_mode 0): the stored tile goes through the backward of the activation
 // that follows in the chain (X3PostAct) -- one read of x per element instead of act_backward's read + read + write pass.
-template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0>
+template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0, int NP = 3>
 __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxArgs p) {
   constexpr int KK = KS * KS, PP = cx_pp(KS), NIT = (2 * PP + 255) / 256;   // staging items per thread
-  constexpr int BMK = 64 * WM, NTW = WM, AST = 6 * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
+  constexpr int BMK = 64 * WM, NTW = WM, AST = 2 * NP * BMK * 16, NDMA = AST / 1024;   // filters per block, pixel tiles per wave, stage bytes
+  using frag_t = typename std::conditional<NP == 2, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,6 +365,14 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
     gsel[it] = g;
   }
   const float slope = SLOPE ? *p.in_slope : 1.f;
+  float in_mul = 1.f, out_mul = 1.f;
+  if (NP == 2) {   // (headroom of one binade for a dropout scale: its entries are <= 1 in both modes, see net.cpp)
+    float ai = *p.amax_in;
+    if (SLOPE) ai *= fmaxf(1.f, fabsf(slope));
+    const int ei = x16_exp(ai, SCALE ? 13 : 14), ew = x16_exp(*p.amax_w, 14);
+    in_mul = x16_pow2(ei);
+    out_mul = x16_pow2(-(ei + ew));
+  }
 
   // ---- lane offsets of the MFMA operand reads
   const unsigned aoff = (unsigned)((h * BMK + wm * 64 + li) * 16);
@@ -391,12 +462,23 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         x[j] = gok[it] ? t : 0.f;
       }
       uint4 H, Mi, L;
-      split8(x, H, Mi, L);
-      if (sdst[it] != 0xFFFFFFFFu) {
-        char* d = Bb + sdst[it];
-        *reinterpret_cast<uint4*>(d) = H;
-        *reinterpret_cast<uint4*>(d + 2 * PP * 16) = Mi;
-        *reinterpret_cast<uint4*>(d + 4 * PP * 16) = L;
+      if (NP == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[j]) : "v"(x[j]), "v"(in_mul));
+        split8h(x, H, L);
+        if (sdst[it] != 0xFFFFFFFFu) {
+          char* d = Bb + sdst[it];
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + 2 * PP * 16) = L;
+        }
+      } else {
+        split8(x, H, Mi, L);
+        if (sdst[it] != 0xFFFFFFFFu) {
+          char* d = Bb + sdst[it];
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + 2 * PP * 16) = Mi;
+          *reinterpret_cast<uint4*>(d + 4 * PP * 16) = L;
+        }
       }
     }
   };
@@ -409,32 +491,35 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   // wave: every group of reads is issued one or two products before its first use, the (h,h) product of a stage is carried
   // over the barrier into the next stage -- it needs registers only -- where it covers the first reads of the new stage and the
   // issue of the A-ring DMA.  Ten fragments are live at most (as in the compiler's own schedule).
-  auto readA = [&](const char* Ab, int pl, bf16x8 (&f)[2]) {
+  auto readA = [&](const char* Ab, int pl, frag_t (&f)[2]) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) f[mt] = *reinterpret_cast<const bf16x8*>(Ab + aoff + (pl * 2 * BMK + mt * 32) * 16);
+    for (int mt = 0; mt < 2; ++mt) f[mt] = *reinterpret_cast<const frag_t*>(Ab + aoff + (pl * 2 * BMK + mt * 32) * 16);
   };
-  auto readB = [&](const char* Bb, int tapoff, int pl, bf16x8 (&f)[NTW]) {
+  auto readB = [&](const char* Bb, int tapoff, int pl, frag_t (&f)[NTW]) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) f[nt] = *reinterpret_cast<const bf16x8*>(Bb + boff[nt] + tapoff + pl * 2 * PP * 16);
+    for (int nt = 0; nt < NTW; ++nt) f[nt] = *reinterpret_cast<const frag_t*>(Bb + boff[nt] + tapoff + pl * 2 * PP * 16);
   };
-  auto mm = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NTW]) {
+  auto mm = [&](const frag_t (&a)[2], const frag_t (&b)[NTW]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < NTW; ++nt) {
+        if constexpr (NP == 2) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
   };
 #define CX_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   const int nC = cend - cbeg;
-  bf16x8 pAH[2], pBH[NTW];   // the (h,h) operands of the previous stage (zeros before the first: the product adds nothing)
+  frag_t pAH[2], pBH[NTW];   // the (h,h) operands of the previous stage (zeros before the first: the product adds nothing)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pAH[i][j] = (__bf16)0.f;
+    for (int j = 0; j < 8; ++j) pAH[i][j] = 0;
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pBH[i][j] = (__bf16)0.f;
+    for (int j = 0; j < 8; ++j) pBH[i][j] = 0;
 
   // Three blocks per CU (44 KB of LDS, <= 168 registers): A ring of two stages -- stage s+1 is requested behind the barrier
   // of stage s, into the slot stage s-1 was read from -- and ONE patch buffer: at a chunk boundary every wave has passed
@@ -457,7 +542,8 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
       const int ky = tap / KS, kx = tap - ky * KS;
       const char* const Ab = As + ((tap + par) & 1) * AST;
       const int tapoff = (ky * PW + kx) * 16;
-      bf16x8 aL[2], aM[2], aH[2], bL[NTW], bM[NTW], bH[NTW];
+      frag_t aL[2], aM[2], aH[2], bL[NTW], bM[NTW], bH[NTW];
+      constexpr int PL = NP - 1;   // plane index of the smallest part
       // stage's A image (requested one stage ago) has landed in every wave's part; right after a chunk's first tap the
       // patch loads issued behind it may still be in flight
       if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NIT) : "memory");
@@ -476,28 +562,32 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         __syncthreads();
         more = chunk + 1 < cend;
         if (more) load_patch(chunk + 1);
-        readA(Ab, 2, aL); readB(Bs, tapoff, 0, bH);
-        readA(Ab, 0, aH); readB(Bs, tapoff, 2, bL);
+        readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
+        readA(Ab, 0, aH); readB(Bs, tapoff, PL, bL);
       } else {
-        readA(Ab, 2, aL); readB(Bs, tapoff, 0, bH);
+        readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
         CX_FENCE();
         mm(pAH, pBH);
         CX_FENCE();
-        readA(Ab, 0, aH); readB(Bs, tapoff, 2, bL);
+        readA(Ab, 0, aH); readB(Bs, tapoff, PL, bL);
         dma_stage(nxt, (tap + 1 + par) & 1);
       }
       CX_FENCE();
       mm(aL, bH);
       CX_FENCE();
-      readA(Ab, 1, aM);
-      CX_FENCE();
-      mm(aH, bL);
-      CX_FENCE();
-      readB(Bs, tapoff, 1, bM);
-      CX_FENCE();
-      mm(aM, bH);
-      mm(aM, bM);
-      mm(aH, bM);
+      if constexpr (NP == 2) {
+        mm(aH, bL);
+      } else {
+        readA(Ab, 1, aM);
+        CX_FENCE();
+        mm(aH, bL);
+        CX_FENCE();
+        readB(Bs, tapoff, 1, bM);
+        CX_FENCE();
+        mm(aM, bH);
+        mm(aM, bM);
+        mm(aH, bM);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) pAH[i] = aH[i];
 #pragma unroll
@@ -507,6 +597,14 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   mm(pAH, pBH);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the idle slot's last request)
 #undef CX_FENCE
+  if (NP == 2) {   // undo the two tensors' scales
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NTW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] *= out_mul;
+  }
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter).  Every filter row of the
   // block exists (M is a multiple of the block's filter count), so only the pixel is predicated.  The 32 bias values of the
@@ -773,11 +871,11 @@ static void x3_choose_tile(int Ho, int Wo, int k, int* TH, int* TW) {
   *TH = bth; *TW = btw;
 }
 
-template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0>
+template <int KS, int WM, bool SLOPE, bool SCALE, int EPI = 0, int NP = 3>
 static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>),
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI, NP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -792,8 +890,8 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   // (the wide epilogue turns four 64 x 32 fp32 tiles over in LDS: 32 KB)
   static const size_t lds_min = getenv("FRCNN_X3_LDS_MIN") ? (size_t)atol(getenv("FRCNN_X3_LDS_MIN")) : 0;   // (experiments: fewer blocks per CU)
-  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (6 * 64 * WM * 16) + (size_t)CX_NB * (6 * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
-  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI>), dim3(grid), dim3(256), lds, a);
+  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (2 * NP * 64 * WM * 16) + (size_t)CX_NB * (2 * NP * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
+  FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI, NP>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
 #ifdef CX_TRACE
   if (a.trace) {   // the last launch's stamps, one line per block
@@ -815,12 +913,15 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot,
-            const X3PostAct* post) {
+            const X3PostAct* post, const float* amax_in, const float* amax_w) {
   FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % 64 == 0,
            "conv_x3: %d channels -> %d filters, %dx%d is not a split-bf16 shape", Cin, M, k, k);
   FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
   CxArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
+  a.amax_in = amax_in; a.amax_w = amax_w;
+  const bool f16 = amax_in != nullptr;
+  FR_CHECK(!f16 || (k == 3 && amax_w), "conv_x3: the two-plane fp16 form is a 3x3 form and needs both magnitudes");
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
@@ -857,7 +958,15 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
-  if (post && a.splitK == 1) {   // (with a K split the fold below applies it)
+  if (f16) {
+    FR_CHECK(act == 0 || act == 3, "conv_x3: the fp16 form is built for no input activation or slope + scale");
+    if (post && a.splitK == 1)
+      rc = bm == 128 ? launch_x3<3, 2, false, false, 1, 2>(a, algo_flops, s) : launch_x3<3, 1, false, false, 1, 2>(a, algo_flops, s);
+    else if (bm == 128)
+      rc = act == 3 ? launch_x3<3, 2, true, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 2, false, false, 0, 2>(a, algo_flops, s);
+    else
+      rc = act == 3 ? launch_x3<3, 1, true, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 1, false, false, 0, 2>(a, algo_flops, s);
+  } else if (post && a.splitK == 1) {   // (with a K split the fold below applies it)
     rc = bm == 128 ? launch_x3<3, 2, false, false, 1>(a, algo_flops, s) : launch_x3<3, 1, false, false, 1>(a, algo_flops, s);
   } else if (k == 3 && bm == 128) {
     rc = act == 3 ? launch_x3<3, 2, true, true>(a, algo_flops, s) : act == 2 ? launch_x3<3, 2, true, false>(a, algo_flops, s)

@@ -41,14 +41,15 @@ void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 
 int get_split_bf16();
 bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)
 size_t conv_x3_pack_bytes(int Kchan, int M, int k);
-struct PackXJob { long w_off; long total; void* dst; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
+struct PackXJob { long w_off; long total; void* dst; const float* amax; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
 PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, int Ho, int Wo);   // Ho x Wo: output map of the launch it feeds
 int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo);
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo, const float* amax_w = nullptr);
+int tensor_absmax(const float* x, long n, float* out, hipStream_t s);   // *out = largest magnitude (device scalar)
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0,
-            const struct X3PostAct* post = nullptr);
+            const struct X3PostAct* post = nullptr, const float* amax_in = nullptr, const float* amax_w = nullptr);
 // Backward of the PReLU + SpatialDropout the OUTPUT gradient of an input-gradient launch passes through next, fused into the
 // launch's epilogue (or into the fold of its split-K slabs): out = prelu'(x) * scale[m] * (conv result), *gslope += sum over
 // x <= 0 of x * scale[m] * (conv result).  What act_backward (elem.hip) does in a pass of its own, minus the bias sums,
