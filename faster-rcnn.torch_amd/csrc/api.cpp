@@ -197,13 +197,12 @@ int frcnn_nms_host(const float* boxes_host, int n, int ncols, float overlap, int
 
 // ---------------------------------------------------------------- conv (operator-level, for parity tests
 // and hosts that drive single layers; the model runtime keeps packed weights resident instead)
-// FRCNN_X3_F16=1 (experiment): the op-level 3x3 convolutions take the two-plane fp16 form of convx.hip; two device scalars hold
-// the largest magnitudes of the input and the weight tensor
-static float* x3_f16_scalars(int k) {
-  static const int on = getenv("FRCNN_X3_F16") ? atoi(getenv("FRCNN_X3_F16")) : 0;
+// option x3_f16: the op-level split convolutions take the two-plane fp16 form of convx.hip; two magnitude records (amax.h:
+// input and weight tensor) and the scalar the pack publishes
+static float* x3_f16_scalars(int) {
   static float* buf = nullptr;
-  if (!on || k != 3) return nullptr;
-  if (!buf && hipMalloc((void**)&buf, 16) != hipSuccess) return nullptr;
+  if (!get_x3_f16()) return nullptr;
+  if (!buf && hipMalloc((void**)&buf, (size_t)(2 * AMAX_REC + 4) * 4) != hipSuccess) return nullptr;
   return buf;
 }
 
@@ -215,12 +214,14 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
     FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
     float* am = x3_f16_scalars(k);   // (experimental two-plane fp16 form: FRCNN_X3_F16=1)
     int rcx = FRCNN_OK;
+    float* const amw = am ? am + AMAX_REC : nullptr;          // the weights' record
+    float* const aws = am ? am + 2 * AMAX_REC : nullptr;      // their largest magnitude
     if (am) {
       rcx = tensor_absmax(in, (long)C * H * W, am, S(stream));
-      if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, am + 1, S(stream));
+      if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, amw, S(stream));
     }
-    if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream), H + 2 * pad - k + 1, W + 2 * pad - k + 1, am ? am + 1 : nullptr);
-    if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream), 0, nullptr, am, am ? am + 1 : nullptr);
+    if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream), H + 2 * pad - k + 1, W + 2 * pad - k + 1, amw, aws);
+    if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream), 0, nullptr, am, aws);
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wf);
     return rcx;
@@ -239,12 +240,14 @@ int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const 
     FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C, k)));
     float* am = x3_f16_scalars(k);
     int rcx = FRCNN_OK;
+    float* const amw = am ? am + AMAX_REC : nullptr;
+    float* const aws = am ? am + 2 * AMAX_REC : nullptr;
     if (am) {
       rcx = tensor_absmax(gout, (long)O * Ho * Wo, am, S(stream));
-      if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, am + 1, S(stream));
+      if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, amw, S(stream));
     }
-    if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream), Ho + 2 * (k - 1 - pad) - k + 1, Wo + 2 * (k - 1 - pad) - k + 1, am ? am + 1 : nullptr);
-    if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream), 0, nullptr, am, am ? am + 1 : nullptr);
+    if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream), Ho + 2 * (k - 1 - pad) - k + 1, Wo + 2 * (k - 1 - pad) - k + 1, amw, aws);
+    if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream), 0, nullptr, am, aws);
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(wd);
     return rcx;

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "amax.h"
 #include <type_traits>
 #ifdef CX_TRACE
 #include <cstdio>
@@ -53,6 +54,13 @@ void set_split_bf16(int on) { g_splitbf16 = on ? 1 : 0; }
 int get_split_bf16() {
   if (g_splitbf16 < 0) g_splitbf16 = getenv("FRCNN_SPLIT_BF16") ? (atoi(getenv("FRCNN_SPLIT_BF16")) != 0) : 1;
   return g_splitbf16;
+}
+
+static int g_x3_f16 = -1;   // option "x3_f16" (environment FRCNN_X3_F16): the split launches take the two-plane fp16 form
+void set_x3_f16(int on) { g_x3_f16 = on ? 1 : 0; }
+int get_x3_f16() {
+  if (g_x3_f16 < 0) g_x3_f16 = getenv("FRCNN_X3_F16") ? (atoi(getenv("FRCNN_X3_F16")) != 0) : 0;
+  return g_x3_f16;
 }
 
 bool conv_x3_eligible(int Cin, int M, int k) {
@@ -130,18 +138,60 @@ __device__ __forceinline__ int x16_exp(float amax, int top) {
 }
 __device__ __forceinline__ float x16_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
 
-// largest magnitude of a tensor, as the bit pattern of a non-negative float (atomicMax on the unsigned image)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+// largest magnitude of a tensor in a pass of its own (operator-level calls, and the tensors whose producer keeps no record)
+__device__ __forceinline__ float absmax_span(const float* __restrict__ x, long n, long first, long stride) {
   float m = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    for (long i = first; i < n / 4; i += stride) {
+      const float4 v = x4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long i = (n / 4) * 4 + first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  } else {
+    for (long i = first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  }
+  return m;
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ rec) {
+  amax_store_block(absmax_span(x, n, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x), rec);
+}
+// one launch for several segments of the flat parameter vector (the weight tensors of the split launches), AMAX_SPAN floats
+// per block; segment j's record is jobs[j].out
+#define AMAX_SPAN 8192
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const float* __restrict__ w, const AmaxJob* __restrict__ jobs, int njobs) {
+  __shared__ float part[4];
+  int jb = 0;
+  while (jb + 1 < njobs && (int)blockIdx.x >= jobs[jb + 1].blk_begin) ++jb;
+  const AmaxJob j = jobs[jb];
+  const int blk = blockIdx.x - j.blk_begin;
+  const long first = (long)blk * AMAX_SPAN;        // this block's span of the segment
+  const long n = j.n - first < AMAX_SPAN ? j.n - first : AMAX_SPAN;
+  float m = absmax_span(w + j.off + first, n, threadIdx.x, blockDim.x);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    j.out[1 + blk] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (blk == 0) j.out[0] = __builtin_bit_cast(float, (int)((j.n + AMAX_SPAN - 1) / AMAX_SPAN));
+  }
 }
-int tensor_absmax(const float* x, long n, float* out, hipStream_t s) {
-  FR_HIP(hipMemsetAsync(out, 0, 4, s));
-  if (n <= 0) return FRCNN_OK;
-  FR_LAUNCH(KC_ELEMWISE, 0, n * 4.0, s, absmax_kernel, dim3((int)std::min<long>(cdivl(n, 256), 2048)), dim3(256), 0, x, n, (unsigned*)out);
+int tensor_absmax_assign_blocks(AmaxJob* jobs, int njobs) {
+  int b = 0;
+  for (int i = 0; i < njobs; ++i) { jobs[i].blk_begin = b; b += (int)cdivl(jobs[i].n, AMAX_SPAN); }
+  return b;
+}
+long tensor_absmax_record_floats(long n) { return 1 + cdivl(n, AMAX_SPAN); }
+int tensor_absmax_multi(const float* w, const AmaxJob* jobs_dev, int njobs, int grid, hipStream_t s) {
+  if (njobs <= 0 || grid <= 0) return FRCNN_OK;
+  FR_LAUNCH(KC_ELEMWISE, 0, 0, s, absmax_multi_kernel, dim3(grid), dim3(256), 0, w, jobs_dev, njobs);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+int tensor_absmax(const float* x, long n, float* rec, hipStream_t s) {
+  const int grid = (int)std::max<long>(1, std::min<long>(cdivl(n, 1024), 1024));
+  FR_LAUNCH(KC_ELEMWISE, 0, n * 4.0, s, absmax_kernel, dim3(grid), dim3(256), 0, x, n, rec);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -164,7 +214,12 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
   const float* __restrict__ w = weights + j.w_off;
   const int M = j.mode == 0 ? j.O : j.C, KC = j.mode == 0 ? j.C : j.O;
   const int BM = j.bm, AST = 2 * NP * BM * 16;
-  const float wmul = NP == 2 ? x16_pow2(x16_exp(*j.amax, 14)) : 1.f;
+  float wmul = 1.f;
+  if (NP == 2) {   // the weight tensor's largest magnitude: from the record of the absmax launch; published as a scalar for the convolution
+    const float wa = amax_load_block(j.amax);
+    wmul = x16_pow2(x16_exp(wa, 14));
+    if (blk == 0 && threadIdx.x == 0 && j.amax_w) *j.amax_w = wa;
+  }
   const int nCh = KC / CX_CH, pairs = (M / BM) * nCh;
   const int tid = threadIdx.x;
   const int groups = BM / ROWS;   // work unit = ROWS filter rows of one pair: equal units, one per block (conv_x3_pack_assign_blocks)
@@ -216,7 +271,9 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
 __device__ __forceinline__ void pack_x3_job(const float* __restrict__ weights, const PackXJob& j, int blk, int nblk, float* tile) {
   if (j.k == 3 && j.amax) pack_x_job<3, 64, 2>(weights, j, blk, nblk, tile);
   else if (j.k == 3) pack_x_job<3, 64>(weights, j, blk, nblk, tile);
+  else if (j.k == 5 && j.amax) pack_x_job<5, 16, 2>(weights, j, blk, nblk, tile);
   else if (j.k == 5) pack_x_job<5, 16>(weights, j, blk, nblk, tile);
+  else if (j.amax) pack_x_job<7, 8, 2>(weights, j, blk, nblk, tile);
   else pack_x_job<7, 8>(weights, j, blk, nblk, tile);
 }
 
@@ -240,7 +297,7 @@ PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, 
   j.bm = conv_x3_bm(mode == 0 ? O : C, Ho, Wo, k);
   j.total = (long)O * C * k * k;
   j.blk_begin = 0; j.nblk = 1;
-  j.amax = nullptr;
+  j.amax = nullptr; j.amax_w = nullptr;
   return j;
 }
 
@@ -264,9 +321,10 @@ int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs
 }
 
 // one pack by itself (op-level entry points and tests)
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo, const float* amax_w) {
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo, const float* amax_rec_w, float* amax_w) {
   PackXJob j = conv_x3_pack_job(0, O, C, k, mode, dst, Ho, Wo);
-  j.amax = amax_w;   // non-null: the two-plane fp16 form, scaled by the weight tensor's largest magnitude
+  j.amax = amax_rec_w;   // non-null: the two-plane fp16 form, scaled by the weight tensor's largest magnitude (its record, amax.h)
+  j.amax_w = amax_w;     // ... which the pack publishes as a scalar here
   int grid = conv_x3_pack_assign_blocks(&j, 1);
   FR_LAUNCH(KC_ELEMWISE, 0, 0, s, pack_x3_kernel, dim3(grid), dim3(256), 0, w, j);
   FR_LAUNCH_CHECK();
@@ -288,8 +346,9 @@ struct CxArgs {
 #ifdef CX_TRACE
   unsigned long long* trace;   // [block][64] timestamps (s_memrealtime, 100 MHz) -- tools/x3_trace.py
 #endif
-  const float* amax_in;   // NP = 2 only: largest magnitude of the input tensor / of the weight tensor (device scalars)
+  const float* amax_in;   // NP = 2 only: the input tensor's magnitude record (amax.h) and the weight tensor's largest magnitude (a scalar, from the pack)
   const float* amax_w;
+  float* amax_out;        // non-null (storing launches): the record of what is stored (amax.h)
   int wide;               // 1: the epilogue goes through LDS and stores 16 bytes per lane (Wo % 4 == 0, TW % 4 == 0, aligned tensors)
   X3PostAct post;         // EPI = 1 only: the activation backward applied to the stored tile (kernels.h)
 };
@@ -367,7 +426,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   const float slope = SLOPE ? *p.in_slope : 1.f;
   float in_mul = 1.f, out_mul = 1.f;
   if (NP == 2) {   // (headroom of one binade for a dropout scale: its entries are <= 1 in both modes, see net.cpp)
-    float ai = *p.amax_in;
+    float ai = amax_load_block(p.amax_in);
     if (SLOPE) ai *= fmaxf(1.f, fabsf(slope));
     const int ei = x16_exp(ai, SCALE ? 13 : 14), ew = x16_exp(*p.amax_w, 14);
     in_mul = x16_pow2(ei);
@@ -629,7 +688,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
     float* const T = reinterpret_cast<float*>(smem) + wave * (64 * 32);
     const int rr = lane >> 3, pg = lane & 7;
     const float pa = EPI == 1 ? *p.post.slope : 0.f;
-    float sa = 0.f;
+    float sa = 0.f, am = 0.f;
     float* const obase = p.out + (p.out_mode == 3 ? (size_t)split * p.M * HoWo : (size_t)0);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
@@ -677,10 +736,12 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
               if (p.out_mode == 1) { w.x += o[i].x; w.y += o[i].y; w.z += o[i].z; w.w += o[i].w; }
             }
             *reinterpret_cast<float4*>(obase + off) = w;
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
           }
         }
       }
     }
+    if (p.amax_out) amax_store_block(am, p.amax_out);
     if (EPI == 1) {
 #pragma unroll
       for (int o2 = 32; o2 > 0; o2 >>= 1) sa += __shfl_xor(sa, o2);
@@ -698,6 +759,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) bv[mt][r] = add_bias ? p.bias[mrow0 + mt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
+  float am = 0.f;
   auto store_tile = [&](auto mode_c) {
     constexpr int OM = decltype(mode_c)::value;
 #pragma unroll
@@ -719,7 +781,9 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float val = acc[mt][nt][r] + bv[mt][r];
-            row[(size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = OM == 1 ? old[r] + val : val;
+            const float st = OM == 1 ? old[r] + val : val;
+            row[(size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = st;
+            am = fmaxf(am, fabsf(st));
           }
         }
       }
@@ -750,7 +814,9 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
             const float g = acc[mt][nt][r] * sc[r];
             const bool pos = xv[r] > 0.f;
             if (!pos) sa += xv[r] * g;
-            p.out[rowo + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = pos ? g : pa * g;
+            const float st = pos ? g : pa * g;
+            p.out[rowo + (size_t)((r & 3) + 8 * (r >> 2)) * HoWo] = st;
+            am = fmaxf(am, fabsf(st));
           }
         }
       }
@@ -758,11 +824,13 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o);
     if (lane == 0 && p.post.gslope) unsafeAtomicAdd(p.post.gslope, sa);
+    if (p.amax_out) amax_store_block(am, p.amax_out);
     return;
   }
   if (p.out_mode == 0) store_tile(std::integral_constant<int, 0>{});
   else if (p.out_mode == 1) store_tile(std::integral_constant<int, 1>{});
   else store_tile(std::integral_constant<int, 3>{});
+  if (p.amax_out) amax_store_block(am, p.amax_out);
 #ifdef CX_TRACE
   stamp(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -777,11 +845,11 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
 template <int VEC>
 __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __restrict__ slab, int nSplit, int M, long hw,
                                                                const float* __restrict__ bias, float* __restrict__ out, int accumulate,
-                                                               X3PostAct post) {
+                                                               X3PostAct post, float* amax) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const long total = (long)M * hw, nvec = total / VEC;
   const float pa = post.x ? *post.slope : 1.f;
-  float sa = 0.f;
+  float sa = 0.f, am = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
     const long t = i * VEC;
     const float b = bias ? bias[t / hw] : 0.f;   // (VEC divides hw: the vector stays inside one filter's map)
@@ -812,8 +880,12 @@ __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(const float* __re
         v[j] = pos ? g : pa * g;
       }
     }
-    if (accumulate) *o += v; else *o = v;
+    if (accumulate) v += *o;
+    *o = v;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) am = fmaxf(am, fabsf(v[j]));
   }
+  if (amax) amax_store_block(am, amax);
   if (post.x && post.gslope) {
     __shared__ float part[4];
 #pragma unroll
@@ -876,7 +948,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI, NP>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // (the kernel also has a few static words: amax.h)
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
@@ -913,15 +985,15 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
 
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot,
-            const X3PostAct* post, const float* amax_in, const float* amax_w) {
+            const X3PostAct* post, const float* amax_in, const float* amax_w, float* amax_out) {
   FR_CHECK((k == 3 || k == 5 || k == 7) && Cin % CX_CH == 0 && M % 64 == 0,
            "conv_x3: %d channels -> %d filters, %dx%d is not a split-bf16 shape", Cin, M, k, k);
   FR_CHECK((double)Cin * H * W * 4.0 < 4294967295.0, "conv_x3: input tensor too large for 32-bit offsets");
   CxArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
-  a.amax_in = amax_in; a.amax_w = amax_w;
+  a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   const bool f16 = amax_in != nullptr;
-  FR_CHECK(!f16 || (k == 3 && amax_w), "conv_x3: the two-plane fp16 form is a 3x3 form and needs both magnitudes");
+  FR_CHECK(!f16 || amax_w, "conv_x3: the two-plane fp16 form needs the magnitudes of both tensors");
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(a.Ho > 0 && a.Wo > 0, "conv_x3: empty output (%dx%d, k=%d, pad=%d)", H, W, k, pad);
@@ -952,20 +1024,25 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     float* ws = nullptr;
     FR_TRY(x3_workspace((size_t)a.splitK * M * a.Ho * a.Wo * 4, &ws, ws_slot & 7));
     a.out = ws; a.out_mode = 3; a.bias = nullptr; slab = true;
+    a.amax_out = nullptr;   // (the fold sees the final values)
   }
   a.wide = x3_wide_enabled() && a.Wo % 4 == 0 && a.TW % 4 == 0 && ((uintptr_t)a.out & 15) == 0 &&
            (!post || ((uintptr_t)post->x & 15) == 0);
   if (algo_flops <= 0) algo_flops = 2.0 * M * Cin * k * k * (double)a.Ho * a.Wo;
   int rc;
   const int act = (in_slope ? 2 : 0) | (in_scale ? 1 : 0);
-  if (f16) {
-    FR_CHECK(act == 0 || act == 3, "conv_x3: the fp16 form is built for no input activation or slope + scale");
+  if (f16 && k != 3) {
+    FR_CHECK(act == 0 && bm == 128, "conv_x3: a %dx%d launch takes no fused input activation and 128-filter blocks", k, k);
+    rc = k == 5 ? launch_x3<5, 2, false, false, 0, 2>(a, algo_flops, s) : launch_x3<7, 2, false, false, 0, 2>(a, algo_flops, s);
+  } else if (f16) {
     if (post && a.splitK == 1)
       rc = bm == 128 ? launch_x3<3, 2, false, false, 1, 2>(a, algo_flops, s) : launch_x3<3, 1, false, false, 1, 2>(a, algo_flops, s);
     else if (bm == 128)
-      rc = act == 3 ? launch_x3<3, 2, true, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 2, false, false, 0, 2>(a, algo_flops, s);
+      rc = act == 3 ? launch_x3<3, 2, true, true, 0, 2>(a, algo_flops, s) : act == 2 ? launch_x3<3, 2, true, false, 0, 2>(a, algo_flops, s)
+         : act == 1 ? launch_x3<3, 2, false, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 2, false, false, 0, 2>(a, algo_flops, s);
     else
-      rc = act == 3 ? launch_x3<3, 1, true, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 1, false, false, 0, 2>(a, algo_flops, s);
+      rc = act == 3 ? launch_x3<3, 1, true, true, 0, 2>(a, algo_flops, s) : act == 2 ? launch_x3<3, 1, true, false, 0, 2>(a, algo_flops, s)
+         : act == 1 ? launch_x3<3, 1, false, true, 0, 2>(a, algo_flops, s) : launch_x3<3, 1, false, false, 0, 2>(a, algo_flops, s);
   } else if (post && a.splitK == 1) {   // (with a K split the fold below applies it)
     rc = bm == 128 ? launch_x3<3, 2, false, false, 1>(a, algo_flops, s) : launch_x3<3, 1, false, false, 1>(a, algo_flops, s);
   } else if (k == 3 && bm == 128) {
@@ -989,13 +1066,13 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     grid = (int)std::min<long>(cdivl(total / vec, 256), 4096);
     if (vec == 4)
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<4>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa, amax_out);
     else if (vec == 2)
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<2>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa, amax_out);
     else
       FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (a.splitK + 1), s, x3_splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0,
-                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa);
+                (const float*)a.out, a.splitK, M, hw, bias, out, out_mode == OUT_ADD ? 1 : 0, pa, amax_out);
     FR_LAUNCH_CHECK();
   }
   return FRCNN_OK;

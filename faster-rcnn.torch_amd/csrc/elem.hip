@@ -10,6 +10,7 @@
 #include <unordered_map>
 
 #include "kernels.h"
+#include "amax.h"
 
 namespace frcnn {
 
@@ -132,9 +133,10 @@ int act_forward(const float* x, int C, long hw, const float* slope, const float*
 // 8-byte-per-lane strided reads (coalesced across the wave).
 __global__ void maxpool_act_forward_kernel(const float* __restrict__ x, int C, int H, int W, int Ho,
                                            int Wo, const float* slope, const float* scale,
-                                           float* __restrict__ out, unsigned char* __restrict__ idx) {
+                                           float* __restrict__ out, unsigned char* __restrict__ idx, float* amax) {
   const float a = slope ? *slope : 1.f;
   long total = (long)C * Ho * Wo;
+  float am = 0.f;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     int ox = (int)(t % Wo);
     long r = t / Wo;
@@ -161,15 +163,17 @@ __global__ void maxpool_act_forward_kernel(const float* __restrict__ x, int C, i
     }
     out[t] = best;
     idx[t] = (unsigned char)bi;
+    am = fmaxf(am, fabsf(best));
   }
+  if (amax) amax_store_block(am, amax);
 }
 int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope, const float* scale,
-                        float* out, unsigned char* idx, hipStream_t s) {
+                        float* out, unsigned char* idx, hipStream_t s, float* amax) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;  // ceil((n-2)/2)+1
   long total = (long)C * Ho * Wo;
   int grid = (int)std::min<long>(std::max<long>(1, cdivl(total, 256)), 4096);
   FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 4.0 + total * 5.0, s, maxpool_act_forward_kernel, dim3(grid),
-            dim3(256), 0, x, C, H, W, Ho, Wo, slope, scale, out, idx);
+            dim3(256), 0, x, C, H, W, Ho, Wo, slope, scale, out, idx, amax);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -188,9 +192,10 @@ template <bool POOLED, bool VEC>
 __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const float* __restrict__ gin, const unsigned char* __restrict__ idx,
                                     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo,
                                     const float* slope, const float* scale, float* __restrict__ gx,
-                                    float* gbias, float* gslope, int chunks, float* part_b, float* part_a) {
+                                    float* gbias, float* gslope, int chunks, float* part_b, float* part_a, float* amax) {
   __shared__ float sh[16];
   __shared__ double shd[16];
+  float am = 0.f;   // largest magnitude written (amax.h)
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long hw = (long)H * W;
   long per = cdivl(hw, chunks);
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
         r[j] = gj;
         if (has_slope && !(xv[j] > 0.f)) { r[j] = a * gj; sa += (double)xv[j] * (double)gj; }
         sb += r[j];
+        am = fmaxf(am, fabsf(r[j]));
       }
       *reinterpret_cast<float4*>(oc + i) = make_float4(r[0], r[1], r[2], r[3]);
     };
@@ -270,8 +276,10 @@ __global__ __launch_bounds__(ACT_BWD_THREADS) void act_backward_kernel(const flo
       }
       gx[(size_t)c * hw + i] = r;
       sb += r;
+      am = fmaxf(am, fabsf(r));
     }
   }
+  if (amax) amax_store_block(am, amax);
   float tb = block_sum(sb, sh);
   if (part_b) {   // deterministic mode: partials to scratch, folded in index order by fold_partials_kernel
     if (threadIdx.x == 0) part_b[blockIdx.x] = tb;
@@ -340,7 +348,7 @@ static int act_bwd_chunks(int C, long hw) {
 
 int maxpool_act_backward(const float* gpool, const unsigned char* idx, const float* x, int C, int H,
                          int W, const float* slope, const float* scale, float* gx, float* gbias,
-                         float* gslope, hipStream_t s) {
+                         float* gslope, hipStream_t s, float* amax) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
   int chunks = act_bwd_chunks(C, (long)H * W);
   float *pb = nullptr, *pa = nullptr;
@@ -349,17 +357,17 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                    ((uintptr_t)idx % 2 == 0);
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, true>), dim3(C * chunks),
-              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa, amax);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * H * W * 9.25, s, (act_backward_kernel<true, false>), dim3(C * chunks),
-              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa);
+              dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa, amax);
   FR_LAUNCH_CHECK();
   if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
   return FRCNN_OK;
 }
 
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
-                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s) {
+                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s, float* amax) {
   int chunks = act_bwd_chunks(C, hw);
   float *pb = nullptr, *pa = nullptr;
   if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
@@ -367,11 +375,11 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
   if (vec)
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, true>), dim3(C * chunks),
               dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
-              gbias, gslope, chunks, pb, pa);
+              gbias, gslope, chunks, pb, pa, amax);
   else
     FR_LAUNCH(KC_ELEMWISE, 0, (double)C * hw * 12.0, s, (act_backward_kernel<false, false>), dim3(C * chunks),
               dim3(ACT_BWD_THREADS), 0, gy, (const unsigned char*)nullptr, x, C, 1, (int)hw, 1, 1, slope, scale, gx,
-              gbias, gslope, chunks, pb, pa);
+              gbias, gslope, chunks, pb, pa, amax);
   FR_LAUNCH_CHECK();
   if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
   return FRCNN_OK;

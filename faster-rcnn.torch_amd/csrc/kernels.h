@@ -41,15 +41,25 @@ void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 
 int get_split_bf16();
 bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)
 size_t conv_x3_pack_bytes(int Kchan, int M, int k);
-struct PackXJob { long w_off; long total; void* dst; const float* amax; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
+struct PackXJob { long w_off; long total; void* dst; const float* amax; float* amax_w; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
 PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, int Ho, int Wo);   // Ho x Wo: output map of the launch it feeds
 int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
-int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo, const float* amax_w = nullptr);
-int tensor_absmax(const float* x, long n, float* out, hipStream_t s);   // *out = largest magnitude (device scalar)
+int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipStream_t s, int Ho, int Wo,
+                 const float* amax_rec_w = nullptr, float* amax_w = nullptr);   // fp16 form: the weights' magnitude record in, their largest magnitude out
+// Magnitude records (amax.h): rec = AMAX_REC floats of device memory per tensor.
+#define AMAX_REC 16400   // floats per record: the count + one entry per block of the producing launch (up to 16 384) + pad
+int tensor_absmax(const float* x, long n, float* rec, hipStream_t s);   // a pass of its own over a tensor
+struct AmaxJob { long off; long n; float* out; int blk_begin; };   // a segment of the flat parameter vector and its record
+int tensor_absmax_assign_blocks(AmaxJob* jobs, int njobs);   // -> grid size
+long tensor_absmax_record_floats(long n);                     // floats of a segment's record
+int tensor_absmax_multi(const float* w, const AmaxJob* jobs_dev, int njobs, int grid, hipStream_t s);
+void set_x3_f16(int on);   // option "x3_f16": the split launches take the two-plane fp16 form (three partial products) instead of three bf16 planes (six)
+int get_x3_f16();
 int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const void* wp,
             const float* bias, int M, int k, int pad, float* out, int out_mode, double algo_flops, hipStream_t s, int ws_slot = 0,
-            const struct X3PostAct* post = nullptr, const float* amax_in = nullptr, const float* amax_w = nullptr);
+            const struct X3PostAct* post = nullptr, const float* amax_in = nullptr, const float* amax_w = nullptr,
+            float* amax_out = nullptr);   // amax_in / amax_w: the two-plane fp16 form; amax_out: magnitude of what is stored (amax.h)
 // Backward of the PReLU + SpatialDropout the OUTPUT gradient of an input-gradient launch passes through next, fused into the
 // launch's epilogue (or into the fold of its split-K slabs): out = prelu'(x) * scale[m] * (conv result), *gslope += sum over
 // x <= 0 of x * scale[m] * (conv result).  What act_backward (elem.hip) does in a pass of its own, minus the bias sums,
@@ -101,14 +111,14 @@ int act_forward(const float* x, int C, long hw, const float* slope, const float*
                 hipStream_t s);
 // 2x2 stride-2 ceil-mode max pool of act(x); idx = argmax code 0..3 (dy*2+dx), first max wins
 int maxpool_act_forward(const float* x, int C, int H, int W, const float* slope, const float* scale,
-                        float* out, unsigned char* idx, hipStream_t s);
+                        float* out, unsigned char* idx, hipStream_t s, float* amax = nullptr);   // amax: see amax.h
 // gx = route(gpool, idx) * scale[c] * prelu'(x);  gbias[c] += sum gx;  *gslope += sum_{x<=0} x*gy*scale
 int maxpool_act_backward(const float* gpool, const unsigned char* idx, const float* x, int C, int H,
                          int W, const float* slope, const float* scale, float* gx, float* gbias,
-                         float* gslope, hipStream_t s);
+                         float* gslope, hipStream_t s, float* amax = nullptr);
 // gx = gy * scale[c] * prelu'(x) (in place allowed); gbias[c] += sum gx; *gslope += ...
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
-                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s);
+                 const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s, float* amax = nullptr);
 // gbias[c] += sum_hw g[c][hw]
 int channel_sum(const float* g, int C, long hw, float* gbias, hipStream_t s);
 // gb[o] += sum_r g[r][o] for a row-major R x O matrix

@@ -49,6 +49,7 @@ struct Conv {
   DevBuf wx, wxd;             // split-bf16 operand stages (convx.hip) for the launches that take that form
   bool x_f = false, x_d = false;
   DevBuf x, gx;               // pre-activation output and its gradient
+  int am = -1;                // first of this convolution's three magnitude records in frcnn_model::amax: |x| (its output), |gx|, |w|
 };
 
 struct Block {
@@ -59,6 +60,7 @@ struct Block {
   DevBuf pooled, gpooled;
   DevBuf pidx;
   int Hp, Wp;
+  int am = -1;                // magnitude record of `pooled`
 };
 
 struct Head {
@@ -104,6 +106,14 @@ struct frcnn_model {
   size_t delta_bytes = 0, gpool_bytes = 0;
   DevBuf pack_jobs;            // device table of PackJob (fwd packs first, then dgrad packs)
   DevBuf x3_jobs;              // device table of PackXJob, same arrangement
+  // Two-plane fp16 form of the split launches (option x3_f16): every tensor such a launch reads is scaled by a power of two that
+  // puts its largest magnitude just below the end of the fp16 range, so the magnitudes travel with the tensors -- one record
+  // (amax.h: a maximum per block of the launch that wrote the tensor) per convolution output, output gradient, weight tensor and
+  // pooled map; amax_ws[c.am] = the weight tensor's largest magnitude as a scalar (published by the pack).
+  DevBuf amax, amax_ws, amax_jobs;   // the records; the weight scalars; AmaxJob table of the weight tensors
+  int n_amax = 0, n_amax_jobs = 0, amax_grid = 0;
+  float* rec(int id) const { return (float*)amax.p + (size_t)id * AMAX_REC; }
+  bool f16_packed = false;     // the current packs are in the fp16 form
   int n_x3_all = 0, n_x3_fwd = 0, x3_grid_all = 0, x3_grid_fwd = 0;
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
@@ -324,17 +334,52 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     FR_HIP(hipMemcpy(m->pack_jobs.p, both.data(), both.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
   {  // split-bf16 pack jobs
-    std::vector<PackXJob> all, fwd;
+    // magnitude scalars of the two-plane fp16 form (see frcnn_model::amax) and the table of the weight tensors' segments
+    {
+      int n = 0;
+      for (auto& c : m->convs) { c.am = n; n += 3; }
+      for (auto& hd : m->heads) { hd.c3.am = n; n += 3; }
+      for (auto& b : m->blocks) b.am = n++;
+      m->n_amax = n;
+      FR_TRY(m->amax.ensure((size_t)n * AMAX_REC * 4));
+      FR_TRY(m->amax_ws.ensure((size_t)n * 4));
+      std::vector<AmaxJob> aj;
+      auto addw = [&](Conv& c) {
+        if (c.x_f || c.x_d) aj.push_back(AmaxJob{c.w_off, (long)c.Cout * c.Cin * c.k * c.k, m->rec(c.am + 2), 0});
+      };
+      for (auto& c : m->convs) addw(c);
+      for (auto& hd : m->heads) addw(hd.c3);
+      m->n_amax_jobs = (int)aj.size();
+      m->amax_grid = tensor_absmax_assign_blocks(aj.data(), m->n_amax_jobs);
+      if (!aj.empty()) {
+        FR_TRY(m->amax_jobs.ensure(aj.size() * sizeof(AmaxJob)));
+        FR_HIP(hipMemcpy(m->amax_jobs.p, aj.data(), aj.size() * sizeof(AmaxJob), hipMemcpyHostToDevice));
+      }
+    }
+    // four tables: [training jobs] [forward jobs], then the same two with the weight magnitude attached (fp16 form)
+    std::vector<PackXJob> all, fwd, all16, fwd16;
     auto add = [&](Conv& c) {
-      if (c.x_f) { all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p, c.Ho, c.Wo)); fwd.push_back(all.back()); }
-      if (c.x_d) all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p, c.H, c.W));
+      if (c.x_f) {
+        all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p, c.Ho, c.Wo)); fwd.push_back(all.back());
+        PackXJob j = all.back(); j.amax = m->rec(c.am + 2); j.amax_w = m->amax_ws.f() + c.am;
+        all16.push_back(j); fwd16.push_back(j);
+      }
+      if (c.x_d) {
+        all.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p, c.H, c.W));
+        PackXJob j = all.back(); j.amax = m->rec(c.am + 2); j.amax_w = m->amax_ws.f() + c.am;
+        all16.push_back(j);
+      }
     };
     for (auto& c : m->convs) add(c);
     for (auto& hd : m->heads) add(hd.c3);
     m->n_x3_all = (int)all.size(); m->n_x3_fwd = (int)fwd.size();
     m->x3_grid_all = conv_x3_pack_assign_blocks(all.data(), m->n_x3_all);
     m->x3_grid_fwd = conv_x3_pack_assign_blocks(fwd.data(), m->n_x3_fwd);
+    conv_x3_pack_assign_blocks(all16.data(), m->n_x3_all);
+    conv_x3_pack_assign_blocks(fwd16.data(), m->n_x3_fwd);
     all.insert(all.end(), fwd.begin(), fwd.end());
+    all.insert(all.end(), all16.begin(), all16.end());
+    all.insert(all.end(), fwd16.begin(), fwd16.end());
     if (!all.empty()) {
       FR_TRY(m->x3_jobs.ensure(all.size() * sizeof(PackXJob)));
       FR_HIP(hipMemcpy(m->x3_jobs.p, all.data(), all.size() * sizeof(PackXJob), hipMemcpyHostToDevice));
@@ -381,7 +426,7 @@ int frcnn_model_destroy(frcnn_model* m) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
     l.mask.release(); l.g.release(); l.xp.release(); l.xpT.release(); l.gp.release(); l.gpT.release();
   }
-  m->img.release(); m->wg_ws.release(); m->wg_ws_first.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release();
+  m->img.release(); m->wg_ws.release(); m->wg_ws_first.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release(); m->amax.release(); m->amax_ws.release(); m->amax_jobs.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
@@ -471,6 +516,7 @@ int frcnn_get_option(const char* name, int* value) {
   if (strcmp(name, "winograd") == 0) { *value = 0; return FRCNN_OK; }   // removed in round 3; kept as a name that reads 0
   if (strcmp(name, "cnet_wgrad_async") == 0) { *value = g_cnet_wgrad_async; return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
+  if (strcmp(name, "x3_f16") == 0) { *value = get_x3_f16(); return FRCNN_OK; }
   FR_CHECK(false, "get_option: unknown option '%s'", name);
   return FRCNN_OK;
 }
@@ -481,6 +527,7 @@ int frcnn_set_option(const char* name, int value) {
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
+  if (strcmp(name, "x3_f16") == 0) { set_x3_f16(value); return FRCNN_OK; }           // takes effect with the next forward pass
   if (strcmp(name, "winograd") == 0) return FRCNN_OK;   // deprecated no-op: the Winograd kernels were removed in round 3
   if (strcmp(name, "cnet_wgrad_async") == 0) { g_cnet_wgrad_async = value ? 1 : 0; return FRCNN_OK; }
   FR_CHECK(false, "set_option: unknown option '%s'", name);
@@ -576,7 +623,8 @@ static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, 
   const Block& in = m->blocks[h.input];
   if (h.c3.x_f)
     FR_TRY(conv_x3(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wx.p, w + h.c3.b_off, h.c3.Cout, h.c3.k, 0,
-                   h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
+                   h.c3.x.f(), OUT_STORE, 0, s, ws_slot, nullptr, m->f16_packed ? m->rec(in.am) : nullptr,
+                   m->f16_packed ? m->amax_ws.f() + h.c3.am : nullptr));
   else
     FR_TRY(conv_igemm(in.pooled.f(), h.c3.Cin, h.c3.H, h.c3.W, nullptr, nullptr, h.c3.wf.f(), w + h.c3.b_off,
                       h.c3.Cout, h.c3.k, 0, h.c3.x.f(), OUT_STORE, 0, s, ws_slot));
@@ -617,15 +665,21 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
   else
     FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
+  const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
+  m->f16_packed = f16;
+  const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
+  if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
+    FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p, m->n_amax_jobs, m->amax_grid, s));
   if (training)
-    FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p, m->n_x3_all, m->x3_grid_all, s));
+    FR_TRY(conv_x3_pack_multi(w, xjobs, m->n_x3_all, m->x3_grid_all, s));
   else
-    FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
+    FR_TRY(conv_x3_pack_multi(w, xjobs + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
   FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
   FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
   const float* cur = m->img.f();
   const float* cur_slope = nullptr;
   const float* cur_scale = nullptr;
+  const float* cur_am = nullptr;   // magnitude scalar of `cur` (fp16 form)
   for (size_t b = 0; b < m->blocks.size(); ++b) {
     Block& blk = m->blocks[b];
     bool pooled_in_conv = false;
@@ -635,11 +689,18 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
       // the block's max pool rides in the epilogue of its last convolution when that launch is a single K split
       IgemmPool pl = {blk.pooled.f(), (unsigned char*)blk.pidx.p, w + c.a_off,
                       (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
+      // fp16 form: the next convolution reads c.x scaled by its largest magnitude, which the launch that writes c.x records
+      const bool want_am = f16 && !last && m->convs[blk.first_conv + st + 1].x_f;
       if (c.x_f)
-        FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.k, c.pad, c.x.f(), OUT_STORE, 0, s));
+        FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.k, c.pad, c.x.f(), OUT_STORE, 0, s, 0,
+                       nullptr, f16 ? cur_am : nullptr, f16 ? m->amax_ws.f() + c.am : nullptr, want_am ? m->rec(c.am) : nullptr));
       else
         FR_TRY(conv_igemm(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wf.f(), w + c.b_off, c.Cout, c.k, c.pad,
                           c.x.f(), OUT_STORE, 0, s, 0, last ? &pl : nullptr, last ? &pooled_in_conv : nullptr));
+      if (want_am) {
+        if (!c.x_f) FR_TRY(tensor_absmax(c.x.f(), (long)c.Cout * c.Ho * c.Wo, m->rec(c.am), s));   // (the fp32 kernel keeps no record)
+        cur_am = m->rec(c.am);
+      }
       cur = c.x.f();
       cur_slope = w + c.a_off;
       cur_scale = (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr;  // model_utilities.lua:20
@@ -647,10 +708,13 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     const Conv& lc = m->convs[blk.first_conv + blk.nconv - 1];
     if (!pooled_in_conv)
       FR_TRY(maxpool_act_forward(cur, lc.Cout, lc.Ho, lc.Wo, cur_slope, cur_scale, blk.pooled.f(),
-                                 (unsigned char*)blk.pidx.p, s));
+                                 (unsigned char*)blk.pidx.p, s, f16 ? m->rec(blk.am) : nullptr));
+    else if (f16)   // (pooled inside the fp32 kernel of the first layer: a pass of its own over the pooled map)
+      FR_TRY(tensor_absmax(blk.pooled.f(), (long)lc.Cout * blk.Hp * blk.Wp, m->rec(blk.am), s));
     cur = blk.pooled.f();
     cur_slope = nullptr;
     cur_scale = nullptr;
+    cur_am = f16 ? m->rec(blk.am) : nullptr;   // the pooled map feeds the next block and the anchor nets on it
     // anchor nets on an earlier block's map run beside the following blocks, each on its own stream
     if (use_side && b + 1 < m->blocks.size()) {
       FR_TRY(ensure_side(m));
@@ -985,10 +1049,11 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
         // (nothing: c.gx is final; its bias gradient comes with the weight gradient below)
       } else if (st == blk.nconv - 1) {
         FR_TRY(maxpool_act_backward(blk.gpooled.f(), (const unsigned char*)blk.pidx.p, c.x.f(), c.Cout, c.Ho, c.Wo,
-                                    w + c.a_off, scale, c.gx.f(), grad + c.b_off, grad + c.a_off, s));
+                                    w + c.a_off, scale, c.gx.f(), grad + c.b_off, grad + c.a_off, s,
+                                    (c.x_d && m->f16_packed) ? m->rec(c.am + 1) : nullptr));
       } else {
         FR_TRY(act_backward(c.gx.f(), c.x.f(), c.Cout, (long)c.Ho * c.Wo, w + c.a_off, scale, c.gx.f(),
-                            grad + c.b_off, grad + c.a_off, s));
+                            grad + c.b_off, grad + c.a_off, s, (c.x_d && m->f16_packed) ? m->rec(c.am + 1) : nullptr));
       }
       // accGradParameters: the input is the previous conv's x (activation fused) or a pooled map / image
       const float* in; const float* in_slope = nullptr; const float* in_scale = nullptr;
@@ -1026,13 +1091,19 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
+      // fp16 form: the magnitude of c.gx was recorded by the launch that finished it (the pooling / activation backward above,
+      // or the previous input-gradient launch through its fused activation backward)
+      const float* ag = nullptr;
+      const float* aw = nullptr;
+      if (c.x_d && m->f16_packed) { ag = m->rec(c.am + 1); aw = m->amax_ws.f() + c.am; }
       if (c.x_d && st > 0 && fuse_act && c.k == 3) {
         Conv& pc = m->convs[blk.first_conv + st - 1];
         X3PostAct post{pc.x.f(), w + pc.a_off, (st - 1 == 0 && blk.has_drop) ? blk.scale.f() : nullptr, grad + pc.a_off};
-        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, &post));
+        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, &post, ag, aw,
+                       (pc.x_d && m->f16_packed) ? m->rec(pc.am + 1) : nullptr));
         act_done = true;
       } else if (c.x_d)
-        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s));
+        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, nullptr, ag, aw));
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
                           c.k - 1 - c.pad, gin, gmode, fl, s));

@@ -148,9 +148,28 @@ def test_input_gradient(F, O, both_forms, C_, H, W, O_, pad):
     assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
 
 
-def test_exactness_properties_at_full_size(F):
-    """b2c2 at the benchmarked size (128 -> 128 @ 225x400), properties that need no oracle: the split of a value is exact
-    (h + m + l == x), so a delta image returns the filter taps BIT FOR BIT and conv(2x) == 2 conv(x) exactly."""
+@pytest.fixture(params=[0, 1], ids=["bf16x6", "f16x3"])
+def x3_form(F, request):
+    """Both operand forms of the split launches: three bf16 planes / six partial products (exact split), two fp16 planes / three."""
+    before = _option(F, "x3_f16")
+    _option(F, "x3_f16", request.param)
+    yield request.param
+    _option(F, "x3_f16", before)
+
+
+def _tap_equal(got, tap, wmax, f16):
+    if not f16:   # h + m + l == x: bit for bit
+        return np.array_equal(got, tap)
+    # two fp16 planes of w * 2^e (the tensor's largest magnitude just below 2^15): 22 significand bits, absolute floor at the
+    # smallest fp16 subnormal
+    return bool(np.all(np.abs(got.astype(np.float64) - tap) <= 2.0 ** -22 * np.abs(tap) + 2.0 ** -38 * wmax))
+
+
+def test_exactness_properties_at_full_size(F, x3_form):
+    """b2c2 at the benchmarked size (128 -> 128 @ 225x400), properties that need no oracle: conv(2x) == 2 conv(x) exactly in
+    both forms (a power of two moves through either split untouched); with three bf16 planes the split of a value is exact
+    (h + m + l == x), so a delta image returns the filter taps BIT FOR BIT; with two fp16 planes to 22 bits."""
+    f16 = bool(x3_form)
     rng = np.random.RandomState(0)
     C_, H, W, O_ = 128, 225, 400, 128
     x = rng.randn(C_, H, W).astype(np.float32)
@@ -167,11 +186,12 @@ def test_exactness_properties_at_full_size(F):
     r = o1.numpy()
     for ky in range(3):
         for kx in range(3):
-            assert np.array_equal(r[:, 100 + 1 - ky, 200 + 1 - kx], w[:, 5, ky, kx])
+            wmax = float(np.abs(w).max())
+            assert _tap_equal(r[:, 100 + 1 - ky, 200 + 1 - kx], w[:, 5, ky, kx], wmax, f16)
             if ky >= 1 and kx >= 1:
-                assert np.array_equal(r[:, 224 + 1 - ky, 399 + 1 - kx], w[:, 77, ky, kx])
+                assert _tap_equal(r[:, 224 + 1 - ky, 399 + 1 - kx], w[:, 77, ky, kx], wmax, f16)
             if ky <= 1 and kx <= 1:
-                assert np.array_equal(r[:, 0 + 1 - ky, 0 + 1 - kx], -2 * w[:, 100, ky, kx])
+                assert _tap_equal(r[:, 0 + 1 - ky, 0 + 1 - kx], -2 * w[:, 100, ky, kx], 2 * wmax, f16)
     r[:, 99:102, 199:202] = 0; r[:, 223:225, 398:400] = 0; r[:, 0:2, 0:2] = 0
     assert not r.any()
 
