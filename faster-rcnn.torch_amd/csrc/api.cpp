@@ -267,7 +267,14 @@ int frcnn_conv2d_backward_weight(const float* in, int C, int H, int W, const flo
   size_t wsb = conv_wgrad_workspace_bytes(C, H, W, O, k, pad);
   void* ws = nullptr;
   FR_HIP(hipMalloc(&ws, wsb));
-  int rc = conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, ws, wsb, S(stream));
+  int rc = FRCNN_OK;
+  float* am = (k == 3 && conv_wgradx_eligible(C, O, k)) ? x3_f16_scalars(k) : nullptr;   // (fp16 form: records of both tensors)
+  if (am) {
+    rc = tensor_absmax(in, (long)C * H * W, am, S(stream));
+    if (rc == FRCNN_OK) rc = tensor_absmax(gout, (long)O * (H + 2 * pad - k + 1) * (W + 2 * pad - k + 1), am + AMAX_REC, S(stream));
+  }
+  if (rc == FRCNN_OK)
+    rc = conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, ws, wsb, S(stream), nullptr, am, am ? am + AMAX_REC : nullptr);
   (void)hipStreamSynchronize(S(stream));
   (void)hipFree(ws);
   FR_TRY(rc);

@@ -1362,13 +1362,14 @@ static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStr
 }
 
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
-               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias) {
+               const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias,
+               const float* amax_in, const float* amax_g) {
   WgradArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
-  if (conv_wgradx_eligible(Cin, O, k)) return conv_wgradx(in, Cin, H, W, in_slope, in_scale, g, O, pad, gw, ws, ws_bytes, s, gbias);
+  if (conv_wgradx_eligible(Cin, O, k)) return conv_wgradx(in, Cin, H, W, in_slope, in_scale, g, O, pad, gw, ws, ws_bytes, s, gbias, amax_in, amax_g);
   if (gbias) FR_TRY(channel_sum(g, O, (long)a.Ho * a.Wo, gbias, s));   // the fp32 kernels leave the bias half to a pass of its own
   FR_CHECK((long)Cin * H * W < (1L << 31) && (long)O * a.Ho * a.Wo < (1L << 31), "conv_wgrad: tensor too large for 32-bit offsets");
   g_wgrad_first_ok = (in_slope == nullptr && in_scale == nullptr);

@@ -75,7 +75,8 @@ struct X3PostAct {
 bool conv_wgradx_eligible(int Cin, int O, int k);
 size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad);
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
-                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr);
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr,
+                const float* amax_in = nullptr, const float* amax_g = nullptr);   // both records (amax.h): the two-plane fp16 form
 // gw[o][c][tap] += sum_s slab[s][tap][o][c]   (the fold shared by the weight-gradient kernels)
 int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s);
 // first layer of a one-convolution block: weight, bias and slope gradients straight from the pooled map's gradient
@@ -89,7 +90,8 @@ int conv_wgrad_first_pooled(const float* in, int Cin, int H, int W, const float*
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s,
-               float* gbias = nullptr);   // gbias: also gbias[o] += sum over pixels of g (in the same launch where the kernel can)
+               float* gbias = nullptr,   // gbias: also gbias[o] += sum over pixels of g (in the same launch where the kernel can)
+               const float* amax_in = nullptr, const float* amax_g = nullptr);   // magnitude records of in / g: conv_wgradx's fp16 form
 
 // ---------------------------------------------------------------- deterministic mode (frcnn_set_option("deterministic", 1))
 // Default: per-block partial sums of the bias / slope gradients and the scatter-adds of the ROI-pooling and sparse anchor-net

@@ -1064,6 +1064,13 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
+      // fp16 form of the weight-gradient launch: the records of both tensors exist when the forward launch that wrote `in` and
+      // the backward launch that wrote c.gx kept them (the same two tensors feed c's forward and c's input gradient)
+      const float* wa_in = nullptr; const float* wa_g = nullptr;
+      if (m->f16_packed && c.x_f && c.x_d && (st > 0 || b > 0)) {
+        wa_in = st > 0 ? m->rec(m->convs[blk.first_conv + st - 1].am) : m->rec(m->blocks[b - 1].am);
+        wa_g = m->rec(c.am + 1);
+      }
       // The first layer's weight gradient ends the pass and the caller's stream has nothing left to do (no input gradient for
       // the image): it runs THERE, with a slab workspace of its own, beside the side stream's last launches instead of
       // behind them (the optimiser waited ~80 us for the side stream's tail).
@@ -1071,12 +1078,12 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       if (use_side && !on_caller) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
       if (on_caller) {
         FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws_first.p,
-                          m->wg_ws_first.bytes, s, fused_here ? grad + c.b_off : nullptr));
+                          m->wg_ws_first.bytes, s, fused_here ? grad + c.b_off : nullptr, wa_in, wa_g));
         FR_HIP(hipEventRecord(m->join_ev, ws));          // (block 0's other convolutions, if any, are on the side stream)
         FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
       } else {
         FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws,
-                          fused_here ? grad + c.b_off : nullptr));
+                          fused_here ? grad + c.b_off : nullptr, wa_in, wa_g));
       }
       if (st == 0) {   // every gradient of block b's parameters is final once this launch has run (its fork also
                        // covers the bias / slope sums that act_backward accumulates on the caller's stream)

@@ -32,6 +32,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "amax.h"
 #include <type_traits>
 
 namespace frcnn {
@@ -41,6 +42,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define WX_TH 4
 #define WX_TW 16
@@ -49,7 +52,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define WX_XROW 48                       // bytes of one patch row: 24 elements, element e <-> input column ox0 - pad - 3 + e
 #define WX_XCH (6 * WX_XROW)             // bytes of one channel's patch (6 rows)
 #define WX_XPLANE (64 * WX_XCH + 8 * 16)  // (+16 per 8 channels, see wx_xaddr)
-#define WX_LDS (3 * WX_GPLANE + 3 * WX_XPLANE)
+#define WX_LDS (3 * WX_GPLANE + 3 * WX_XPLANE)    // one image of the three-plane form (the kernel's own constant: NP planes)
 
 bool conv_wgradx_eligible(int Cin, int O, int k) {
   return get_split_bf16() && k == 3 && Cin % 64 == 0 && O % 64 == 0;
@@ -75,6 +78,20 @@ __device__ __forceinline__ void wx_split4(const float* v, uint2& H, uint2& Mi, u
   H = make_uint2(h[0], h[1]); Mi = make_uint2(m[0], m[1]); L = make_uint2(l[0], l[1]);
 }
 
+__device__ __forceinline__ unsigned wx_cvt2h(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 r = __builtin_convertvector(v, f16x2);
+  return __builtin_bit_cast(unsigned, r);
+}
+// (convx.hip's x16_exp / x16_pow2: the power of two that puts a tensor's largest magnitude into [2^top, 2^(top+1)))
+__device__ __forceinline__ int wx_exp(float amax, int top) {
+  const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
+  if (be == 0) return 0;
+  const int e = top - (be - 127);
+  return e < -100 ? -100 : e > 100 ? 100 : e;
+}
+__device__ __forceinline__ float wx_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
 struct WgradXArgs {
   const float* in;
   const float* in_slope;
@@ -82,6 +99,8 @@ struct WgradXArgs {
   const float* g;
   float* slab;   // [nSplit][9][O][Cin]
   float* gbias;  // optional [O]: += sum over pixels of g (accGradParameters' bias half), taken from the staged gradient tiles
+  const float* amax_in;   // NP = 2 (two-plane fp16 form): magnitude records of `in` and `g` (amax.h)
+  const float* amax_g;
   int Cin, H, W, O, Ho, Wo, pad;
   int tilesX, tilesY, oTiles, cTiles, nSplit;
 };
@@ -125,9 +144,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 //                                * rows 1..3: the split of tile i + 1 (in registers since tile i - 1) and its LDS writes into
 //                                  the OTHER LDS image,
 //   after row 4: one barrier, the global loads of tile i + 2, and row 0 of tile i + 1 is read under the MFMAs of row 5.
-template <bool SLOPE, bool SCALE, int VEC>
+// NP = 3: three bf16 planes per operand, six partial products (the exact split).  NP = 2: two fp16 planes of the operands scaled
+// by powers of two (convx.hip, "two-plane fp16 form"), three partial products: half the MFMAs under the same staging work.
+template <bool SLOPE, bool SCALE, int VEC, int NP = 3>
 __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // two images of WX_LDS bytes: [G planes][X planes]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two images of LDSI bytes: [G planes][X planes]
+  constexpr unsigned LDSI = NP * (WX_GPLANE + WX_XPLANE), XB = NP * WX_GPLANE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wo = wave >> 1, wc = wave & 1;
@@ -148,6 +170,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   const int o0 = ot * 64, c0 = ct * 64;
   const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
   const float slope = SLOPE ? *p.in_slope : 1.f;
+  float gmul = 1.f, xmul = 1.f, out_mul = 1.f;
+  if (NP == 2) {
+    const float ag = amax_load_block(p.amax_g);
+    float ax = amax_load_block(p.amax_in);
+    if (SLOPE) ax *= fmaxf(1.f, fabsf(slope));
+    const int eg = wx_exp(ag, 14), ex = wx_exp(ax, SCALE ? 13 : 14);   // (a dropout scale's entries are <= 1: one binade of headroom)
+    gmul = wx_pow2(eg); xmul = wx_pow2(ex); out_mul = wx_pow2(-(eg + ex));
+  }
 
   f32x16 acc[9];
 #pragma unroll
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   auto xat = [&](int elem_off) { return xsrc + elem_off; };
   const float xscale = SCALE ? p.in_scale[c0 + srow] : 1.f;
   const unsigned gdst = (unsigned)(srow * WX_GROW) + ((((unsigned)sq >> 1) ^ wx_gswz(srow)) << 4) + (sq & 1) * 8;   // ^ (k << 5) per row
-  const unsigned xdst = 3 * WX_GPLANE + wx_xaddr(srow) + sq * 8;                                                  // + 32 k per item
+  const unsigned xdst = XB + wx_xaddr(srow) + sq * 8;                                                  // + 32 k per item
   int xr[9], xs[9];   // patch row / segment of item k
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -178,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // ---- fragment addressing
   const int oA = wo * 32 + li, cB = wc * 32 + li;
   const unsigned abase = (unsigned)(oA * WX_GROW) + (((unsigned)h ^ wx_gswz(oA)) << 4);   // ^ (ks << 5)
-  const unsigned bbase = 3 * WX_GPLANE + wx_xaddr(cB) + h * 16;                           // + 48 r (+ 16)
+  const unsigned bbase = XB + wx_xaddr(cB) + h * 16;                           // + 48 r (+ 16)
 
   // ---- the tiles of this block: t_i = split + i nSplit
   const int nPix = p.tilesX * p.tilesY;
@@ -280,22 +310,40 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
         x1 = inside(itc, 2 * j + 1, P) ? x1 : 0.f;
       }
       if (it < 4) bsum += bsum_on ? x0 + x1 : 0.f;
-      sh[it][j] = wx_cvt2(x0, x1);
-      sr[it][2 * j] = x0 - up_lo(sh[it][j]);
-      sr[it][2 * j + 1] = x1 - up_hi(sh[it][j]);
+      if constexpr (NP == 2) {
+        const float mul = it < 4 ? gmul : xmul;
+        x0 *= mul; x1 *= mul;
+        sh[it][j] = wx_cvt2h(x0, x1);
+        const f16x2 hv = __builtin_bit_cast(f16x2, sh[it][j]);
+        sr[it][2 * j] = x0 - (float)hv[0];
+        sr[it][2 * j + 1] = x1 - (float)hv[1];
+      } else {
+        sh[it][j] = wx_cvt2(x0, x1);
+        sr[it][2 * j] = x0 - up_lo(sh[it][j]);
+        sr[it][2 * j + 1] = x1 - up_hi(sh[it][j]);
+      }
       WX_PIN(sh[it][j]); WX_PIN(sr[it][2 * j]); WX_PIN(sr[it][2 * j + 1]);
     } else if constexpr (ph == 5 || ph == 7) {
       constexpr int j = (ph - 5) / 2;
-      sm[it][j] = wx_cvt2(sr[it][2 * j], sr[it][2 * j + 1]);
-      const float s0 = sr[it][2 * j] - up_lo(sm[it][j]), s1 = sr[it][2 * j + 1] - up_hi(sm[it][j]);
-      sl[it][j] = wx_cvt2(s0, s1);
-      WX_PIN(sm[it][j]); WX_PIN(sl[it][j]);
+      if constexpr (NP == 2) {
+        sl[it][j] = wx_cvt2h(sr[it][2 * j], sr[it][2 * j + 1]);
+        WX_PIN(sl[it][j]);
+      } else {
+        sm[it][j] = wx_cvt2(sr[it][2 * j], sr[it][2 * j + 1]);
+        const float s0 = sr[it][2 * j] - up_lo(sm[it][j]), s1 = sr[it][2 * j + 1] - up_hi(sm[it][j]);
+        sl[it][j] = wx_cvt2(s0, s1);
+        WX_PIN(sm[it][j]); WX_PIN(sl[it][j]);
+      }
     } else {
       char* d = it < 4 ? smem + (gwb ^ ((unsigned)it << 5)) : smem + xwb + 32 * (it - 4);
       constexpr int PL = it < 4 ? WX_GPLANE : WX_XPLANE;
       *reinterpret_cast<uint2*>(d) = make_uint2(sh[it][0], sh[it][1]);
-      *reinterpret_cast<uint2*>(d + PL) = make_uint2(sm[it][0], sm[it][1]);
-      *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(sl[it][0], sl[it][1]);
+      if constexpr (NP == 2) {
+        *reinterpret_cast<uint2*>(d + PL) = make_uint2(sl[it][0], sl[it][1]);
+      } else {
+        *reinterpret_cast<uint2*>(d + PL) = make_uint2(sm[it][0], sm[it][1]);
+        *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(sl[it][0], sl[it][1]);
+      }
       asm volatile("" ::: "memory");
     }
   };
@@ -313,18 +361,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   // walk the PATCH rows: the 16 elements a lane reads of patch row r (two 16-byte reads per plane) hold its 8 pixels at all
   // three column taps -- tap kx starts at element 3 + kx: kx = 1 is registers 2..5 as they are, kx = 0 / 2 are v_perm of
   // neighbouring registers -- and serve every (ks, ky) with ks + ky = r.  The gradient fragments stay in registers.
-  bf16x8 a[WX_TH][3];
-  u32x4 b[3][3], bn[3][3];   // [kx][plane] of the row being multiplied / of the next one
-  u32x4 raw[3][2];
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest partial products first; plane 0 = h, 1 = m, 2 = l
+  u32x4 a[WX_TH][NP];
+  u32x4 b[3][NP], bn[3][NP];   // [kx][plane] of the row being multiplied / of the next one
+  u32x4 raw[NP][2];
+  constexpr int NQ = NP == 2 ? 3 : 6;   // partial products, smallest first; plane 0 = h, then m, l (three planes) / l (two)
+  constexpr int PA[6] = {NP == 2 ? 1 : 2, 0, NP == 2 ? 0 : 1, 1, 0, 0}, PB[6] = {0, NP == 2 ? 1 : 2, NP == 2 ? 0 : 1, 0, 1, 0};
   auto read_row = [&](unsigned rb, int r) {
     if (r < WX_TH) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        a[r][pl] = *reinterpret_cast<const bf16x8*>(smem + rb + pl * WX_GPLANE + (abase ^ ((unsigned)r << 5)));
+      for (int pl = 0; pl < NP; ++pl)
+        a[r][pl] = *reinterpret_cast<const u32x4*>(smem + rb + pl * WX_GPLANE + (abase ^ ((unsigned)r << 5)));
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NP; ++pl) {
       raw[pl][0] = *reinterpret_cast<const u32x4*>(smem + rb + bbase + pl * WX_XPLANE + r * WX_XROW);
       raw[pl][1] = *reinterpret_cast<const u32x4*>(smem + rb + bbase + pl * WX_XPLANE + r * WX_XROW + 16);
     }
@@ -357,25 +406,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   load_origin(pre[0]);                                                // tile 2
   static_for<13>([&](auto itc) { load_step(itc, pre[0]); });
   read_row(0, 0);
-  static_for<6>([&](auto sc) { cut_step(sc); });
+  static_for<2 * NP>([&](auto sc) { cut_step(sc); });
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[kx][pl] = bn[kx][pl];
+    for (int pl = 0; pl < NP; ++pl) b[kx][pl] = bn[kx][pl];
 
   // tile i: products from image i & 1; tile i + 1 is staged from set P (= (i + 1) & 1), which then receives tile i + 3
   auto tile = [&](int i, Pre& P) {
-    const unsigned rb = (i & 1) ? WX_LDS : 0, wb = WX_LDS - rb;
-    const unsigned gwb = gdst + wb, xwb = xdst + wb;   // (WX_LDS is a multiple of 128: the row XOR of gdst still applies)
+    const unsigned rb = (i & 1) ? LDSI : 0, wb = LDSI - rb;
+    const unsigned gwb = gdst + wb, xwb = xdst + wb;   // (LDSI is a multiple of 128: the row XOR of gdst still applies)
     bsum_on = i + 1 < nT;                                 // rows 1..3 stage tile i + 1
     auto row = [&](auto rc) {
       constexpr int r = decltype(rc)::value;
       constexpr int nky = r < 3 ? r + 1 : 6 - r;            // (ks, ky) pairs of this row: 1 2 3 3 2 1
-      constexpr int NM = 18 * nky;
+      constexpr int NM = 3 * NQ * nky;
       // side work of the row: staging steps (rows 1..3), load steps (row 4), then the six tap-cut steps of the next row
       constexpr int NPX = 9 - XPH0;
       constexpr int NSTG = r == 1 ? 4 * 5 + NPX : (r == 2 || r == 3) ? 4 * NPX : r == 4 ? 13 : 0;
-      constexpr int NS = NSTG + 6;
+      constexpr int NS = NSTG + 2 * NP;
       __builtin_amdgcn_sched_barrier(0);
       if (r < 5) read_row(rb, r + 1); else read_row(wb, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +435,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
         constexpr int q = m / (3 * nky), kyi = (m / 3) % nky, kx = m % 3;
         constexpr int ky = (r < WX_TH ? 0 : r - (WX_TH - 1)) + kyi, ks = r - ky;
         static_assert(ks >= 0 && ks < WX_TH && ky < 3, "tap walk");
-        acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][PA[q]], __builtin_bit_cast(bf16x8, b[kx][PB[q]]), acc[3 * ky + kx], 0, 0, 0);
+        if constexpr (NP == 2)
+          acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks][PA[q]]), __builtin_bit_cast(f16x8, b[kx][PB[q]]), acc[3 * ky + kx], 0, 0, 0);
+        else
+          acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][PA[q]]), __builtin_bit_cast(bf16x8, b[kx][PB[q]]), acc[3 * ky + kx], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // rows 0 and 5 (side work = the tap cuts only) leave the first MFMAs to cover the latency of the reads above
         constexpr int LEAD = NSTG == 0 ? 6 : 0;
@@ -407,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[kx][pl] = bn[kx][pl];
+        for (int pl = 0; pl < NP; ++pl) b[kx][pl] = bn[kx][pl];
       if (r == 4) __syncthreads();   // image `wb` is complete, image `rb` has been read for the last time
     };
     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{});
@@ -434,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        sl[(size_t)tap * OC + (size_t)o * p.Cin + c] = acc[tap][r];
+        sl[(size_t)tap * OC + (size_t)o * p.Cin + c] = NP == 2 ? acc[tap][r] * out_mul : acc[tap][r];
       }
   }
 }
@@ -454,19 +506,19 @@ size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad) {
   return (size_t)a.nSplit * 9 * O * Cin * 4 + 256;
 }
 
-template <bool SLOPE, bool SCALE, int VEC>
+template <bool SLOPE, bool SCALE, int VEC, int NP = 3>
 static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradx_kernel<SLOPE, SCALE, VEC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgradx_kernel<SLOPE, SCALE, VEC, NP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, NP == 2 ? 120 * 1024 : 160 * 1024));   // (NP = 2 has static words: amax.h)
     attr_set = true;
   }
   const int grid = a.oTiles * a.cTiles * a.nSplit;
   const double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.O * a.Ho * a.Wo);
   if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
-  const size_t lds = 2 * WX_LDS;   // two images (> 80 KB: one block per CU)
-  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE, VEC>), dim3(grid), dim3(256), lds, s, a);
+  const size_t lds = 2 * (size_t)NP * (WX_GPLANE + WX_XPLANE);   // two images (> 80 KB: one block per CU)
+  hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE, VEC, NP>), dim3(grid), dim3(256), lds, s, a);
   FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
   if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
   FR_LAUNCH_CHECK();
@@ -483,21 +535,23 @@ static bool readable_past_end(const void* p, size_t bytes, size_t slack) {
   return (uintptr_t)p + bytes + slack <= (uintptr_t)base + size;
 }
 
-template <bool SLOPE, bool SCALE>
+template <bool SLOPE, bool SCALE, int NP = 3>
 static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
   // one aligned 16-byte load per 4-pixel segment when every segment lies inside a row or outside the image as a whole; one
   // unaligned one when the width is arbitrary and the 12 bytes behind both tensors belong to their allocations
   if (a.pad == 1 && a.W % 4 == 0 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.g & 15) == 0)
-    return launch_wgradx_v<SLOPE, SCALE, 1>(a, flops, gw, s);
+    return launch_wgradx_v<SLOPE, SCALE, 1, NP>(a, flops, gw, s);
   if (a.pad == 1 && readable_past_end(a.in, (size_t)a.Cin * a.H * a.W * 4, 12) && readable_past_end(a.g, (size_t)a.O * a.Ho * a.Wo * 4, 12))
-    return launch_wgradx_v<SLOPE, SCALE, 2>(a, flops, gw, s);
-  return launch_wgradx_v<SLOPE, SCALE, 0>(a, flops, gw, s);
+    return launch_wgradx_v<SLOPE, SCALE, 2, NP>(a, flops, gw, s);
+  return launch_wgradx_v<SLOPE, SCALE, 0, NP>(a, flops, gw, s);
 }
 
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
-                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias) {
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias, const float* amax_in, const float* amax_g) {
   WgradXArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g; a.gbias = gbias;
+  a.amax_in = amax_in; a.amax_g = amax_g;
+  FR_CHECK((amax_in != nullptr) == (amax_g != nullptr), "conv_wgradx: the fp16 form needs the magnitude records of both tensors");
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
   FR_CHECK(Cin % 64 == 0 && O % 64 == 0, "conv_wgradx: %d channels x %d filters is not a split-bf16 shape", Cin, O);
   FR_CHECK((long)Cin * H * W < (1L << 30) && (long)O * a.Ho * a.Wo < (1L << 30), "conv_wgradx: tensor too large for 32-bit offsets");
@@ -506,6 +560,10 @@ int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, c
   FR_CHECK(ws && ws_bytes >= need, "conv_wgradx: workspace too small (%zu < %zu)", ws_bytes, need);
   a.slab = (float*)(((uintptr_t)ws + 255) / 256 * 256);
   const double flops = 2.0 * O * Cin * 9 * (double)a.Ho * a.Wo;
+  if (amax_in) {
+    if (in_slope) return in_scale ? launch_wgradx<true, true, 2>(a, flops, gw, s) : launch_wgradx<true, false, 2>(a, flops, gw, s);
+    return in_scale ? launch_wgradx<false, true, 2>(a, flops, gw, s) : launch_wgradx<false, false, 2>(a, flops, gw, s);
+  }
   if (in_slope) return in_scale ? launch_wgradx<true, true>(a, flops, gw, s) : launch_wgradx<true, false>(a, flops, gw, s);
   return in_scale ? launch_wgradx<false, true>(a, flops, gw, s) : launch_wgradx<false, false>(a, flops, gw, s);
 }
