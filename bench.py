@@ -7,11 +7,12 @@ step, data-parallel over N GPUs of one node (gradient all-reduce on RCCL).
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line on rank 0 (contract in the task statement), carrying
-  "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_x3: forward + input-gradient of the 3x3
-                    convolutions in the split-bf16 operand form; conv_igemm 3x3, fp32 MFMA, with the option off)
+  "roofline"     -- achieved TFLOP/s of the dominant kernel (conv_x3: forward + input-gradient of the convolutions
+                    in the split operand form; conv_igemm 3x3, fp32 MFMA, with the option off)
                     = algorithmic FLOPs of its launches / their HIP-event durations, measured live over the timed
-                    steps, vs the matrix-core peak FOR THAT FORMULATION: the bf16 dense peak / 6 (six bf16 MFMA
-                    partial products per fp32 product); the fp32-MFMA peak for conv_igemm;
+                    steps, vs the matrix-core peak FOR THAT FORMULATION: the fp16 / bf16 dense peak / 3 (two fp16
+                    planes per operand, three partial products per fp32 product: option x3_f16 = 1, the default) or
+                    / 6 (three bf16 planes, six partial products: x3_f16 = 0); the fp32-MFMA peak for conv_igemm;
   "cpu_baseline" -- the CPU restatement of the reference (oracle/, "port") timed on this host, N=1 only:
                     the training step on the benchmarked 3x450x800 frame with all cores (1 warm-up + median
                     of 3) and with one thread on a 1/16-area frame (BASELINE.md section 4);
@@ -41,7 +42,17 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # ... v_mfma_f32_32x32x16_bf16: 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (dense)
-SPLIT_PRODUCTS = 6              # bf16 x bf16 partial products per fp32 product in the split-operand kernels (convx.hip)
+SPLIT_PRODUCTS = 6              # bf16 x bf16 partial products per fp32 product in the three-plane split form (convx.hip, x3_f16 = 0)
+F16_PRODUCTS = 3                # fp16 x fp16 partial products per fp32 product in the two-plane form (x3_f16 = 1, the default)
+
+
+def split_products(F):
+    """Partial products per fp32 product of the split launches as configured: 3 (two fp16 planes) or 6 (three bf16 planes).
+    v_mfma_f32_32x32x16_f16 and _bf16 have the same dense peak."""
+    import ctypes
+    v = ctypes.c_int(0)
+    F._lib.call("frcnn_get_option", b"x3_f16", ctypes.byref(v))
+    return F16_PRODUCTS if v.value else SPLIT_PRODUCTS
 CONV_CLASSES = ("conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "conv_x3", "conv_wgradx")
 FULL_H, FULL_W = 450, 800
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s is what a float4 copy reaches
@@ -257,7 +268,7 @@ def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
     F._lib.call("frcnn_prof_collect", la, ms, fl, by)
     k = F._lib.KC_NAMES.index("conv_x3")
     if ms[k] > 0:
-        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+        peak = BF16_MFMA_PEAK_TFLOPS / split_products(F)
         ach = (fl[k] / 1e12) / (ms[k] / 1e3)
         conv_ms = sum(ms[F._lib.KC_NAMES.index(c)] for c in CONV_CLASSES) / 8.0
         out["roofline"] = dict(bound="mfma", kernel="conv_x3_kernel (3x3 forward launches of the frame)", achieved=round(ach, 2), peak=round(peak, 1),
@@ -329,7 +340,7 @@ def large_leg(F, with_cpu, steps=12):
     launches, ms, fl, by = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
     F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
     k = F._lib.KC_NAMES.index("conv_x3")
-    peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    peak = BF16_MFMA_PEAK_TFLOPS / split_products(F)
     ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
     _, train_flops = conv_flops_per_image(model, H, W)
     out = dict(metric="images/sec (vgg_large 1000x600 fwd+bwd, config/imagenet.lua: 200 classes, 45 015 anchors, 6x6 ROI pooling)",
@@ -648,7 +659,7 @@ def main():
                                          tflops=round((f2[i] / 1e12) / (m2[i] / 1e3), 2) if f2[i] > 0 and m2[i] > 0 else None)
         split_on = l2[F._lib.KC_NAMES.index("conv_x3")] > 0
         kdom = F._lib.KC_NAMES.index("conv_x3" if split_on else "conv_igemm_k3")
-        peak_dom = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS
+        peak_dom = BF16_MFMA_PEAK_TFLOPS / split_products(F) if split_on else FP32_MFMA_PEAK_TFLOPS
         if m2[kdom] > 0:
             a2 = (f2[kdom] / 1e12) / (m2[kdom] / 1e3)
             iso = dict(achieved=round(a2, 2), frac=round(a2 / peak_dom, 4), avg_launch_ms=round(m2[kdom] / max(l2[kdom], 1), 4),
@@ -676,7 +687,8 @@ def main():
         fwd_flops, train_flops = conv_flops_per_image(model, H, W)
         split_on = launches[F._lib.KC_NAMES.index("conv_x3")] > 0
         k = F._lib.KC_NAMES.index("conv_x3" if split_on else "conv_igemm_k3")
-        peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split_on else FP32_MFMA_PEAK_TFLOPS
+        nprod = split_products(F)
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if split_on else FP32_MFMA_PEAK_TFLOPS
         ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
         traffic = None
         traffic_taken = None
@@ -703,9 +715,15 @@ def main():
             metric="images/sec (%s %dx%d fwd+bwd)" % (args.model, W, H), value=round(world * args.steps / dt, 3), unit="images/sec",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-            arithmetic=("fp32 tensors, fp32 accumulation; the 3x3 convolutions (forward, input gradient, weight gradient) form every fp32 "
-                        "product from six exact bf16 x bf16 partial products of three-way split operands (24 significand bits, "
-                        "v_mfma_f32_32x32x16_bf16); every other product is a plain fp32 product (v_mfma_f32_32x32x2_f32 / VALU)"
+            arithmetic=(("fp32 tensors, fp32 accumulation; the 3x3 / 5x5 / 7x7 convolutions (forward, input gradient, 3x3 weight gradient) scale "
+                         "each operand tensor by a power of two chosen from its largest magnitude, split it into two fp16 planes (22 significand "
+                         "bits) and form every product from three exact fp16 x fp16 partial products (v_mfma_f32_32x32x16_f16); measured "
+                         "error against fp64 at the level of the fp32 matrix-core kernel (tools/x3_f16_check.py); the classification net's "
+                         "products use three bf16 planes / six partial products; every other product is a plain fp32 product"
+                         if nprod == F16_PRODUCTS else
+                         "fp32 tensors, fp32 accumulation; the 3x3 convolutions (forward, input gradient, weight gradient) form every fp32 "
+                         "product from six exact bf16 x bf16 partial products of three-way split operands (24 significand bits, "
+                         "v_mfma_f32_32x32x16_bf16); every other product is a plain fp32 product (v_mfma_f32_32x32x2_f32 / VALU)")
                         if split_on else "fp32 tensors, fp32 products (v_mfma_f32_32x32x2_f32 / VALU), fp32 accumulation"),
             config=dict(workload=args.model + " %dx%d train step: lossAndGradient (pnet fwd, sparse RPN loss, ROI pool, cnet fwd/bwd, "
                                  "ROI-pool bwd, pnet bwd) + gradient all-reduce + rmsprop; config/%s.lua values; frames resident in HBM when the timed "
@@ -725,8 +743,10 @@ def main():
                            "every launch, the update) and the time it then waits for the step's 64-byte statistics; while wait > 0 the "
                            "host is ahead of the device and does not bound `value`"),
             roofline=dict(bound="mfma",
-                          kernel=("conv_x3_kernel (3x3 conv forward + input-gradient, split-bf16 operands: 6 bf16 MFMA partial products "
-                                  "per fp32 product)" if split_on else
+                          kernel=(("conv_x3_kernel (conv forward + input-gradient, two fp16 planes per operand: 3 fp16 MFMA partial products "
+                                   "per fp32 product)" if nprod == F16_PRODUCTS else
+                                   "conv_x3_kernel (3x3 conv forward + input-gradient, split-bf16 operands: 6 bf16 MFMA partial products "
+                                   "per fp32 product)") if split_on else
                                   "conv_igemm_kernel<3,8,*> (3x3 conv forward + input-gradient, fp32 MFMA)"),
                           achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
                           frac=round(ach / peak, 4), traffic=traffic,
@@ -734,9 +754,10 @@ def main():
                                           "--pmc WRITE_SIZE passes of this command (FETCH x2, the gfx950 correction; tools/pmc_traffic.py), "
                                           "taken when the profile was made -- not counted in this run" if traffic is not None else None),
                           traffic_taken=traffic_taken,
-                          peak_note=("algorithmic (fp32-product) TFLOP/s against the dense bf16 matrix-core peak 2516.6 / 6 partial "
-                                     "products; executed bf16 MFMA rate = 6 x achieved = %.0f TFLOP/s; the fp32 matrix-core peak is "
-                                     "157.3 TFLOP/s" % (SPLIT_PRODUCTS * ach) if split_on else "fp32 matrix-core peak"),
+                          peak_note=("algorithmic (fp32-product) TFLOP/s against the dense fp16 / bf16 matrix-core peak 2516.6 / %d partial "
+                                     "products; executed MFMA rate = %d x achieved = %.0f TFLOP/s (%.3f of the dense peak); the fp32 matrix-core "
+                                     "peak is 157.3 TFLOP/s" % (nprod, nprod, nprod * ach, nprod * ach / BF16_MFMA_PEAK_TFLOPS)
+                                     if split_on else "fp32 matrix-core peak"),
                           sampled_steps=sampled, launches_per_step=launches[k] / sampled, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),

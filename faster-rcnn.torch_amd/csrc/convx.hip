@@ -59,7 +59,7 @@ int get_split_bf16() {
 static int g_x3_f16 = -1;   // option "x3_f16" (environment FRCNN_X3_F16): the split launches take the two-plane fp16 form
 void set_x3_f16(int on) { g_x3_f16 = on ? 1 : 0; }
 int get_x3_f16() {
-  if (g_x3_f16 < 0) g_x3_f16 = getenv("FRCNN_X3_F16") ? (atoi(getenv("FRCNN_X3_F16")) != 0) : 0;
+  if (g_x3_f16 < 0) g_x3_f16 = getenv("FRCNN_X3_F16") ? (atoi(getenv("FRCNN_X3_F16")) != 0) : 1;   // default on since round 5
   return g_x3_f16;
 }
 

@@ -40,6 +40,15 @@ def both_forms(F):
     _option(F, "split_bf16", before)
 
 
+@pytest.fixture(params=[0, 1], ids=["bf16x6", "f16x3"])
+def x3_form(F, request):
+    """Both operand forms of the split launches: three bf16 planes / six partial products (exact split), two fp16 planes / three."""
+    before = _option(F, "x3_f16")
+    _option(F, "x3_f16", request.param)
+    yield request.param
+    _option(F, "x3_f16", before)
+
+
 def _rms(a, want):
     return float(np.sqrt(np.mean((a.astype(np.float64) - want) ** 2)))
 
@@ -58,7 +67,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("C_,H,W,O_,pad", SHAPES)
-def test_forward_is_an_fp32_convolution(F, O, both_forms, C_, H, W, O_, pad):
+def test_forward_is_an_fp32_convolution(F, O, both_forms, x3_form, C_, H, W, O_, pad):
     rng = np.random.RandomState(C_ + H)
     x = rng.randn(C_, H, W).astype(np.float32)
     w = (rng.randn(O_, C_, 3, 3) * np.sqrt(2.0 / (9 * O_))).astype(np.float32)
@@ -78,7 +87,7 @@ def test_forward_is_an_fp32_convolution(F, O, both_forms, C_, H, W, O_, pad):
     assert es <= 2.0 * ed + 1e-9, (es, ed)
 
 
-def test_wide_dynamic_range(F, O, both_forms):
+def test_wide_dynamic_range(F, O, both_forms, x3_form):
     """Magnitudes spread over ~12 decades (log-normal): the three-way split keeps 24 significand bits of every operand
     whatever its exponent, so the error stays that of an fp32 product."""
     rng = np.random.RandomState(3)
@@ -102,7 +111,7 @@ def test_wide_dynamic_range(F, O, both_forms):
     assert rs.max() <= 2.0 * rd.max() + 1e-9, (rs.max(), rd.max())
 
 
-def test_fused_activation_of_the_producing_layer(F, O, both_forms):
+def test_fused_activation_of_the_producing_layer(F, O, both_forms, x3_form):
     rng = np.random.RandomState(1)
     C_, H, W, O_, pad = 32, 21, 34, 128, 1
     x = rng.randn(C_, H, W).astype(np.float32)
@@ -126,7 +135,7 @@ def test_fused_activation_of_the_producing_layer(F, O, both_forms):
 
 @pytest.mark.parametrize("C_,H,W,O_,pad", [(128, 57, 100, 64, 1), (256, 38, 63, 512, 1), (128, 31, 45, 48, 0),
                                             (64, 57, 100, 128, 1)])   # the last: M = 64 input channels (64-filter blocks)
-def test_input_gradient(F, O, both_forms, C_, H, W, O_, pad):
+def test_input_gradient(F, O, both_forms, x3_form, C_, H, W, O_, pad):
     """updateGradInput: M = C input channels (a multiple of 64), K = O filters (a multiple of 16)."""
     rng = np.random.RandomState(C_ * 7 + O_)
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
@@ -146,15 +155,6 @@ def test_input_gradient(F, O, both_forms, C_, H, W, O_, pad):
     assert_close(split, want, 1e-4, "split-bf16 conv dgrad")
     assert_close(split2, 2 * want, 2e-4, "split-bf16 conv dgrad accumulate")
     assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
-
-
-@pytest.fixture(params=[0, 1], ids=["bf16x6", "f16x3"])
-def x3_form(F, request):
-    """Both operand forms of the split launches: three bf16 planes / six partial products (exact split), two fp16 planes / three."""
-    before = _option(F, "x3_f16")
-    _option(F, "x3_f16", request.param)
-    yield request.param
-    _option(F, "x3_f16", before)
 
 
 def _tap_equal(got, tap, wmax, f16):
@@ -198,7 +198,7 @@ def test_exactness_properties_at_full_size(F, x3_form):
 
 @pytest.mark.parametrize("C_,H,W,O_,pad", [(64, 57, 100, 128, 1), (128, 29, 50, 64, 1), (256, 38, 63, 512, 1), (64, 9, 11, 64, 1),
                                             (64, 31, 45, 64, 0), (64, 75, 125, 64, 1), (128, 37, 250, 64, 1)])
-def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
+def test_weight_gradient(F, O, both_forms, x3_form, C_, H, W, O_, pad):
     """accGradParameters (csrc/wgradx.hip): both operands split while they are staged into pixel-contiguous planes."""
     rng = np.random.RandomState(C_ * 13 + O_)
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
@@ -223,7 +223,7 @@ def test_weight_gradient(F, O, both_forms, C_, H, W, O_, pad):
 
 
 @pytest.mark.parametrize("W", [34, 36, 48])   # 36 / 48: the 16-byte-segment loader (W % 4 = 0), 34: the per-element one
-def test_weight_gradient_with_fused_activation(F, O, W):
+def test_weight_gradient_with_fused_activation(F, O, x3_form, W):
     rng = np.random.RandomState(2)
     C_, H, O_, pad = 64, 21, 64, 1
     x = rng.randn(C_, H, W).astype(np.float32)
@@ -240,7 +240,7 @@ def test_weight_gradient_with_fused_activation(F, O, W):
 
 
 @pytest.mark.parametrize("C_,H,W,O_,k", [(384, 29, 50, 256, 5), (384, 29, 50, 256, 7), (32, 17, 23, 128, 5), (16, 9, 30, 128, 7)])
-def test_anchor_net_kernel_sizes(F, O, both_forms, C_, H, W, O_, k):
+def test_anchor_net_kernel_sizes(F, O, both_forms, x3_form, C_, H, W, O_, k):
     """The 5x5 and 7x7 valid convolutions of the anchor nets (models/model_utilities.lua:31, vgg_small.lua:13-14) in the
     same form: forward and input gradient."""
     rng = np.random.RandomState(C_ + k)
@@ -281,7 +281,7 @@ MODEL_LAYERS = [  # name, Cin, H, W, Cout, pad -- the 3x3 launches of a vgg_smal
 
 
 @pytest.mark.parametrize("name,C_,H,W,O_,pad", MODEL_LAYERS)
-def test_model_layer_shapes_full_size(F, name, C_, H, W, O_, pad):
+def test_model_layer_shapes_full_size(F, x3_form, name, C_, H, W, O_, pad):
     """Every 3x3 launch shape of the benchmarked step at FULL size -- forward without and with the fused input activation
     (PReLU slope + dropout scale: the <SLOPE, SCALE> instantiations), and the input gradient -- against the fp32 matrix-core
     kernel on the same inputs, three times each.  The small shapes above did not catch a timing-dependent fault of the
@@ -316,7 +316,7 @@ def test_model_layer_shapes_full_size(F, name, C_, H, W, O_, pad):
 
 
 @pytest.mark.parametrize("k", [5, 7])
-def test_anchor_net_shapes_full_size(F, k):
+def test_anchor_net_shapes_full_size(F, x3_form, k):
     """The 5x5 / 7x7 anchor nets of vgg_small at the benchmarked size (384 -> 256 on the 29x50 map, valid): since round 5 their
     forward pass takes the split form by default (8x16-pixel tiles, 240 / 308-position patch, up to 24 K splits + fold).
     Against the fp32 matrix-core kernel, three runs."""
