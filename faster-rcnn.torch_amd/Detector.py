@@ -12,6 +12,8 @@ of the winner table.  The list detect() returns builds its {p, a, r, l, r2, clas
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -60,8 +62,13 @@ class _Detections(object):
 
 
 class Detector(object):
-    def __init__(self, model):  # Detector.lua:8-15
+    def __init__(self, model, static_weights=False):  # Detector.lua:8-15
+        """static_weights=True: the caller promises not to write the weight vector between detect() calls; the library then packs
+        the convolution weights once instead of once per frame (option static_weights of the C ABI; a training-mode pass or
+        another Detector(..., static_weights=...) drops the packs)."""
         self.model = model
+        if static_weights or os.environ.get("FRCNN_STATIC_WEIGHTS"):
+            _lib.call("frcnn_set_option", b"static_weights", 1)
         cfg = model["cfg"]
         self.anchors = Anchors(model["pnet"], cfg["scales"])
         self.localizer = Localizer(model["pnet"].outnode.children[-1])

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "amax.h"
 #include <type_traits>
 
 namespace frcnn {
@@ -211,6 +212,7 @@ struct IgemmArgs {
   unsigned char* pool_idx;     // arg-max code dy*2+dx, first maximum wins
   const float* pool_slope;     // PReLU slope of the pooled activation (device scalar) or null
   const float* pool_scale;     // dropout scale [M] or null
+  float* pool_amax;            // magnitude record of the pooled map (amax.h) or null
   int Hp, Wp;
 };
 
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
     const bool has_ps = p.pool_slope != nullptr;
     const size_t pofs = (size_t)(oy0 >> 1) * p.Wp + (ox >> 1);
     const size_t HpWp = (size_t)p.Hp * p.Wp;
+    float am = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mrow0 + (r & 3) + 8 * (r >> 2);
@@ -548,8 +551,10 @@ __global__ __launch_bounds__(256, (igemm_blocks_per_cu<CC, MODE>(KS, BM))) void 
         }
         p.pool_out[(size_t)m * HpWp + pofs] = best;
         p.pool_idx[(size_t)m * HpWp + pofs] = (unsigned char)bi;
+        am = fmaxf(am, fabsf(best));
       }
     }
+    if (p.pool_amax) amax_store_block(am, p.pool_amax);
   };
   if constexpr (MT == 1 && NTW == 2 && KS == 3) {
     if (p.pool_out) { store_tile_pool(); goto done; }
@@ -626,7 +631,7 @@ static int launch_igemm_n(IgemmArgs& a, int klass, double flops, hipStream_t s) 
   static bool attr_set = false;
   if (!attr_set) {
     FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<KS, CC, BM, MODE, NIT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // (a few static words: amax.h)
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
@@ -648,7 +653,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
                double algo_flops, hipStream_t s, int ws_slot, const IgemmPool* pool, bool* pool_fused) {
   IgemmArgs a;
-  a.pool_out = nullptr; a.pool_idx = nullptr; a.pool_slope = nullptr; a.pool_scale = nullptr; a.Hp = a.Wp = 0;
+  a.pool_out = nullptr; a.pool_idx = nullptr; a.pool_slope = nullptr; a.pool_scale = nullptr; a.pool_amax = nullptr; a.Hp = a.Wp = 0;
   if (pool_fused) *pool_fused = false;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.wp = wp; a.bias = bias; a.out = out;
   a.Cin = Cin; a.H = H; a.W = W; a.M = M; a.Mpad = conv_mpad(M);
@@ -686,7 +691,7 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
   }
   if (fuse) {
     a.TH = 4; a.TW = 32;
-    a.pool_out = pool->out; a.pool_idx = pool->idx; a.pool_slope = pool->slope; a.pool_scale = pool->scale;
+    a.pool_out = pool->out; a.pool_idx = pool->idx; a.pool_slope = pool->slope; a.pool_scale = pool->scale; a.pool_amax = pool->amax;
     a.Hp = (a.Ho - 2 + 1) / 2 + 1; a.Wp = (a.Wo - 2 + 1) / 2 + 1;
     if (pool_fused) *pool_fused = true;
   } else {

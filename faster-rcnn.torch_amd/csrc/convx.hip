@@ -141,16 +141,17 @@ __device__ __forceinline__ float x16_pow2(int e) { return __builtin_bit_cast(flo
 // largest magnitude of a tensor in a pass of its own (operator-level calls, and the tensors whose producer keeps no record)
 __device__ __forceinline__ float absmax_span(const float* __restrict__ x, long n, long first, long stride) {
   float m = 0.f;
-  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
-    for (long i = first; i < n / 4; i += stride) {
-      const float4 v = x4[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    for (long i = (n / 4) * 4 + first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
-  } else {
-    for (long i = first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  // scalar head up to the first 16-byte boundary, 16-byte body, scalar tail (the weight tensors start at any element)
+  long head = (long)((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2;
+  if (head > n) head = n;
+  for (long i = first; i < head; i += stride) m = fmaxf(m, fabsf(x[i]));
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + head);
+  const long n4 = (n - head) / 4;
+  for (long i = first; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
+  for (long i = head + 4 * n4 + first; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
   return m;
 }
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ rec) {

@@ -28,7 +28,7 @@ enum { OUT_STORE = 0, OUT_ADD = 1 };
 // Optional `pool`: also produce maxpool_act_forward(out) (2x2, stride 2, ceil mode, act = scale[m] * prelu(., *slope)) from the
 // accumulators; *pool_fused tells whether the launch could do it (3x3, plain store, one K split) -- otherwise the caller
 // runs maxpool_act_forward itself.
-struct IgemmPool { float* out; unsigned char* idx; const float* slope; const float* scale; };
+struct IgemmPool { float* out; unsigned char* idx; const float* slope; const float* scale; float* amax = nullptr; };   // amax: magnitude record of `out` (amax.h)
 int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* wp, const float* bias, int M, int k, int pad, float* out, int out_mode,
                double algo_flops, hipStream_t s, int ws_slot = 0,  // ws_slot: split-K workspace (0 | 1)

@@ -91,6 +91,9 @@ struct ClsLayer {
 
 using namespace frcnn;
 
+static int g_static_weights = 0;   // option "static_weights" (see forward_impl)
+static long g_static_gen = 0;      // bumped by every set_option("static_weights", v)
+
 struct frcnn_model {
   frcnn_model_desc d;
   std::vector<Conv> convs;     // backbone convs in order
@@ -114,6 +117,8 @@ struct frcnn_model {
   int n_amax = 0, n_amax_jobs = 0, amax_grid = 0;
   float* rec(int id) const { return (float*)amax.p + (size_t)id * AMAX_REC; }
   bool f16_packed = false;     // the current packs are in the fp16 form
+  long eval_packs_gen = -1;    // option static_weights: generation (g_static_gen) the evaluate-mode packs were made in, -1 = none
+  const float* eval_packs_w = nullptr;
   int n_x3_all = 0, n_x3_fwd = 0, x3_grid_all = 0, x3_grid_fwd = 0;
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
@@ -386,6 +391,7 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     }
   }
   m->H = H; m->W = W;
+  m->eval_packs_gen = -1;   // (pack buffers and job tables were rebuilt)
   return FRCNN_OK;
 }
 
@@ -513,6 +519,7 @@ int frcnn_get_option(const char* name, int* value) {
   if (strcmp(name, "side_stream") == 0) { *value = side_enabled() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { *value = get_gemm_x_roles(); return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
+  if (strcmp(name, "static_weights") == 0) { *value = g_static_weights; return FRCNN_OK; }
   if (strcmp(name, "winograd") == 0) { *value = 0; return FRCNN_OK; }   // removed in round 3; kept as a name that reads 0
   if (strcmp(name, "cnet_wgrad_async") == 0) { *value = g_cnet_wgrad_async; return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
@@ -525,6 +532,7 @@ int frcnn_set_option(const char* name, int value) {
   FR_CHECK(name != nullptr, "set_option: null name");
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
+  if (strcmp(name, "static_weights") == 0) { g_static_weights = value != 0; ++g_static_gen; return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   if (strcmp(name, "x3_f16") == 0) { set_x3_f16(value); return FRCNN_OK; }           // takes effect with the next forward pass
@@ -659,21 +667,29 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     }
   }
   FR_TRY(dropout_channel_masks(dj, s));
-  // weights change every optimiser step: refresh the packed copies (one table-driven launch)
+  // weights change every optimiser step: refresh the packed copies (one table-driven launch each).  Option static_weights: an
+  // evaluate-mode pass re-uses the packs of the previous evaluate-mode pass with the same weight vector -- the host's promise that
+  // it has not written the weights in between (a training-mode pass, a shape change and every frcnn_set_option("static_weights", v)
+  // call drop them).
   m->head_packs_fresh = false;
-  if (training)
-    FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
-  else
-    FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
   const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
+  const bool reuse = !training && g_static_weights && m->eval_packs_gen == g_static_gen && m->eval_packs_w == w && m->f16_packed == f16;
   m->f16_packed = f16;
-  const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
-  if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
-    FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p, m->n_amax_jobs, m->amax_grid, s));
-  if (training)
-    FR_TRY(conv_x3_pack_multi(w, xjobs, m->n_x3_all, m->x3_grid_all, s));
-  else
-    FR_TRY(conv_x3_pack_multi(w, xjobs + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
+  if (!reuse) {
+    if (training)
+      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
+    else
+      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
+    const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
+    if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
+      FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p, m->n_amax_jobs, m->amax_grid, s));
+    if (training)
+      FR_TRY(conv_x3_pack_multi(w, xjobs, m->n_x3_all, m->x3_grid_all, s));
+    else
+      FR_TRY(conv_x3_pack_multi(w, xjobs + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
+  }
+  m->eval_packs_gen = training ? -1 : g_static_gen;
+  m->eval_packs_w = w;
   FR_TRY(m->img.ensure((size_t)3 * H * W * 4));
   FR_HIP(hipMemcpyAsync(m->img.p, img, (size_t)3 * H * W * 4, hipMemcpyDeviceToDevice, s));
   const float* cur = m->img.f();
@@ -688,7 +704,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
       const bool last = st == blk.nconv - 1;
       // the block's max pool rides in the epilogue of its last convolution when that launch is a single K split
       IgemmPool pl = {blk.pooled.f(), (unsigned char*)blk.pidx.p, w + c.a_off,
-                      (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr};
+                      (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr, f16 ? m->rec(blk.am) : nullptr};
       // fp16 form: the next convolution reads c.x scaled by its largest magnitude, which the launch that writes c.x records
       const bool want_am = f16 && !last && m->convs[blk.first_conv + st + 1].x_f;
       if (c.x_f)
@@ -709,8 +725,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     if (!pooled_in_conv)
       FR_TRY(maxpool_act_forward(cur, lc.Cout, lc.Ho, lc.Wo, cur_slope, cur_scale, blk.pooled.f(),
                                  (unsigned char*)blk.pidx.p, s, f16 ? m->rec(blk.am) : nullptr));
-    else if (f16)   // (pooled inside the fp32 kernel of the first layer: a pass of its own over the pooled map)
-      FR_TRY(tensor_absmax(blk.pooled.f(), (long)lc.Cout * blk.Hp * blk.Wp, m->rec(blk.am), s));
+    // (pooled inside the fp32 kernel of the first layer: that launch kept the pooled map's record)
     cur = blk.pooled.f();
     cur_slope = nullptr;
     cur_scale = nullptr;
