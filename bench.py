@@ -240,20 +240,30 @@ def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
     nat = model["native"]
     wa = amplified(nat, w0, cfg["class_count"] + 1)
     weights.copy_(torch.from_numpy(wa)); nat.bn_running.copy_(torch.from_numpy(bn0))
-    d = F.Detector(model)
     host = [F.synthetic_image(FULL_H, FULL_W, i) for i in range(4)]
     imgs = [F.to_device(x) for x in host]
-    for i in range(4):
-        r = d.detect(imgs[i])
-    torch.cuda.synchronize()
     n = 40
-    t0 = time.perf_counter()
-    for i in range(n):
-        r = d.detect(imgs[i % 4])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+
+    def run(static):
+        det = F.Detector(model, static_weights=static)
+        if not static:
+            F._lib.call("frcnn_set_option", b"static_weights", 0)
+        for i in range(4):
+            res = det.detect(imgs[i])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            res = det.detect(imgs[i % 4])
+        torch.cuda.synchronize()
+        return det, res, (time.perf_counter() - t0) / n
+    # a detector serves a trained model: the weights do not change between frames and their packed / split copies are made once
+    # (option static_weights); the time with the copies remade for every frame, as a training loop's validation pass would, beside it
+    _, _, dt_repack = run(False)
+    d, r, dt = run(True)
     out = dict(metric="images/sec (vgg_small 800x450 inference: Detector:detect)", value=round(1.0 / dt, 2), ms_per_image=round(dt * 1e3, 3),
                frames=n, matches=int(d.last_scan["n"]), candidates=int(len(d.last_pick)), winners=len(r),
+               weights="packed once (frcnn_set_option static_weights = 1: the host does not write the weights between frames)",
+               ms_per_image_weights_repacked_every_frame=round(dt_repack * 1e3, 3),
                note="head logits amplified x30 (random weights would pass no anchor at p > 0.95)")
     # where a frame's time goes: 8 more frames with every kernel class bracketed by HIP events (outside the timed frames)
     nk = len(F._lib.KC_NAMES)
@@ -302,6 +312,7 @@ def inference_leg(F, cfg, model, weights, w0, bn0, with_cpu):
                              oracle_matches=int(len(ref["match_idx"])), oracle_candidates=int(len(ref["cand_ids"])),
                              oracle_winners=int(len(ref["winners"])))
     weights.copy_(torch.from_numpy(w0))
+    F._lib.call("frcnn_set_option", b"static_weights", 0)   # (the legs that follow write the weights)
     return out
 
 

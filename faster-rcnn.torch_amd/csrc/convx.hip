@@ -47,6 +47,9 @@ constexpr int cx_pp(int k) { return k == 3 ? CX_PP : k == 5 ? 240 : 308; }
 #define CX_NA 2                         // A ring slots
 #define CX_NB 1                         // patch buffers
 #define CX_NTMAX 128                    // pixels per block
+#ifndef CX_PREFETCH_B
+#define CX_PREFETCH_B 1                 // fp16 form: the next tap's patch fragments are read a product early (see the stage loop)
+#endif
 #define CX_ASTAGE (6 * CX_BM * 16)      // bytes of one A stage of a 128-filter block: [plane 3][half 2][128 filters][8 bf16]
 
 static int g_splitbf16 = -1;   // -1: not decided yet (environment FRCNN_SPLIT_BF16, default on)
@@ -592,6 +595,14 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   bool more = false;
   int stage = 0;
   const int nStages = nC * KK;
+  // NP = 2: the patch fragments of tap t + 1 are read under the last product of tap t -- the patch is valid for the whole chunk, only
+  // the A image waits for the stage's barrier -- so that behind a barrier a wave reads two A fragments, not four (FRCNN... see
+  // EXPERIMENTS.md round 5: with three products a stage has half the MFMAs to hide its LDS round trips behind)
+  frag_t nbH[NTW], nbL[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { nbH[i][j] = 0; nbL[i][j] = 0; }
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int par = KK % 2 == 0 ? 0 : (chunk - cbeg) & 1;   // A ring slot of the chunk's first tap
 #ifdef CX_TRACE
@@ -624,6 +635,15 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         if (more) load_patch(chunk + 1);
         readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
         readA(Ab, 0, aH); readB(Bs, tapoff, PL, bL);
+      } else if constexpr (NP == 2 && CX_PREFETCH_B) {
+        readA(Ab, PL, aL);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) { bH[i] = nbH[i]; bL[i] = nbL[i]; }
+        CX_FENCE();
+        mm(pAH, pBH);
+        CX_FENCE();
+        readA(Ab, 0, aH);
+        dma_stage(nxt, (tap + 1 + par) & 1);
       } else {
         readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
         CX_FENCE();
@@ -636,6 +656,13 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
       mm(aL, bH);
       CX_FENCE();
       if constexpr (NP == 2) {
+        if constexpr (CX_PREFETCH_B) {
+          if (tap + 1 < KK) {   // (compile-time: the tap loop is unrolled)
+            const int nky = (tap + 1) / KS, nkx = (tap + 1) - nky * KS;
+            readB(Bs, (nky * PW + nkx) * 16, 0, nbH); readB(Bs, (nky * PW + nkx) * 16, PL, nbL);
+            CX_FENCE();
+          }
+        }
         mm(aH, bL);
       } else {
         readA(Ab, 1, aM);

@@ -57,7 +57,17 @@ int frcnn_device_name(char *buf_host, int len);
  * "gemm_x_roles" (default -1; environment FRCNN_GEMM_X): which products of a large nn.Linear (the cnet's Linear(13824, 1024))
  * take the split-bf16 operand form of csrc/gemmx.hip -- bit 1 forward, 2 input gradient, 4 weight gradient; -1 = the
  * measured rule (the input gradient always; forward and weight gradient from 192 rows on, where they beat the fp32 kernels),
- * 0 = fp32 matrix-core kernels for all three. */
+ * 0 = fp32 matrix-core kernels for all three.
+ * "x3_f16" (default 1; environment FRCNN_X3_F16): the operand form of the split convolutions (with "split_bf16" on).  1 = two
+ * fp16 planes per operand and THREE exact partial products per fp32 product: each tensor is scaled by a power of two taken from
+ * its largest magnitude (recorded by the launch that wrote it), h = f16(x 2^e), l = f16(x 2^e - h), 22 significand bits per
+ * operand; measured against fp64 the error is that of the fp32 matrix-core kernels (tools/x3_f16_check.py,
+ * tests/test_gpu_convx.py run both forms).  0 = three bf16 planes and six partial products: the split is exact (24 bits, no
+ * dependence on the tensor's range) at twice the matrix-pipe time.  Takes effect with the next forward pass.
+ * "static_weights" (default 0): the host promises that it does not write the weight vector between evaluate-mode forward passes
+ * (Detector:detect on a trained model); the library then re-uses the packed / split copies of the convolution weights instead of
+ * remaking them per pass.  A training-mode pass, a change of the frame size and every frcnn_set_option("static_weights", v) call
+ * drop the copies -- a host that has written the weights itself says so by setting the option again. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 

@@ -412,6 +412,41 @@ def test_detect_first_nms_bound(F, setup):
         s["weights"].copy_(torch.from_numpy(s["w"]))
 
 
+def test_static_weights_reuses_packs_until_told(F, setup):
+    """Option static_weights: evaluate-mode passes re-use the packed weight copies -- same detections as with the copies remade
+    per frame; after the host writes the weights and says so (the option set again) the new weights are in effect."""
+    import torch
+    s = setup
+    model = s["model"]
+    w = _amplified_weights(model["native"], s["w"], 17, cls_gain=200.0)
+
+    def run(det, img):
+        win = det.detect(img)
+        return det.last_pick.tolist(), det.last_scan["p"].numpy().copy(), [(x["class"], x["confidence"]) for x in win]
+    try:
+        s["weights"].copy_(torch.from_numpy(w))
+        imgs = [F.synthetic_image(H, W, k) for k in (5, 6)]
+        plain = F.Detector(model)
+        want = [run(plain, im) for im in imgs]
+        d = F.Detector(model, static_weights=True)
+        for _ in range(2):   # (second round: the packs of the first are re-used)
+            got = [run(d, im) for im in imgs]
+            for a, b in zip(got, want):
+                assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        # new weights: without a word the stale packs would still be used (that is the contract) -- the host says so
+        w2 = w.copy(); w2[:model["native"].pnet_params] *= np.float32(0.5)
+        s["weights"].copy_(torch.from_numpy(w2))
+        F._lib.call("frcnn_set_option", b"static_weights", 1)
+        after = run(d, imgs[0])
+        F._lib.call("frcnn_set_option", b"static_weights", 0)
+        fresh = run(F.Detector(model), imgs[0])
+        assert after[0] == fresh[0] and np.array_equal(after[1], fresh[1])
+        assert not np.array_equal(after[1], want[0][1]) or len(after[1]) != len(want[0][1])
+    finally:
+        F._lib.call("frcnn_set_option", b"static_weights", 0)
+        s["weights"].copy_(torch.from_numpy(s["w"]))
+
+
 def test_sparse_head_backward_equals_dense(F, setup):
     """frcnn_pnet_set_sparse_deltas: the anchor-head backward restricted to the non-zero delta positions must
     give the gradient of the dense backward (same arithmetic on fewer pixels; fp32 summation order differs)."""

@@ -22,7 +22,7 @@ for off, cnt, kind, aux in nat.param_table:
     if kind == 3 and cnt == 512 * (cfg["class_count"] + 1):
         w[off:off + cnt] *= float(os.environ.get("CLS_GAIN", "200"))
 weights.copy_(torch.from_numpy(w))
-d = F.Detector(model)
+d = F.Detector(model)   # FRCNN_STATIC_WEIGHTS=1: the packed weight copies are made once, not per frame
 imgs = [F.to_device(F.synthetic_image(450, 800, i)) if hasattr(F, "to_device") else F.synthetic_image(450, 800, i) for i in range(4)]
 for i in range(3):
     r = d.detect(imgs[i % 4])
