@@ -44,7 +44,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define CX_PP 204                       // patch positions per (plane, half) in LDS (pitch) of the 3x3 kernels; patch plane <= CX_PP
 // the 5x5 / 7x7 instantiations take the patch of an 8 x 16-pixel tile: 12 x 20 / 14 x 22 positions (two blocks per CU)
 constexpr int cx_pp(int k) { return k == 3 ? CX_PP : k == 5 ? 240 : 308; }
-#define CX_NA 2                         // A ring slots
+#define CX_NA 2                         // A ring slots of the three-plane form
+#ifndef CX_RING2
+#define CX_RING2 4                       // ... of the two-plane form: one barrier per TWO taps (cx_ring)
+#endif
+constexpr int cx_ring(int np) { return np == 2 ? CX_RING2 : CX_NA; }
 #define CX_NB 1                         // patch buffers
 #define CX_NTMAX 128                    // pixels per block
 #ifndef CX_PREFETCH_B
@@ -460,7 +464,8 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   const int cend = min(cbeg + p.chunksPerSplit, p.nChunks);
 
   char* const As = smem;
-  char* const Bs = smem + CX_NA * AST;
+  constexpr int RING = cx_ring(NP);
+  char* const Bs = smem + RING * AST;
 
   // A stage DMA: 12 KB (128-filter blocks) / 6 KB = wave instructions of 1 KB, dealt round-robin to the four waves.
   // (global_load_lds, not the buffer form: with BOTH the ring DMA and the patch loads below on buffer resources the
@@ -590,11 +595,12 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   // and written, and a second barrier publishes it.
   load_patch(cbeg);
   dma_stage(0, 0);
+  const int nStages = nC * KK;
+  if constexpr (RING == 4) dma_stage(nStages > 1 ? 1 : 0, 1);
   store_patch(Bs);
   stamp(1);
   bool more = false;
   int stage = 0;
-  const int nStages = nC * KK;
   // NP = 2: the patch fragments of tap t + 1 are read under the last product of tap t -- the patch is valid for the whole chunk, only
   // the A image waits for the stage's barrier -- so that behind a barrier a wave reads two A fragments, not four (FRCNN... see
   // EXPERIMENTS.md round 5: with three products a stage has half the MFMAs to hide its LDS round trips behind)
@@ -603,6 +609,72 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { nbH[i][j] = 0; nbL[i][j] = 0; }
+  if constexpr (RING == 4) {
+    // ---- two-plane form: ring of FOUR stages, taps in groups (0,1) (2,3) ... (KK-1): ONE barrier per group.  At a group's
+    // barrier its stages have landed (requested at the previous group's barrier, a whole group of MFMAs ago) and every wave is done
+    // with the stages before it, whose slots the next group's request takes.  A follower tap has no wait and no barrier: its A
+    // fragments are read under the leader's products like the patch fragments.  (With three products a stage has 12 MFMAs per wave:
+    // a barrier per stage cost as much as it protected.)
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
+#ifdef CX_TRACE
+      if (chunk - cbeg < 24) stamp(8 + chunk - cbeg);
+#endif
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap, ++stage) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const char* const Ab = As + (stage & 3) * AST;
+        const int tapoff = (ky * PW + kx) * 16;
+        frag_t aL[2], aH[2], bL[NTW], bH[NTW];
+        constexpr int PL = 1;
+        const bool leader = (tap & 1) == 0;   // (compile-time: the tap loop is unrolled)
+        // the next group: taps (t+2, t+3), the single last tap, or the next chunk's (0, 1)
+        const int g1 = stage + (tap + 2 <= KK - 1 ? 2 : (tap == KK - 1 ? 1 : 2));
+        const bool two = tap == KK - 1 || tap + 3 <= KK - 1;
+        if (leader) {
+          if (tap == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NIT) : "memory");   // (the patch loads issued at tap 0 stay in flight)
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+        if (tap == 0) {
+          mm(pAH, pBH);
+          CX_FENCE();
+          if (chunk > cbeg) store_patch(Bs);
+          dma_stage(min(g1, nStages - 1), g1 & 3);
+          if (two) dma_stage(min(g1 + 1, nStages - 1), (g1 + 1) & 3);
+          __syncthreads();
+          more = chunk + 1 < cend;
+          if (more) load_patch(chunk + 1);
+          readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
+          readA(Ab, 0, aH); readB(Bs, tapoff, PL, bL);
+        } else {
+          readA(Ab, PL, aL);
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) { bH[i] = nbH[i]; bL[i] = nbL[i]; }
+          CX_FENCE();
+          mm(pAH, pBH);
+          CX_FENCE();
+          readA(Ab, 0, aH);
+          if (leader) {
+            dma_stage(min(g1, nStages - 1), g1 & 3);
+            if (two) dma_stage(min(g1 + 1, nStages - 1), (g1 + 1) & 3);
+          }
+        }
+        CX_FENCE();
+        mm(aL, bH);
+        CX_FENCE();
+        if (tap + 1 < KK) {
+          const int nky = (tap + 1) / KS, nkx = (tap + 1) - nky * KS;
+          readB(Bs, (nky * PW + nkx) * 16, 0, nbH); readB(Bs, (nky * PW + nkx) * 16, PL, nbL);
+          CX_FENCE();
+        }
+        mm(aH, bL);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pAH[i] = aH[i];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) pBH[i] = bH[i];
+      }
+    }
+  } else
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int par = KK % 2 == 0 ? 0 : (chunk - cbeg) & 1;   // A ring slot of the chunk's first tap
 #ifdef CX_TRACE
@@ -990,7 +1062,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   // (the wide epilogue turns four 64 x 32 fp32 tiles over in LDS: 32 KB)
   static const size_t lds_min = getenv("FRCNN_X3_LDS_MIN") ? (size_t)atol(getenv("FRCNN_X3_LDS_MIN")) : 0;   // (experiments: fewer blocks per CU)
-  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)CX_NA * (2 * NP * 64 * WM * 16) + (size_t)CX_NB * (2 * NP * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
+  const size_t lds = std::max(lds_min, std::max<size_t>((size_t)cx_ring(NP) * (2 * NP * 64 * WM * 16) + (size_t)CX_NB * (2 * NP * cx_pp(KS) * 16), a.wide ? 4 * 64 * 32 * 4 : 0));
   FR_LAUNCH(KC_CONV_X3, flops, bytes, s, (conv_x3_kernel<KS, WM, SLOPE, SCALE, EPI, NP>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
 #ifdef CX_TRACE
