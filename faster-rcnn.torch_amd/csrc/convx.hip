@@ -139,7 +139,7 @@ __device__ __forceinline__ void split8h(const float* v, uint4& H, uint4& L) {
 // exponent e with amax * 2^e in [2^top, 2^(top+1)); 0 for an all-zero tensor
 __device__ __forceinline__ int x16_exp(float amax, int top) {
   const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
-  if (be == 0) return 0;
+  if (be == 0 || be == 255) return 0;   // all zero -- or an infinity somewhere: no scaling (the finite elements keep fp16's own range)
   const int e = top - (be - 127);
   return e < -100 ? -100 : e > 100 ? 100 : e;
 }
@@ -432,13 +432,14 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
     gsel[it] = g;
   }
   const float slope = SLOPE ? *p.in_slope : 1.f;
-  float in_mul = 1.f, out_mul = 1.f;
+  float in_mul = 1.f, out_mul = 1.f, out_mul2 = 1.f;   // (the inverse scale in two halves: 2^-(ei + ew) need not be an fp32 number)
   if (NP == 2) {   // (headroom of one binade for a dropout scale: its entries are <= 1 in both modes, see net.cpp)
     float ai = amax_load_block(p.amax_in);
     if (SLOPE) ai *= fmaxf(1.f, fabsf(slope));
     const int ei = x16_exp(ai, SCALE ? 13 : 14), ew = x16_exp(*p.amax_w, 14);
     in_mul = x16_pow2(ei);
-    out_mul = x16_pow2(-(ei + ew));
+    const int et = -(ei + ew), e1 = et / 2;
+    out_mul = x16_pow2(e1); out_mul2 = x16_pow2(et - e1);
   }
 
   // ---- lane offsets of the MFMA operand reads
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
 #pragma unroll
       for (int b = 0; b < NTW; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] *= out_mul;
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = (acc[a][b][r] * out_mul) * out_mul2;
   }
 
   // ---- epilogue: D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (filter).  Every filter row of the

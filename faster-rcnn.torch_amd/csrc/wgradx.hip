@@ -86,7 +86,7 @@ __device__ __forceinline__ unsigned wx_cvt2h(float a, float b) {
 // (convx.hip's x16_exp / x16_pow2: the power of two that puts a tensor's largest magnitude into [2^top, 2^(top+1)))
 __device__ __forceinline__ int wx_exp(float amax, int top) {
   const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
-  if (be == 0) return 0;
+  if (be == 0 || be == 255) return 0;   // all zero -- or an infinity somewhere: no scaling (the finite elements keep fp16's own range)
   const int e = top - (be - 127);
   return e < -100 ? -100 : e > 100 ? 100 : e;
 }
@@ -170,13 +170,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   const int o0 = ot * 64, c0 = ct * 64;
   const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
   const float slope = SLOPE ? *p.in_slope : 1.f;
-  float gmul = 1.f, xmul = 1.f, out_mul = 1.f;
+  float gmul = 1.f, xmul = 1.f, out_mul = 1.f, out_mul2 = 1.f;   // (the inverse scale in two halves: 2^-(eg + ex) need not be an fp32 number)
   if (NP == 2) {
     const float ag = amax_load_block(p.amax_g);
     float ax = amax_load_block(p.amax_in);
     if (SLOPE) ax *= fmaxf(1.f, fabsf(slope));
     const int eg = wx_exp(ag, 14), ex = wx_exp(ax, SCALE ? 13 : 14);   // (a dropout scale's entries are <= 1: one binade of headroom)
-    gmul = wx_pow2(eg); xmul = wx_pow2(ex); out_mul = wx_pow2(-(eg + ex));
+    gmul = wx_pow2(eg); xmul = wx_pow2(ex);
+    const int et = -(eg + ex), e1 = et / 2;
+    out_mul = wx_pow2(e1); out_mul2 = wx_pow2(et - e1);
   }
 
   f32x16 acc[9];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        sl[(size_t)tap * OC + (size_t)o * p.Cin + c] = NP == 2 ? acc[tap][r] * out_mul : acc[tap][r];
+        sl[(size_t)tap * OC + (size_t)o * p.Cin + c] = NP == 2 ? (acc[tap][r] * out_mul) * out_mul2 : acc[tap][r];
       }
   }
 }

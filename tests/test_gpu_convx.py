@@ -196,6 +196,52 @@ def test_exactness_properties_at_full_size(F, x3_form):
     assert not r.any()
 
 
+@pytest.mark.parametrize("xs,ws,gs", [(0.0, 1.0, 0.0), (1e-30, 1.0, 1e10), (1e30, 1e-8, 1e-20), (1e-20, 1e-15, 1e20), (3e4, 7e3, 1.0)])
+def test_two_plane_form_at_the_ends_of_the_range(F, O, xs, ws, gs):
+    """The fp16 form scales each tensor by a power of two taken from its largest magnitude: an all-zero tensor, magnitudes near the
+    ends of the fp32 range and products that would overflow fp16 many times over must all come out as the fp32 convolution
+    (forward, input gradient and weight gradient; relative to the largest output; the scales are chosen so that the RESULTS are
+    fp32 numbers -- the sum of the two tensors' exponents is not, which is why the kernels undo the scaling in two halves)."""
+    before = _option(F, "x3_f16")
+    _option(F, "x3_f16", 1)
+    try:
+        rng = np.random.RandomState(11)
+        C_, H, W, O_, pad = 64, 19, 28, 128, 1
+        x = (rng.randn(C_, H, W) * xs).astype(np.float32)
+        w = (rng.randn(O_, C_, 3, 3) * ws).astype(np.float32)
+        g = (rng.randn(O_, H, W) * gs).astype(np.float32)
+        dx, dw, dg = _dev(F, x), _dev(F, w), _dev(F, g)
+        out = F.DeviceTensor.empty((O_, H, W)); gin = F.DeviceTensor.empty((C_, H, W)); gw = F.DeviceTensor.zeros((O_, C_, 3, 3))
+        F._lib.call("frcnn_conv2d_forward", F.ptr(dx), C_, H, W, None, None, F.ptr(dw), None, O_, 3, pad, F.ptr(out), F.stream_ptr())
+        F._lib.call("frcnn_conv2d_backward_input", F.ptr(dg), O_, H, W, F.ptr(dw), C_, 3, pad, F.ptr(gin), 0, F.stream_ptr())
+        F._lib.call("frcnn_conv2d_backward_weight", F.ptr(dx), C_, H, W, None, None, F.ptr(dg), O_, 3, pad, F.ptr(gw), None, F.stream_ptr())
+        x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+        for got, name in ((out.numpy(), "forward"), (gin.numpy(), "input gradient"), (gw.numpy(), "weight gradient")):
+            assert np.isfinite(got).all(), "%s: not finite" % name
+        if xs == 0.0:
+            assert not out.numpy().any() and not gin.numpy().any() and not gw.numpy().any()
+            return
+        # references in fp64 by the definition (small shape)
+        xp = np.pad(x64, ((0, 0), (1, 1), (1, 1)))
+        ref_y = np.zeros((O_, H, W)); ref_gw = np.zeros((O_, C_, 3, 3))
+        for ky in range(3):
+            for kx in range(3):
+                patch = xp[:, ky:ky + H, kx:kx + W]
+                ref_y += np.einsum("oc,chw->ohw", w64[:, :, ky, kx], patch)
+                ref_gw[:, :, ky, kx] = np.einsum("ohw,chw->oc", g64, patch)
+        gp = np.pad(g64, ((0, 0), (1, 1), (1, 1)))
+        ref_gin = np.zeros((C_, H, W))
+        for ky in range(3):
+            for kx in range(3):
+                ref_gin += np.einsum("oc,ohw->chw", w64[:, :, 2 - ky, 2 - kx], gp[:, ky:ky + H, kx:kx + W])
+        for got, ref, name in ((out.numpy(), ref_y, "forward"), (gin.numpy(), ref_gin, "input gradient"), (gw.numpy(), ref_gw, "weight gradient")):
+            scale = np.abs(ref).max()
+            assert scale > 0
+            assert np.abs(got.astype(np.float64) - ref).max() <= 1e-5 * scale, (name, np.abs(got - ref).max() / scale)
+    finally:
+        _option(F, "x3_f16", before)
+
+
 @pytest.mark.parametrize("C_,H,W,O_,pad", [(64, 57, 100, 128, 1), (128, 29, 50, 64, 1), (256, 38, 63, 512, 1), (64, 9, 11, 64, 1),
                                             (64, 31, 45, 64, 0), (64, 75, 125, 64, 1), (128, 37, 250, 64, 1)])
 def test_weight_gradient(F, O, both_forms, x3_form, C_, H, W, O_, pad):
