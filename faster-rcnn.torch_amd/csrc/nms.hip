@@ -115,10 +115,12 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
   mask[(size_t)rpos * nw + cb] = bits;
 }
 
-// Greedy scan in sorted order, 64 boxes per step.  Wave 0 resolves the 64 x 64 diagonal block serially in
-// registers (the next step's diagonal words are already in flight); then ALL 1024 threads OR the mask rows of
-// the boxes kept in this step into the `removed` bit set (LDS, ds_or_b64): (kept row, word) pairs are dealt
-// round-robin, so the global loads of one step are independent and coalesced along the words.
+// Greedy scan in sorted order, 64 boxes per step, as a two-stage pipeline with ONE barrier per step.  In step g wave 0 resolves
+// the 64 x 64 diagonal block of group g serially in registers (the next step's diagonal words are already in flight), emits the
+// picks, and ORs word g + 1 of the rows it kept into `removed` -- the only word step g + 1 needs from them.  The other fifteen
+// waves meanwhile OR the REST of the mask rows (words >= g + 1) of the boxes kept in step g - 1.  So at the start of step g + 1 word
+// g + 1 holds every contribution: group g's by wave 0, group g - 1's by the background waves, older groups' by earlier steps.
+// (Round 4's scan had the two phases one after the other behind a barrier each: 1.5 us a step, 229 us a frame of Detector:detect.)
 #define NMS_RED_THREADS 1024
 __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
                                                                      const int* __restrict__ sorted, int n,
@@ -127,20 +129,22 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsig
   extern __shared__ unsigned long long removed[];  // [nw]
   if (n_dev) n = min(*n_dev, n);
   const int nw = (n + 63) >> 6;   // words of this run; nwp = pitch of the mask rows (the host-side bound)
-  __shared__ int kept_list[64];
-  __shared__ int nkept;
+  __shared__ int kept_list[2][64];
+  __shared__ int nkept[2];
   __shared__ int cnt;
   for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
-  if (threadIdx.x == 0) cnt = 0;
+  if (threadIdx.x == 0) { cnt = 0; nkept[0] = nkept[1] = 0; }
   unsigned long long diag_next = 0ull;
   if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * nwp];
   __syncthreads();
   for (int g = 0; g < nw; ++g) {
-    if (threadIdx.x < 64) {  // wave 0 resolves the diagonal block sequentially
+    if (threadIdx.x < 64) {  // wave 0: group g
       const int row = g * 64 + threadIdx.x;
       const unsigned long long diag = diag_next;
       const int nrow = row + 64;
       if (g + 1 < nw) diag_next = nrow < n ? mask[(size_t)nrow * nwp + g + 1] : 0ull;
+      // this row's word g + 1, requested before the serial part (needed only if the row is kept)
+      const unsigned long long urgent = (g + 1 < nw && row < n) ? mask[(size_t)row * nwp + g + 1] : 0ull;
       // wave-uniform bit sets in scalar registers; one step per KEPT box (first clear bit), not per box
       const unsigned long long w0 = removed[g];
       unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
@@ -156,25 +160,27 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsig
                                       (unsigned)__builtin_amdgcn_readlane(dlo, t);
         word |= dt | (1ull << t);
       }
-      // emit picks in order
+      // emit picks in order; the kept rows' word g + 1 goes into `removed` now, the rest of their rows in the next step
       const int base = cnt;
       if ((kept >> threadIdx.x) & 1ull) {
         const int before = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
         pick[base + before] = (long long)sorted[row] + 1;  // 1-based like the Lua surface
-        kept_list[before] = row;
+        kept_list[g & 1][before] = row;
+        if (urgent) atomicOr(&removed[g + 1], urgent);
       }
       if (threadIdx.x == 0) {
-        nkept = __popcll(kept);
+        nkept[g & 1] = __popcll(kept);
         cnt = base + __popcll(kept);
       }
-    }
-    __syncthreads();
-    const int nk = nkept, W = nw - (g + 1);
-    const int items = nk * W;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-      const int q = it / W, w = g + 1 + (it - q * W);
-      const unsigned long long v = mask[(size_t)kept_list[q] * nwp + w];
-      if (v) atomicOr(&removed[w], v);
+    } else if (g > 0) {      // waves 1..15: the rest of the rows kept in step g - 1 (their word g went in during that step)
+      const int nk = nkept[(g - 1) & 1], W = nw - (g + 1);
+      const int items = nk * W;
+      const int* kl = kept_list[(g - 1) & 1];
+      for (int it = (int)threadIdx.x - 64; it < items; it += NMS_RED_THREADS - 64) {
+        const int q = it / W, w = g + 1 + (it - q * W);
+        const unsigned long long v = mask[(size_t)kl[q] * nwp + w];
+        if (v) atomicOr(&removed[w], v);
+      }
     }
     __syncthreads();
   }
