@@ -348,8 +348,14 @@ int frcnn_linear_forward(const float* x, int R, int I, const float* weight, cons
   if (linear_x_eligible(1, R, I, O)) {   // split-bf16 operand form (gemmx.hip); the model runtime keeps the planes resident
     void* xp = nullptr;
     FR_HIP(hipMalloc(&xp, (size_t)3 * R * I * 2));
-    int rc = split_planes(x, R, I, xp, nullptr, S(stream));
-    if (rc == FRCNN_OK) rc = linear_x_forward(xp, R, I, weight, bias, O, y, S(stream));
+    float* am = x3_f16_scalars(3);   // (two-plane fp16 form: records of x and of the weight matrix)
+    int rc = FRCNN_OK;
+    if (am) {
+      rc = tensor_absmax(x, (long)R * I, am, S(stream));
+      if (rc == FRCNN_OK) rc = tensor_absmax(weight, (long)O * I, am + AMAX_REC, S(stream));
+    }
+    if (rc == FRCNN_OK) rc = split_planes(x, R, I, xp, nullptr, S(stream), am);
+    if (rc == FRCNN_OK) rc = linear_x_forward(xp, R, I, weight, bias, O, y, S(stream), 0, nullptr, am, am ? am + AMAX_REC : nullptr);
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(xp);
     return rc;
@@ -370,9 +376,15 @@ int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const f
     };
     if (xd) alloc(&gp, (size_t)3 * R * O * 2);
     if (xw) { alloc(&gpT, (size_t)3 * O * Rp * 2); alloc(&xpT, (size_t)3 * I * Rp * 2); }
-    if (rc == FRCNN_OK) rc = split_planes(gy, R, O, gp, gpT, S(stream));
+    float* am = xd ? x3_f16_scalars(3) : nullptr;   // (two-plane fp16 form of the input-gradient product)
+    if (rc == FRCNN_OK && am) {
+      rc = tensor_absmax(gy, (long)R * O, am, S(stream));
+      if (rc == FRCNN_OK) rc = tensor_absmax(weight, (long)O * I, am + AMAX_REC, S(stream));
+      if (rc == FRCNN_OK) rc = split_planes(gy, R, O, gp, nullptr, S(stream), am);
+      if (rc == FRCNN_OK && gpT) rc = split_planes(gy, R, O, nullptr, gpT, S(stream));
+    } else if (rc == FRCNN_OK) rc = split_planes(gy, R, O, gp, gpT, S(stream));
     if (rc == FRCNN_OK && xw) rc = split_planes(x, R, I, nullptr, xpT, S(stream));
-    if (rc == FRCNN_OK && xd) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream));
+    if (rc == FRCNN_OK && xd) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream), 0, nullptr, am, am ? am + AMAX_REC : nullptr);
     if (rc == FRCNN_OK && xw) rc = linear_x_wgrad(gpT, xpT, R, O, I, gweight, S(stream));
     (void)hipStreamSynchronize(S(stream));
     (void)hipFree(gp); (void)hipFree(gpT); (void)hipFree(xpT);

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "amax.h"
 
 namespace frcnn {
 
@@ -25,6 +26,8 @@ typedef float xf32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 xf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 xf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) unsigned g_xzero16[4] = {0u, 0u, 0u, 0u};
 
@@ -50,6 +53,32 @@ __device__ __forceinline__ void x_split8(const float* v, uint4& H, uint4& Mi, ui
   L = make_uint4(ll[0], ll[1], ll[2], ll[3]);
 }
 
+// ---- the two-plane fp16 form (convx.hip): x 2^e = h + l, e from the tensor's largest magnitude (its record, amax.h)
+__device__ __forceinline__ unsigned x_cvt2h(float a, float b) {
+  xf32x2 v = {a, b};
+  xf16x2 r = __builtin_convertvector(v, xf16x2);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void x_split8h(const float* v, uint4& H, uint4& L) {
+  unsigned hh[4], ll[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    hh[j] = x_cvt2h(x0, x1);
+    const xf16x2 hv = __builtin_bit_cast(xf16x2, hh[j]);
+    ll[j] = x_cvt2h(x0 - (float)hv[0], x1 - (float)hv[1]);
+  }
+  H = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  L = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+__device__ __forceinline__ int gx_exp(float amax, int top) {
+  const int be = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
+  if (be == 0 || be == 255) return 0;
+  const int e = top - (be - 127);
+  return e < -100 ? -100 : e > 100 ? 100 : e;
+}
+__device__ __forceinline__ float gx_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
 // ------------------------------------------------------------------------------------------ activation planes
 // src [R][C] fp32  ->  P  [3][C/8][R][8] bf16   (the matrix as the k-contiguous operand with rows = R, k = C)
 //                  and PT [3][Rp/8][C][8] bf16  (its transpose: rows = C, k = R, rows R..Rp-1 of k zero).
@@ -58,9 +87,12 @@ __device__ __forceinline__ void x_split8(const float* v, uint4& H, uint4& Mi, ui
 // consecutive memory per wave instruction (whole 128-byte lines; row-major planes made every lane touch a line of its own
 // and the kernel ran at the rate of the texture addresser, 4x below this).  Either destination may be null.  One block =
 // a 64 x 64 tile through LDS: coalesced reads, 16-byte coalesced writes both ways.
+template <int NP>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int C, int Rp,
-                                                           unsigned short* __restrict__ P, unsigned short* __restrict__ PT) {
+                                                           unsigned short* __restrict__ P, unsigned short* __restrict__ PT,
+                                                           const float* __restrict__ amax) {
   __shared__ float tile[64 * 65];
+  const float mul = NP == 2 ? gx_pow2(gx_exp(amax_load_block(amax), 14)) : 1.f;
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 256) {
     const int r = e >> 6, c = e & 63;
@@ -74,13 +106,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
       if (r0 + r < R && c0 + c8 < C) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tile[r * 65 + c8 + j];
+        for (int j = 0; j < 8; ++j) v[j] = tile[r * 65 + c8 + j] * mul;
         uint4 H, Mi, L;
-        x_split8(v, H, Mi, L);
         unsigned short* d = P + ((size_t)((c0 + c8) >> 3) * R + r0 + r) * 8;
-        *reinterpret_cast<uint4*>(d) = H;
-        *reinterpret_cast<uint4*>(d + plane) = Mi;
-        *reinterpret_cast<uint4*>(d + 2 * plane) = L;
+        if (NP == 2) {
+          x_split8h(v, H, L);
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + plane) = L;
+        } else {
+          x_split8(v, H, Mi, L);
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + plane) = Mi;
+          *reinterpret_cast<uint4*>(d + 2 * plane) = L;
+        }
       }
     }
     if (PT) {  // 8 consecutive rows (one k group of the transpose) of one column; consecutive threads, consecutive columns
@@ -102,12 +140,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 int linear_x_rows_padded(int R) { return (R + 15) & ~15; }
 
-int split_planes(const float* src, int R, int C, void* P, void* PT, hipStream_t s) {
+int split_planes(const float* src, int R, int C, void* P, void* PT, hipStream_t s, const float* amax) {
   FR_CHECK(C % 8 == 0, "split_planes: %d columns (a multiple of 8 is needed for 16-byte plane entries)", C);
+  FR_CHECK(!amax || !PT, "split_planes: the two-plane fp16 form has no transposed planes (the weight-gradient product takes three bf16 planes)");
   const int Rp = linear_x_rows_padded(R);
   dim3 grid(cdiv(C, 64), cdiv(Rp, 64));
-  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * C * (4.0 + (P ? 6.0 : 0.0) + (PT ? 6.0 : 0.0)), s, split_planes_kernel, grid, dim3(256), 0,
-            src, R, C, Rp, (unsigned short*)P, (unsigned short*)PT);
+  if (amax)
+    FR_LAUNCH(KC_ELEMWISE, 0, (double)R * C * 8.0, s, split_planes_kernel<2>, grid, dim3(256), 0,
+              src, R, C, Rp, (unsigned short*)P, (unsigned short*)PT, amax);
+  else
+  FR_LAUNCH(KC_ELEMWISE, 0, (double)R * C * (4.0 + (P ? 6.0 : 0.0) + (PT ? 6.0 : 0.0)), s, split_planes_kernel<3>, grid, dim3(256), 0,
+            src, R, C, Rp, (unsigned short*)P, (unsigned short*)PT, amax);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -122,6 +165,8 @@ struct GxArgs {
   const float* bias;
   int M, N, K, kPerSplit, out_mode;   // 0 store, 1 add, 3 split-K slab [split][M][N]
   int tm, tn;                         // row / column tiles (the grid is one-dimensional: tm * tn * splits blocks)
+  const float* amax_a;                // NP = 2 (fp32-weight modes): magnitude records of the A tensor and of the weights (amax.h)
+  const float* amax_b;
 };
 
 // Block = TM (64 | 128 | 192 | 256) rows x 256 columns, EIGHT waves as 2 (rows) x 4 (columns): a wave owns TM / 2 rows x 64
@@ -136,28 +181,36 @@ struct GxArgs {
 // ring - 1 steps ahead, counted vmcnt, one barrier per step; one block per CU.
 #define GX_TN 256
 #define GX_LDS_MAX (160 * 1024)
-constexpr int gx_stage_bytes(int TM, int BMODE) { return 96 * TM + (BMODE == 0 ? 96 * GX_TN : 64 * GX_TN); }
+constexpr int gx_stage_bytes(int TM, int BMODE, int NP = 3) { return 32 * NP * TM + (BMODE == 0 ? 32 * NP * GX_TN : 64 * GX_TN); }
 // Tiles of up to 128 rows are laid out for TWO blocks per CU (<= 80 KB of LDS, <= 128 registers): two independent blocks
 // fill each other's barrier and fragment-latency bubbles (Linear(13824,1024) input gradient, 64-row tiles: 99 us with a
 // ring of three = 66 KB, 121 us with a ring of four = 88 KB and one block per CU); taller tiles own the CU.
 constexpr int gx_blocks_per_cu(int TM) { return TM <= 128 ? 2 : 1; }
-constexpr int gx_ring(int TM, int BMODE) {
-  const int room = GX_LDS_MAX / gx_blocks_per_cu(TM) / gx_stage_bytes(TM, BMODE);
+constexpr int gx_ring(int TM, int BMODE, int NP = 3) {
+  const int room = (GX_LDS_MAX - (NP == 2 ? 1024 : 0)) / gx_blocks_per_cu(TM) / gx_stage_bytes(TM, BMODE, NP);   // (NP = 2 has static words: amax.h)
   return room < 2 ? 2 : room > 4 ? 4 : room;
 }
 template <int N> __device__ __forceinline__ void gx_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int WM, int BMODE>
+template <int TM, int WM, int BMODE, int NP = 3>
 __global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_kernel(GxArgs p) {
+  static_assert(NP == 3 || BMODE != 0, "the two-plane form is built for the fp32-weight modes");
   constexpr int RW = TM / WM, MTW = RW / 32, NTW = WM;  // rows of one wave, its 32-row tiles and its 32-column tiles
-  constexpr int SA = 96 * TM;                           // bytes of one A stage: [plane 3][half 2][TM rows][8 bf16]
+  constexpr int SA = 32 * NP * TM;                      // bytes of one A stage: [plane NP][half 2][TM rows][8 x 16 bit]
   constexpr int SB = BMODE == 0 ? 96 * GX_TN : 64 * GX_TN;   // B stage: planes | [256 n][4 chunks of 4 k] | [16 k][256 n] fp32
   constexpr int NA = SA / 1024, NB = SB / 1024;         // wave instructions (1 KB each) per stage
   constexpr int IA = (NA + 7) / 8, IB = NB / 8;         // ... per wave (A: the last ones may repeat a slot -- same bytes twice)
   static_assert(NB % 8 == 0, "B stage must deal evenly to the eight waves");
   constexpr int SS = SA + SB;
-  constexpr int RING = gx_ring(TM, BMODE);
+  constexpr int RING = gx_ring(TM, BMODE, NP);
   extern __shared__ __attribute__((aligned(16))) char xsm[];
+  float wmul = 1.f, out_mul = 1.f, out_mul2 = 1.f;   // NP = 2: weight scale; the inverse of both scales in two halves
+  if (NP == 2) {
+    const int ea = gx_exp(amax_load_block(p.amax_a), 14), ew = gx_exp(amax_load_block(p.amax_b), 14);
+    wmul = gx_pow2(ew);
+    const int et = -(ea + ew), e1 = et / 2;
+    out_mul = gx_pow2(e1); out_mul2 = gx_pow2(et - e1);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WM == 2 ? wave >> 2 : 0, wn = WM == 2 ? wave & 3 : wave;
@@ -259,19 +312,19 @@ __global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_ker
     // a block that owns its CU issues every fragment read of the step before the first MFMA (left alone the scheduler sinks
     // each group of reads to just before its use and waits lgkmcnt(0) five times a step); the two-per-CU tiles leave the
     // order to the compiler -- all fragments live at once would not fit their 128 registers
-    xbf16x8 bp[NTW][3], ap[MTW][3];
+    uint4 bp[NTW][3], ap[MTW][3];
     auto load_a = [&](int pl) {
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
-        ap[mt][pl] = *reinterpret_cast<const xbf16x8*>(A_ + ((pl * 2 + h) * TM + arow + mt * 32) * 16);
+        ap[mt][pl] = *reinterpret_cast<const uint4*>(A_ + ((pl * 2 + h) * TM + arow + mt * 32) * 16);
     };
     if (BMODE == 0) {
       auto load_b = [&](int pl) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          bp[nt][pl] = *reinterpret_cast<const xbf16x8*>(B_ + ((pl * 2 + h) * GX_TN + bcol + nt * 32) * 16);
+          bp[nt][pl] = *reinterpret_cast<const uint4*>(B_ + ((pl * 2 + h) * GX_TN + bcol + nt * 32) * 16);
       };
-      load_a(2); load_b(0); load_a(0); load_b(2); load_a(1); load_b(1);
+      load_a(2); load_b(0); load_a(0); load_b(2); load_a(1); load_b(1);   // (BMODE 0 is a three-plane mode)
     } else {
       float vv[NTW][8];
 #pragma unroll
@@ -289,27 +342,46 @@ __global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_ker
           for (int j = 0; j < 8; ++j) vv[nt][j] = Bf[(8 * h + j) * GX_TN + col];
         }
       }
-      load_a(2); load_a(0); load_a(1);
+      if constexpr (NP == 2) { load_a(1); load_a(0); } else { load_a(2); load_a(0); load_a(1); }
       if constexpr (gx_blocks_per_cu(TM) == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {   // the weight fragments are split while the A fragments are on their way
         uint4 H, Mi, L;
-        x_split8(vv[nt], H, Mi, L);
-        bp[nt][0] = __builtin_bit_cast(xbf16x8, H);
-        bp[nt][1] = __builtin_bit_cast(xbf16x8, Mi);
-        bp[nt][2] = __builtin_bit_cast(xbf16x8, L);
+        if constexpr (NP == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[nt][j] *= wmul;
+          x_split8h(vv[nt], H, L);
+          bp[nt][0] = H; bp[nt][1] = L;
+        } else {
+          x_split8(vv[nt], H, Mi, L);
+          bp[nt][0] = H; bp[nt][1] = Mi; bp[nt][2] = L;
+        }
       }
     }
     if constexpr (gx_blocks_per_cu(TM) == 1) __builtin_amdgcn_sched_barrier(0);
     // smallest partial products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); plane index 0 = h, 1 = m, 2 = l
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    // (two fp16 planes: (l,h) (h,l) (h,h); plane index 0 = h, 1 = l)
+    constexpr int NQ = NP == 2 ? 3 : 6;
+    constexpr int PA[6] = {NP == 2 ? 1 : 2, 0, NP == 2 ? 0 : 1, 1, 0, 0}, PB[6] = {0, NP == 2 ? 1 : 2, NP == 2 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NQ; ++t)
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[mt][PA[t]], bp[nt][PB[t]], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) {
+          if constexpr (NP == 2)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(xf16x8, ap[mt][PA[t]]), __builtin_bit_cast(xf16x8, bp[nt][PB[t]]), acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, ap[mt][PA[t]]), __builtin_bit_cast(xbf16x8, bp[nt][PB[t]]), acc[mt][nt], 0, 0, 0);
+        }
+  }
+  if (NP == 2) {   // undo the two tensors' scales
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+      for (int b = 0; b < NTW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = (acc[a][b][r] * out_mul) * out_mul2;
   }
 
   // ---- epilogue: D layout col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m).  The accumulate mode reads the
@@ -365,16 +437,16 @@ bool linear_x_eligible(int role, int R, int I, int O) {
   return role == 2 || R >= 192;
 }
 
-template <int TM, int WM, int BMODE>
+template <int TM, int WM, int BMODE, int NP = 3>
 static int launch_gx(GxArgs& a, dim3 grid, double flops, double bytes, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<TM, WM, BMODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS_MAX));
+    FR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<TM, WM, BMODE, NP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS_MAX - (NP == 2 ? 1024 : 0)));
     attr_set = true;
   }
-  const size_t lds = (size_t)gx_ring(TM, BMODE) * gx_stage_bytes(TM, BMODE);
-  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_planes_kernel<TM, WM, BMODE>), grid, dim3(512), lds, a);
+  const size_t lds = (size_t)gx_ring(TM, BMODE, NP) * gx_stage_bytes(TM, BMODE, NP);
+  FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_planes_kernel<TM, WM, BMODE, NP>), grid, dim3(512), lds, a);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -418,6 +490,12 @@ static int launch_gx_tm(int TM, GxArgs& a, dim3 grid, double flops, double bytes
       case 128: return launch_gx<128, 2, 0>(a, grid, flops, bytes, s);
       default: return launch_gx<64, 2, 0>(a, grid, flops, bytes, s);
     }
+  } else if (a.amax_a) {   // two fp16 planes x fp32 weights split in registers
+    switch (TM) {
+      case 192: return launch_gx<192, 1, BMODE, 2>(a, grid, flops, bytes, s);
+      case 128: return launch_gx<128, 1, BMODE, 2>(a, grid, flops, bytes, s);
+      default: return launch_gx<64, 1, BMODE, 2>(a, grid, flops, bytes, s);
+    }
   } else {
     switch (TM) {
       case 192: return launch_gx<192, 1, BMODE>(a, grid, flops, bytes, s);
@@ -459,9 +537,11 @@ static int gx_run(GxArgs& a, int bmode, int splitK_max, float* user_C, const flo
 
 // Y[R][O] = X W^T + b ; Xp = planes of X, [3][I/8][R][8]
 int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot,
-                     GemmFold* defer) {
+                     GemmFold* defer, const float* amax_x, const float* amax_w) {
   FR_CHECK(((uintptr_t)W & 3) == 0 && I % 16 == 0, "linear_x_forward: operand alignment");
+  FR_CHECK((amax_x != nullptr) == (amax_w != nullptr), "linear_x_forward: the fp16 form needs the records of both operands");
   GxArgs a;
+  a.amax_a = amax_x; a.amax_b = amax_w;
   a.Ap = (const unsigned short*)Xp; a.aPlane = (long)R * I; a.aLd = R;
   a.B = W; a.bPlane = 0; a.bLd = I;
   a.ldc = O; a.M = R; a.N = O; a.K = I;
@@ -470,9 +550,11 @@ int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* 
 
 // gX[R][I] (= | +=) gY W ; Gp = planes of gY, [3][O/8][R][8]
 int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot,
-                   GemmFold* defer) {
+                   GemmFold* defer, const float* amax_g, const float* amax_w) {
   FR_CHECK(((uintptr_t)W & 3) == 0 && I % 4 == 0 && O % 16 == 0, "linear_x_dgrad: operand alignment");
+  FR_CHECK((amax_g != nullptr) == (amax_w != nullptr), "linear_x_dgrad: the fp16 form needs the records of both operands");
   GxArgs a;
+  a.amax_a = amax_g; a.amax_b = amax_w;
   a.Ap = (const unsigned short*)Gp; a.aPlane = (long)R * O; a.aLd = R;
   a.B = W; a.bPlane = 0; a.bLd = I;
   a.ldc = I; a.M = R; a.N = I; a.K = O;
@@ -483,6 +565,7 @@ int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* g
 int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot) {
   const int Rp = linear_x_rows_padded(R);
   GxArgs a;
+  a.amax_a = nullptr; a.amax_b = nullptr;
   a.Ap = (const unsigned short*)GpT; a.aPlane = (long)O * Rp; a.aLd = O;
   a.B = XpT; a.bPlane = (long)I * Rp; a.bLd = I;
   a.ldc = I; a.M = O; a.N = I; a.K = Rp;

@@ -162,11 +162,13 @@ int get_gemm_x_roles();
 bool linear_x_eligible(int role, int R, int I, int O);   // role: 1 forward, 2 input gradient, 4 weight gradient
 int linear_x_rows_padded(int R);                       // rows of the transposed planes (R rounded up to 16, zero filled)
 int split_planes(const float* src, int R, int C, void* P /* [3][C/8][R][8] bf16 or null */, void* PT /* [3][Rp/8][C][8] or null */,
-                 hipStream_t s);
+                 hipStream_t s, const float* amax = nullptr);   // amax (record of src, amax.h): two fp16 planes [2][C/8][R][8] instead (P only)
+// amax_x / amax_g + amax_w (records of the activation operand and of the weight matrix): the two-plane fp16 form (planes made by
+// split_planes with the same record)
 int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* bias, int O, float* y, hipStream_t s, int ws_slot = 0,
-                     GemmFold* defer = nullptr);
+                     GemmFold* defer = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr);
 int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot = 0,
-                   GemmFold* defer = nullptr);
+                   GemmFold* defer = nullptr, const float* amax_g = nullptr, const float* amax_w = nullptr);
 int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot = 0);
 
 

@@ -85,6 +85,10 @@ struct ClsLayer {
   DevBuf xp, xpT, gp, gpT;    // split-bf16 planes of the layer's input and of its output gradient (gemmx.hip), when it takes that form
   int x_form = 0;             // set per call: which of this layer's products run in the split-bf16 operand form
                               // (bit 1 forward, 2 input gradient, 4 weight gradient: linear_x_eligible)
+  DevBuf am;                  // two-plane fp16 form of the forward / input-gradient products: magnitude records (amax.h) of the
+                              // layer's input, of its output gradient and of its weight matrix, AMAX_REC floats each
+  const float* am_w_of = nullptr;   // the weight vector the third record was taken from ...
+  long am_w_gen = -1;               // ... in an evaluate-mode pass of this static_weights generation (-1: a training pass)
 };
 
 }  // namespace frcnn
@@ -1147,6 +1151,11 @@ static bool cnet_fuse() {
   const char* e = getenv("FRCNN_CNET_FUSE");   // (read per call: the tests switch it)
   return !(e && atoi(e) == 0);
 }
+// the classification net's large products in the two-plane fp16 form: with option x3_f16 (FRCNN_GEMM_F16=0: these stay three-plane)
+static bool gemm_f16_on() {
+  static const bool env_on = !(getenv("FRCNN_GEMM_F16") && atoi(getenv("FRCNN_GEMM_F16")) == 0);
+  return env_on && get_x3_f16();
+}
 static int ensure_cnet(frcnn_model* m, int R) {
   for (auto& L : m->cls) {
     size_t n = (size_t)R * L.n * 4;
@@ -1162,6 +1171,7 @@ static int ensure_cnet(frcnn_model* m, int R) {
     if (L.x_form & 1) FR_TRY(L.xp.ensure((size_t)3 * R * L.in * 2));
     if (L.x_form & 2) FR_TRY(L.gp.ensure((size_t)3 * R * L.n * 2));
     if (L.x_form & 4) { FR_TRY(L.xpT.ensure((size_t)3 * L.in * Rp * 2)); FR_TRY(L.gpT.ensure((size_t)3 * L.n * Rp * 2)); }
+    if (L.x_form & 3) FR_TRY(L.am.ensure((size_t)3 * AMAX_REC * 4));
   }
   int nc = m->d.class_count + 1;
   int nf = m->cls.empty() ? m->D : m->cls.back().n;
@@ -1187,7 +1197,18 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
     ClsLayer& L = m->cls[l];
     GemmFold fold;   // (fused: the layer's row-wise kernel folds the product's split-K slabs itself)
     GemmFold* defer = cnet_fuse() ? &fold : nullptr;
-    if (L.x_form & 1) {   // split-bf16 operand form: the input's planes once
+    if ((L.x_form & 3) && gemm_f16_on()) {   // two-plane fp16 form: the weight matrix's magnitude (forward and input gradient share it)
+      float* rw = L.am.f() + 2 * AMAX_REC;
+      const bool have = !training && g_static_weights && L.am_w_gen == g_static_gen && L.am_w_of == w;
+      if (!have) FR_TRY(tensor_absmax(w + L.w_off, (long)L.n * L.in, rw, s));
+      L.am_w_of = w; L.am_w_gen = training ? -1 : g_static_gen;
+    }
+    if ((L.x_form & 1) && gemm_f16_on()) {   // two fp16 planes of the input, scaled by its largest magnitude
+      float* rx = L.am.f();
+      FR_TRY(tensor_absmax(cur, (long)R * L.in, rx, s));
+      FR_TRY(split_planes(cur, R, L.in, L.xp.p, nullptr, s, rx));
+      FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s, 0, defer, rx, rx + 2 * AMAX_REC));
+    } else if (L.x_form & 1) {   // split-bf16 operand form: the input's planes once
       FR_TRY(split_planes(cur, R, L.in, L.xp.p, nullptr, s));
       FR_TRY(linear_x_forward(L.xp.p, R, L.in, w + L.w_off, w + L.b_off, L.n, L.lin.f(), s, 0, defer));
     } else {
@@ -1332,7 +1353,12 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
     float* gin = l == 0 ? gx : L.gin.f();
     const bool xw = (L.x_form & 4) != 0, xd = (L.x_form & 2) != 0 && gin;
     // chain: the gradient's planes (row-major orientation) and the input-gradient product
-    if (xd) {
+    if (xd && gemm_f16_on() && L.am_w_of == w) {   // (the weight record of this step's forward pass)
+      float* rg = L.am.f() + AMAX_REC;
+      FR_TRY(tensor_absmax(L.g.f(), (long)R * L.n, rg, s));
+      FR_TRY(split_planes(L.g.f(), R, L.n, L.gp.p, nullptr, s, rg));
+      FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s, 0, gdefer, rg, L.am.f() + 2 * AMAX_REC));
+    } else if (xd) {
       FR_TRY(split_planes(L.g.f(), R, L.n, L.gp.p, nullptr, s));
       FR_TRY(linear_x_dgrad(L.gp.p, R, L.n, w + L.w_off, L.in, gin, OUT_STORE, s, 0, gdefer));
     } else if (gin) {
