@@ -197,13 +197,15 @@ int frcnn_nms_host(const float* boxes_host, int n, int ncols, float overlap, int
 
 // ---------------------------------------------------------------- conv (operator-level, for parity tests
 // and hosts that drive single layers; the model runtime keeps packed weights resident instead)
-// option x3_f16: the op-level split convolutions take the two-plane fp16 form of convx.hip; two magnitude records (amax.h:
-// input and weight tensor) and the scalar the pack publishes
-static float* x3_f16_scalars(int) {
-  static float* buf = nullptr;
-  if (!get_x3_f16()) return nullptr;
-  if (!buf && hipMalloc((void**)&buf, (size_t)(2 * AMAX_REC + 4) * 4) != hipSuccess) return nullptr;
-  return buf;
+// option x3_f16: the op-level split launches take the two-plane fp16 form; the magnitude records of their two operands (amax.h) and
+// the scalar the pack publishes live in a buffer of the CALL (freed with it: two host threads or streams may run these entry points
+// side by side)
+#define X3_REC_BYTES ((size_t)(2 * AMAX_REC + 4) * 4)
+static int x3_f16_records(float** out) {
+  *out = nullptr;
+  if (!get_x3_f16()) return FRCNN_OK;
+  FR_HIP(hipMalloc((void**)out, X3_REC_BYTES));
+  return FRCNN_OK;
 }
 
 int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_slope, const float* in_scale,
@@ -212,18 +214,18 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
   float* wf = nullptr;
   if (conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
     FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
-    float* am = x3_f16_scalars(k);   // (experimental two-plane fp16 form: FRCNN_X3_F16=1)
-    int rcx = FRCNN_OK;
+    float* am = nullptr;
+    int rcx = x3_f16_records(&am);
     float* const amw = am ? am + AMAX_REC : nullptr;          // the weights' record
     float* const aws = am ? am + 2 * AMAX_REC : nullptr;      // their largest magnitude
-    if (am) {
+    if (am && rcx == FRCNN_OK) {
       rcx = tensor_absmax(in, (long)C * H * W, am, S(stream));
       if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, amw, S(stream));
     }
     if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 0, wf, S(stream), H + 2 * pad - k + 1, W + 2 * pad - k + 1, amw, aws);
     if (rcx == FRCNN_OK) rcx = conv_x3(in, C, H, W, in_slope, in_scale, wf, bias, O, k, pad, out, OUT_STORE, 0, S(stream), 0, nullptr, am, aws);
     (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(wf);
+    (void)hipFree(wf); (void)hipFree(am);
     return rcx;
   }
   FR_HIP(hipMalloc((void**)&wf, conv_pack_floats(C, O, k) * 4));
@@ -238,18 +240,18 @@ int frcnn_conv2d_backward_input(const float* gout, int O, int Ho, int Wo, const 
   float* wd = nullptr;
   if (conv_x3_eligible(O, C, k)) {
     FR_HIP(hipMalloc((void**)&wd, conv_x3_pack_bytes(O, C, k)));
-    float* am = x3_f16_scalars(k);
-    int rcx = FRCNN_OK;
+    float* am = nullptr;
+    int rcx = x3_f16_records(&am);
     float* const amw = am ? am + AMAX_REC : nullptr;
     float* const aws = am ? am + 2 * AMAX_REC : nullptr;
-    if (am) {
+    if (am && rcx == FRCNN_OK) {
       rcx = tensor_absmax(gout, (long)O * Ho * Wo, am, S(stream));
       if (rcx == FRCNN_OK) rcx = tensor_absmax(weight, (long)O * C * k * k, amw, S(stream));
     }
     if (rcx == FRCNN_OK) rcx = conv_x3_pack(weight, O, C, k, 1, wd, S(stream), Ho + 2 * (k - 1 - pad) - k + 1, Wo + 2 * (k - 1 - pad) - k + 1, amw, aws);
     if (rcx == FRCNN_OK) rcx = conv_x3(gout, O, Ho, Wo, nullptr, nullptr, wd, nullptr, C, k, k - 1 - pad, gin, accumulate ? OUT_ADD : OUT_STORE, 0, S(stream), 0, nullptr, am, aws);
     (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(wd);
+    (void)hipFree(wd); (void)hipFree(am);
     return rcx;
   }
   FR_HIP(hipMalloc((void**)&wd, conv_pack_floats(O, C, k) * 4));
@@ -268,15 +270,16 @@ int frcnn_conv2d_backward_weight(const float* in, int C, int H, int W, const flo
   void* ws = nullptr;
   FR_HIP(hipMalloc(&ws, wsb));
   int rc = FRCNN_OK;
-  float* am = (k == 3 && conv_wgradx_eligible(C, O, k)) ? x3_f16_scalars(k) : nullptr;   // (fp16 form: records of both tensors)
-  if (am) {
+  float* am = nullptr;   // (fp16 form: records of both tensors)
+  if (k == 3 && conv_wgradx_eligible(C, O, k)) rc = x3_f16_records(&am);
+  if (am && rc == FRCNN_OK) {
     rc = tensor_absmax(in, (long)C * H * W, am, S(stream));
     if (rc == FRCNN_OK) rc = tensor_absmax(gout, (long)O * (H + 2 * pad - k + 1) * (W + 2 * pad - k + 1), am + AMAX_REC, S(stream));
   }
   if (rc == FRCNN_OK)
     rc = conv_wgrad(in, C, H, W, in_slope, in_scale, gout, O, k, pad, gweight, ws, wsb, S(stream), nullptr, am, am ? am + AMAX_REC : nullptr);
   (void)hipStreamSynchronize(S(stream));
-  (void)hipFree(ws);
+  (void)hipFree(ws); (void)hipFree(am);
   FR_TRY(rc);
   if (gbias) {
     int Ho = H + 2 * pad - k + 1, Wo = W + 2 * pad - k + 1;
@@ -348,16 +351,16 @@ int frcnn_linear_forward(const float* x, int R, int I, const float* weight, cons
   if (linear_x_eligible(1, R, I, O)) {   // split-bf16 operand form (gemmx.hip); the model runtime keeps the planes resident
     void* xp = nullptr;
     FR_HIP(hipMalloc(&xp, (size_t)3 * R * I * 2));
-    float* am = x3_f16_scalars(3);   // (two-plane fp16 form: records of x and of the weight matrix)
-    int rc = FRCNN_OK;
-    if (am) {
+    float* am = nullptr;   // (two-plane fp16 form: records of x and of the weight matrix)
+    int rc = x3_f16_records(&am);
+    if (am && rc == FRCNN_OK) {
       rc = tensor_absmax(x, (long)R * I, am, S(stream));
       if (rc == FRCNN_OK) rc = tensor_absmax(weight, (long)O * I, am + AMAX_REC, S(stream));
     }
     if (rc == FRCNN_OK) rc = split_planes(x, R, I, xp, nullptr, S(stream), am);
     if (rc == FRCNN_OK) rc = linear_x_forward(xp, R, I, weight, bias, O, y, S(stream), 0, nullptr, am, am ? am + AMAX_REC : nullptr);
     (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(xp);
+    (void)hipFree(xp); (void)hipFree(am);
     return rc;
   }
   return gemm_f32(x, I, 1, weight, 1, I, y, O, R, O, I, OUT_STORE, bias, S(stream));
@@ -376,7 +379,8 @@ int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const f
     };
     if (xd) alloc(&gp, (size_t)3 * R * O * 2);
     if (xw) { alloc(&gpT, (size_t)3 * O * Rp * 2); alloc(&xpT, (size_t)3 * I * Rp * 2); }
-    float* am = xd ? x3_f16_scalars(3) : nullptr;   // (two-plane fp16 form of the input-gradient product)
+    float* am = nullptr;   // (two-plane fp16 form of the input-gradient product)
+    if (rc == FRCNN_OK && xd) rc = x3_f16_records(&am);
     if (rc == FRCNN_OK && am) {
       rc = tensor_absmax(gy, (long)R * O, am, S(stream));
       if (rc == FRCNN_OK) rc = tensor_absmax(weight, (long)O * I, am + AMAX_REC, S(stream));
@@ -387,7 +391,7 @@ int frcnn_linear_backward(const float* x, const float* gy, int R, int I, const f
     if (rc == FRCNN_OK && xd) rc = linear_x_dgrad(gp, R, O, weight, I, gx, OUT_STORE, S(stream), 0, nullptr, am, am ? am + AMAX_REC : nullptr);
     if (rc == FRCNN_OK && xw) rc = linear_x_wgrad(gpT, xpT, R, O, I, gweight, S(stream));
     (void)hipStreamSynchronize(S(stream));
-    (void)hipFree(gp); (void)hipFree(gpT); (void)hipFree(xpT);
+    (void)hipFree(gp); (void)hipFree(gpT); (void)hipFree(xpT); (void)hipFree(am);
     FR_TRY(rc);
     if (gx && !xd) FR_TRY(gemm_f32(gy, O, 1, weight, I, 1, gx, I, R, I, O, OUT_STORE, nullptr, S(stream)));
     if (gweight && !xw) FR_TRY(gemm_f32(gy, 1, O, x, I, 1, gweight, I, O, I, R, OUT_ADD, nullptr, S(stream)));

@@ -635,9 +635,12 @@ static int launch_igemm_n(IgemmArgs& a, int klass, double flops, hipStream_t s) 
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
+  float* const late_amax = (a.pool_amax && grid > AMAX_MAX_BLOCKS) ? a.pool_amax : nullptr;   // more blocks than a record has entries:
+  if (late_amax) a.pool_amax = nullptr;                                                       // the magnitude in a pass of its own
   double bytes = 4.0 * ((double)a.Cin * a.H * a.W + (double)a.M * a.Ho * a.Wo);
   FR_LAUNCH(klass, flops, bytes, s, (conv_igemm_kernel<KS, CC, BM, MODE, NIT>), dim3(grid), dim3(256), lds, a);
   FR_LAUNCH_CHECK();
+  if (late_amax) FR_TRY(tensor_absmax(a.pool_out, (long)a.M * a.Hp * a.Wp, late_amax, s));
   return FRCNN_OK;
 }
 

@@ -187,7 +187,12 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const float* __restri
 }
 int tensor_absmax_assign_blocks(AmaxJob* jobs, int njobs) {
   int b = 0;
-  for (int i = 0; i < njobs; ++i) { jobs[i].blk_begin = b; b += (int)cdivl(jobs[i].n, AMAX_SPAN); }
+  for (int i = 0; i < njobs; ++i) {
+    jobs[i].blk_begin = b;
+    const long nb = cdivl(jobs[i].n, AMAX_SPAN);
+    if (nb > AMAX_MAX_BLOCKS) return -1;   // (a segment of more than 134 M values: its record would not hold the spans)
+    b += (int)nb;
+  }
   return b;
 }
 long tensor_absmax_record_floats(long n) { return 1 + cdivl(n, AMAX_SPAN); }
@@ -1053,6 +1058,7 @@ static int launch_x3(CxArgs& a, double flops, hipStream_t s) {
     attr_set = true;
   }
   int grid = a.tilesX * a.tilesY * a.mTiles * a.splitK;
+  if (grid > AMAX_MAX_BLOCKS) a.amax_out = nullptr;   // (more blocks than a record has entries: conv_x3 takes the magnitude in a pass of its own)
 #ifdef CX_TRACE
   static unsigned long long* tbuf = nullptr;
   const char* tfile = getenv("FRCNN_X3_TRACE");
@@ -1157,6 +1163,8 @@ int conv_x3(const float* in, int Cin, int H, int W, const float* in_slope, const
     rc = k == 5 ? launch_x3<5, 2, false, false>(a, algo_flops, s) : launch_x3<7, 2, false, false>(a, algo_flops, s);
   }
   FR_TRY(rc);
+  if (amax_out && !slab && (long)a.tilesX * a.tilesY * a.mTiles > AMAX_MAX_BLOCKS)   // (see launch_x3: the launch kept no record)
+    FR_TRY(tensor_absmax(out, (long)M * a.Ho * a.Wo, amax_out, s));
   if (slab) {
     long total = (long)M * a.Ho * a.Wo;
     int grid;

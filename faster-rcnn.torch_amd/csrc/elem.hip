@@ -351,6 +351,7 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                          float* gslope, hipStream_t s, float* amax) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
   int chunks = act_bwd_chunks(C, (long)H * W);
+  FR_CHECK(!amax || (long)C * chunks <= AMAX_MAX_BLOCKS, "maxpool_act_backward: %ld blocks do not fit the magnitude record", (long)C * chunks);
   float *pb = nullptr, *pa = nullptr;
   if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (W % 4 == 0) && (Wo % 2 == 0) && (((uintptr_t)gpool | (uintptr_t)x | (uintptr_t)gx) % 16 == 0) &&
@@ -369,6 +370,7 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
                  const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s, float* amax) {
   int chunks = act_bwd_chunks(C, hw);
+  FR_CHECK(!amax || (long)C * chunks <= AMAX_MAX_BLOCKS, "act_backward: %ld blocks do not fit the magnitude record", (long)C * chunks);
   float *pb = nullptr, *pa = nullptr;
   if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (hw % 4 == 0) && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) % 16 == 0);

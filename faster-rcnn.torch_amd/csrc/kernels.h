@@ -49,6 +49,7 @@ int conv_x3_pack(const float* w, int O, int C, int k, int mode, void* dst, hipSt
                  const float* amax_rec_w = nullptr, float* amax_w = nullptr);   // fp16 form: the weights' magnitude record in, their largest magnitude out
 // Magnitude records (amax.h): rec = AMAX_REC floats of device memory per tensor.
 #define AMAX_REC 16400   // floats per record: the count + one entry per block of the producing launch (up to 16 384) + pad
+#define AMAX_MAX_BLOCKS 16384   // a launch that keeps a record may have at most this many blocks (checked by the launchers)
 int tensor_absmax(const float* x, long n, float* rec, hipStream_t s);   // a pass of its own over a tensor
 struct AmaxJob { long off; long n; float* out; int blk_begin; };   // a segment of the flat parameter vector and its record
 int tensor_absmax_assign_blocks(AmaxJob* jobs, int njobs);   // -> grid size

@@ -360,6 +360,7 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       for (auto& hd : m->heads) addw(hd.c3);
       m->n_amax_jobs = (int)aj.size();
       m->amax_grid = tensor_absmax_assign_blocks(aj.data(), m->n_amax_jobs);
+      FR_CHECK(m->amax_grid >= 0, "ensure_shapes: a weight tensor is too large for its magnitude record");
       if (!aj.empty()) {
         FR_TRY(m->amax_jobs.ensure(aj.size() * sizeof(AmaxJob)));
         FR_HIP(hipMemcpy(m->amax_jobs.p, aj.data(), aj.size() * sizeof(AmaxJob), hipMemcpyHostToDevice));

@@ -152,3 +152,27 @@ def _fullsize(F, O, large=False, pool=None, examples=None):
     for kind, (nd, nt) in differing.items():
         assert nd <= max(4, 2e-5 * nt), (kind, nd, nt)
     nat.bn_running.copy_(torch.from_numpy(bn0))
+
+
+def test_frames_with_more_blocks_than_a_magnitude_record_holds(F, small_cfg):
+    """Two-plane fp16 form: a launch records one maximum per block in a record of 16 384 entries; a 3000 x 3000 frame gives the
+    first layers more blocks than that, and they take the magnitude in a pass of their own.  The anchor nets' outputs must agree
+    with the three-bf16-plane form (which needs no magnitudes) to the usual bar."""
+    import ctypes
+    model = F.vgg_small(dict(small_cfg))
+    w, g = F.combine_and_flatten_parameters(model["pnet"], model["cnet"])
+    pnet = model["pnet"]
+    pnet.evaluate()
+    img = F.to_device(F.synthetic_image(3000, 3000, 3))
+    before = ctypes.c_int(0)
+    F._lib.call("frcnn_get_option", b"x3_f16", ctypes.byref(before))
+    res = {}
+    try:
+        for form in (1, 0):
+            F._lib.call("frcnn_set_option", b"x3_f16", form)
+            res[form] = [o.numpy().copy() for o in pnet.forward(img)]
+    finally:
+        F._lib.call("frcnn_set_option", b"x3_f16", before.value)
+    for a, b in zip(res[1], res[0]):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
