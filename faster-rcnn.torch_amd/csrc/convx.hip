@@ -1,6 +1,11 @@
-// convx.hip -- the 3x3 nn.SpatialConvolution forward / updateGradInput (models/model_utilities.lua:8 driven by
-// objective.lua:71,189 and Detector.lua:33) on the gfx950 bf16 matrix cores WITHOUT giving up fp32 results:
-// "split operands".  Every fp32 value x is written as the exact sum of three bf16 numbers
+// convx.hip -- the 3x3 (and the anchor nets' 5x5 / 7x7) nn.SpatialConvolution forward / updateGradInput
+// (models/model_utilities.lua:8,31 driven by objective.lua:71,189 and Detector.lua:33) on the gfx950 16-bit matrix cores
+// WITHOUT giving up fp32 results: "split operands".  Two forms, one kernel body (template parameter NP = planes per operand):
+//   NP = 2 (option x3_f16, the default since round 5): two fp16 planes of the operand scaled by a power of two, THREE exact
+//          partial products per fp32 product -- described at split8h below; the scale comes from the tensor's magnitude record
+//          (amax.h), kept by the launch that wrote the tensor; a ring of four 8 KB A stages, one barrier per two taps.
+//   NP = 3: three bf16 planes, SIX partial products, the exact split described next; a ring of two 12 KB stages.
+// Every fp32 value x is written as the exact sum of three bf16 numbers
 //     x = h + m + l + eps,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m),   |eps| <= 2^-26 |x|
 // (round to nearest; x - h and x - h - m are exact in fp32), and a product x*y is formed from the six partial products
 //     l*h' + h*l' + m*m' + m*h' + h*m' + h*h'                      (the dropped m*l', l*m', l*l' are <= 2^-25 |x y|)
@@ -18,7 +23,7 @@
 // GEMM view: D[m = filter][n = pixel] = sum_{tap, c} W[m][c][tap] * X[c][pixel + tap];  block = 128 filters x (TH x TW <=
 // 128) pixels, 2 x 2 waves of 64 x 64 (four 32x32 accumulators), K step = 16 channels of one tap (lane half h takes
 // channels 8h..8h+7), stage = one tap of a 16-channel chunk: A ring of two 12 KB stages (LDS-DMA one stage ahead), one patch
-// buffer per block.  44 KB of LDS, <= 168 registers -> three blocks per CU.
+// buffer per block.  44 KB of LDS (45 KB with NP = 2), <= 168 registers -> three blocks per CU.
 #include <cstdlib>
 
 #include "kernels.h"
@@ -115,7 +120,7 @@ __device__ __forceinline__ void split8(const float* v, uint4& H, uint4& Mi, uint
   L = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// ---- the two-plane fp16 form (experimental, FRCNN_X3_F16): x * 2^e = h + l + eps with h = f16(x 2^e), l = f16(x 2^e - h),
+// ---- the two-plane fp16 form (option x3_f16): x * 2^e = h + l + eps with h = f16(x 2^e), l = f16(x 2^e - h),
 // |eps| <= 2^-23 |x 2^e| in the normal range; e puts the tensor's largest magnitude into [2^14, 2^15) (x16_exp), so that
 // h never overflows and the residual of every element within 2^-18 of the maximum is a normal fp16 number.  A product is
 // formed from THREE exact partial products h*h' + h*l' + l*h' (11 x 11 significand bits; the dropped l*l' is <= 2^-22).

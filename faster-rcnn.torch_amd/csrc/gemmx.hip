@@ -3,7 +3,9 @@
 // gradient -- in the SPLIT-bf16 operand form of convx.hip: fp32 tensors in and out, fp32 accumulation, every fp32 product
 // formed from six exact bf16 x bf16 partial products of three-way split operands on v_mfma_f32_32x32x16_bf16 (arithmetic and
 // accuracy: convx.hip; tests/test_gpu_elem.py::test_linear_fc1_split_bf16_form measures it against fp64 and against the
-// fp32 matrix-core kernel of gemm.hip).
+// fp32 matrix-core kernel of gemm.hip).  Round 5: forward and input gradient (the fp32-weight modes) also in the two-plane
+// fp16 form of convx.hip (template parameter NP = 2, with option x3_f16: three partial products; the activation operand's planes
+// and the in-register weight split are scaled by powers of two from the operands' magnitude records, amax.h).
 //
 // Who splits what.  The ACTIVATION operands (the pooled ROI features X [R][I], the gradient gY [R][O]) are small (R is a
 // few hundred rows) and each is used by two products in two orientations: one pass (`split_planes_kernel`) writes their

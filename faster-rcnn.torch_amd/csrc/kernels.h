@@ -34,9 +34,11 @@ int conv_igemm(const float* in, int Cin, int H, int W, const float* in_slope, co
                double algo_flops, hipStream_t s, int ws_slot = 0,  // ws_slot: split-K workspace (0 | 1)
                const IgemmPool* pool = nullptr, bool* pool_fused = nullptr);
 
-// ---- split-bf16 operand form of the 3x3 convolution (convx.hip): fp32 tensors in and out, every product formed from six
-// exact bf16 x bf16 partial products (three-way split of both operands) accumulated in fp32 on the bf16 matrix cores -- the
-// accuracy of the fp32 matrix-core kernel at 6/16 of its matrix-pipe time.  wp = stages packed by conv_x3_pack*.
+// ---- split operand forms of the convolutions (convx.hip): fp32 tensors in and out, fp32 accumulation on the 16-bit matrix
+// cores; every product formed from three exact fp16 x fp16 partial products of operands scaled by powers of two and split in
+// two (option x3_f16, the default; needs the magnitudes of both tensors: amax_* below), or from six exact bf16 x bf16 partial
+// products of a three-way split -- the accuracy of the fp32 matrix-core kernel at 3/16 (6/16) of its matrix-pipe time.
+// wp = stages packed by conv_x3_pack*.
 void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 launches take this form, 0 = fp32 MFMA only
 int get_split_bf16();
 bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)

@@ -1,6 +1,9 @@
 // wgradx.hip -- accGradParameters of the 3x3 nn.SpatialConvolution (models/model_utilities.lua:8 driven by
-// objective.lua:189) in the split-bf16 operand form of convx.hip: fp32 tensors in and out, every product formed from six
-// exact bf16 x bf16 partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+// objective.lua:189) in the split operand forms of convx.hip: fp32 tensors in and out, every product formed from three exact
+// fp16 x fp16 partial products of two-plane operands (template parameter NP = 2: option x3_f16, the default; both tensors scaled
+// by powers of two from their magnitude records, amax.h) or from six exact bf16 x bf16 partial products (NP = 3), accumulated
+// in fp32 by v_mfma_f32_32x32x16_f16 / _bf16.  The description below is written for three planes; with two, a tile has 108 MFMAs
+// per wave instead of 216 and an LDS image 52 KB instead of 78.
 //
 //   gw[o][c][ky][kx] += sum_pix g[o][pix] * act(in)[c][pix + (ky,kx) - pad]          (+ optionally gbias[o] += sum_pix g[o][pix])
 //
