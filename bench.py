@@ -769,6 +769,11 @@ def main():
                                      "products; executed MFMA rate = %d x achieved = %.0f TFLOP/s (%.3f of the dense peak); the fp32 matrix-core "
                                      "peak is 157.3 TFLOP/s" % (nprod, nprod, nprod * ach, nprod * ach / BF16_MFMA_PEAK_TFLOPS)
                                      if split_on else "fp32 matrix-core peak"),
+                          executed=(dict(partial_products_per_fp32_product=nprod, tflops=round(nprod * ach, 1),
+                                         frac_of_dense_16bit_peak=round(nprod * ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                                         note="matrix-core FLOPs actually issued (the MFMA-utilisation figure); the two-plane fp16 form "
+                                              "issues half of what the three-plane bf16 form does for the same algorithmic work")
+                                    if split_on else None),
                           sampled_steps=sampled, launches_per_step=launches[k] / sampled, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
                           algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),
