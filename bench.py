@@ -19,9 +19,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying
   "parity"       -- the GPU step on the oracle's inputs against the oracle's loss and gradient (the run
                     exits non-zero when they differ);
   "other_legs"   -- BASELINE config 2 (Detector:detect, images/sec, with its own roofline / glue-time split) and nms()
-                    alone at n = 300 ... 26 544, each with its CPU-restatement time and its id parity, and BASELINE
-                    config 5's one-GPU workload (vgg_large), measured after the timed region;
-  "sustained"    -- the same metric over 1000 back-to-back steps (steady clocks; not `value`);
+                    alone at n = 300 ... 26 544, each with its CPU-restatement time and its id parity, BASELINE
+                    config 5's one-GPU workload (vgg_large), and the headline workload in the two other arithmetic forms
+                    (exact_split: three bf16 planes, 24 bits; fp32_mfma: plain fp32 matrix-core products), measured after
+                    the timed region;
+  "sustained"    -- the same metric over >= 12 s of back-to-back steps (~5 000; steady clocks, visible to an SMI sampler; not `value`);
   "roofline_hbm" -- the HBM-bound kernel classes of the step (RMSprop, ROI pooling, element-wise passes): algorithmic
                     bytes / HIP-event time against the 8 TB/s peak.
   --comm native  -- the exchange step through the library's own communicator (frcnn_comm_*, the calls a LuaJIT
@@ -56,7 +58,8 @@ def split_products(F):
 CONV_CLASSES = ("conv_igemm_k3", "conv_igemm_other", "conv_wgrad_k3", "conv_wgrad_other", "conv_x3", "conv_wgradx")
 FULL_H, FULL_W = 450, 800
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s is what a float4 copy reaches
-SUSTAINED_STEPS = 1000
+SUSTAINED_SECONDS = 12.5     # the sustained pass: long enough for an external SMI sampler
+SUSTAINED_STEPS_MAX = 8000
 
 
 def csrc_sha256():
@@ -209,14 +212,32 @@ def gpu_parity_step(F, model, weights, gradient, w0, bn0, inp):
     class _One(object):
         def nextTraining(self, count=None):
             return [dict(img=inp["img"], positive=inp["pos"], negative=inp["neg"])]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import decisions
     try:
         stats = dict(pcls=[], preg=[], dcls=[], dreg=[])
         f = F.create_objective(model, weights, gradient, _One(), stats)
-        loss, grad = f(weights)
+        with decisions.CaptureBeforeBackward(F, model, f) as cap:    # the device's pool winners / PReLU branches (tests/decisions.py)
+            loss, grad = f(weights)
         g = grad.cpu().numpy().copy()
     finally:
         model["pnet"].drop_masks = None; model["cnet"].drop_masks = None
-    return loss, g
+    return loss, g, cap.captured[0]
+
+
+def injected_parity(O, om, tables, w0, inp, bn0, captured, g_gpu):
+    """The gradient comparison with the device's DISCRETE decisions (2x2 pool winners, ROI arg-max, PReLU branches) handed to the
+    oracle, as the strict tests do (tests/test_gpu_fullsize.py): what remains is arithmetic.  Returns (relative L2 of the
+    gradient, {kind: (decisions the oracle would have taken differently, of how many)}).  One more oracle step."""
+    import decisions
+    g = np.zeros_like(w0); acc = np.zeros(8); bn = bn0.copy()
+    own = decisions.blank_like(captured)
+    with O.decisions(inject=captured, record=own):
+        O.train_image(om, w0.copy(), g, inp["img"], *tables, inp["pm"], inp["cm"], bn, acc)
+    g /= max(acc[2], 1.0)
+    rel = float(np.linalg.norm(g_gpu.astype(np.float64) - g) / np.linalg.norm(g.astype(np.float64)))
+    diff = decisions.count_differences(captured, own)
+    return rel, {k: dict(differing=int(nd), of=int(nt)) for k, (nd, nt) in diff.items()}
 
 
 def amplified(nat, w, ncls, gain=30.0):
@@ -373,15 +394,87 @@ def large_leg(F, with_cpu, steps=12):
         inp = parity_inputs(F, cfg, model, H, W)
         tables = oracle_tables(inp["pos"], inp["neg"], inp["rois"])
         dtc, o_loss, o_grad = cpu_train_step(O, om, tables, w0, inp, bn0)
-        g_loss, g_grad = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
+        g_loss, g_grad, captured = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
         rel = float(np.linalg.norm(g_grad.astype(np.float64) - o_grad) / np.linalg.norm(o_grad.astype(np.float64)))
+        rel_inj, differing = injected_parity(O, om, tables, w0, inp, bn0, captured, g_grad)
         out["cpu_baseline"] = dict(value=round(1.0 / dtc, 5), unit="images/sec", cores=O.get_threads(), kind="port",
                                    sample="ONE training step of the CPU restatement on the same 3x600x1000 frame, %d examples (%.1f s, no warm-up)" % (inp["R"], dtc))
-        out["parity"] = dict(loss_gpu=g_loss, loss_oracle=float(o_loss), gradient_rel_l2=rel, examples=inp["R"],
-                             ok=bool(abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3))
+        out["parity"] = dict(loss_gpu=g_loss, loss_oracle=float(o_loss), gradient_rel_l2=rel, gradient_rel_l2_injected=rel_inj,
+                             decisions_differing=differing, examples=inp["R"],
+                             ok=bool(abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3 and rel_inj <= 1e-3))
     del f, it, model, weights, gradient
     torch.cuda.empty_cache()
     return out
+
+
+def dtype_text(F):
+    """`dtype` of the JSON line: tensors, accumulation and results are fp32; what the options change is the form in which the
+    OPERANDS of the matrix-core products are presented (say so in the field itself)."""
+    v = C.c_int(0)
+    F._lib.call("frcnn_get_option", b"split_bf16", C.byref(v)); split = v.value
+    F._lib.call("frcnn_get_option", b"x3_f16", C.byref(v)); f16 = v.value
+    if not split:
+        return "f32 (fp32 operands, v_mfma_f32_32x32x2_f32)"
+    if f16:
+        return "f32 (conv / Linear(13824,1024) operands as 2 x fp16 split planes: 22 significand bits, 3 MFMA partial products; fp32 accumulate)"
+    return "f32 (conv operands as 3 x bf16 split planes: 24 significand bits, 6 MFMA partial products; fp32 accumulate)"
+
+
+def arithmetic_leg(F, name, options, steps=20):
+    """The headline workload (vgg_small 800x450 training step) in another arithmetic form, driver-timed beside the headline
+    (VERDICT r5 next 3): `options` are frcnn_set_option pairs set before the model is shaped (split_bf16 only takes effect for
+    models shaped afterwards) and restored afterwards.  20 steps after 7 warm-up steps, the convolution classes bracketed on
+    every 4th step, own roofline against the peak of THAT form."""
+    import torch
+    before = {}
+    v = C.c_int(0)
+    for k, val in options.items():
+        F._lib.call("frcnn_get_option", k.encode(), C.byref(v)); before[k] = v.value
+        F._lib.call("frcnn_set_option", k.encode(), val)
+    try:
+        cfg = dict(F.duplo_cfg)
+        model = F.vgg_small(cfg)
+        weights, gradient = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=42)
+        it = F.SyntheticBatchIterator(model, H=FULL_H, W=FULL_W, images_per_batch=1, pool=4)
+        f = F.create_objective(model, weights, gradient, it, dict(pcls=[], preg=[], dcls=[], dreg=[]))
+        state = dict(learningRate=1e-4, alpha=0.9)
+        for _ in range(7):
+            F.rmsprop(f, weights, state)
+        torch.cuda.synchronize()
+        conv_mask = sum(1 << F._lib.KC_NAMES.index(n) for n in CONV_CLASSES)
+        nk = len(F._lib.KC_NAMES)
+        sink = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+        F._lib.call("frcnn_prof_collect", *sink)      # (drain)
+        sampled = 0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            on = i % 4 == 0
+            if on:
+                F._lib.call("frcnn_prof_enable", conv_mask); sampled += 1
+            F.rmsprop(f, weights, state)
+            if on:
+                F._lib.call("frcnn_prof_enable", 0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        la, ms, fl, by = [(C.c_longlong * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)()]
+        F._lib.call("frcnn_prof_collect", la, ms, fl, by)
+        split_on = la[F._lib.KC_NAMES.index("conv_x3")] > 0
+        k = F._lib.KC_NAMES.index("conv_x3" if split_on else "conv_igemm_k3")
+        nprod = split_products(F)
+        peak = BF16_MFMA_PEAK_TFLOPS / nprod if split_on else FP32_MFMA_PEAK_TFLOPS
+        ach = (fl[k] / 1e12) / (ms[k] / 1e3) if ms[k] > 0 else 0.0
+        out = dict(metric="images/sec (vgg_small %dx%d fwd+bwd)" % (FULL_W, FULL_H), options=options, dtype=dtype_text(F),
+                   value=round(1.0 / dt, 2), unit="images/sec", ms_per_step=round(dt * 1e3, 3), steps=steps,
+                   roofline=dict(bound="mfma", kernel=F._lib.KC_NAMES[k], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                                 frac=round(ach / peak, 4), launches_per_step=la[k] / max(sampled, 1),
+                                 avg_launch_ms=round(ms[k] / max(la[k], 1), 4),
+                                 executed_tflops=round(nprod * ach, 1) if split_on else round(ach, 2)))
+        del f, it, model, weights, gradient
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        for k, val in before.items():
+            F._lib.call("frcnn_set_option", k.encode(), val)
 
 
 def nms_leg(F, with_cpu):
@@ -414,6 +507,65 @@ def nms_leg(F, with_cpu):
                 row["ids_identical"] = bool(list(pick) == want.tolist())
             rows.append(row)
     return rows
+
+
+# xGMI figures of SURVEY 8e / MI355X_MICROARCH.md: 8 GPUs, full mesh, 7 links x ~153 GB/s per GPU and direction
+XGMI_LINK_GBS = 153.0
+
+
+def exchange_schedule(F, step, n_probe=3, ranks=8):
+    """N = 1: the bucket schedule of the data-parallel exchange as the step would issue it (objective.exchange_probe marks the
+    program points where each bucket's all-reduce starts at N > 1), with the time into the step at which each bucket's
+    gradient slice is final, and a MODEL of the all-reduce time at 8 ranks from the xGMI figures -- something a first
+    multi-GPU run can be compared with.  Not a measurement of any collective."""
+    import sys as _sys
+    import torch
+    obj = _sys.modules["frcnn_amd.objective"]
+    rows = {}
+    order = []
+    span = []
+    for _ in range(n_probe):
+        obj.exchange_probe = []
+        try:
+            step()
+            torch.cuda.synchronize()
+            marks = obj.exchange_probe
+        finally:
+            obj.exchange_probe = None
+        t0 = [m for m in marks if m[0] == "step_begin"][0][4]
+        for label, lo, hi, waits_on, ev in marks:
+            if label == "step_begin":
+                continue
+            t = t0.elapsed_time(ev)
+            if label == "backward_end":
+                span.append(t); continue
+            if label not in rows:
+                rows[label] = dict(bucket=label, elements=hi - lo, bytes=4 * (hi - lo), waits_on=waits_on, final_ms=[])
+                order.append(label)
+            rows[label]["final_ms"].append(t)
+    out = []
+    for label in order:
+        r = rows[label]
+        r["final_ms_into_step"] = round(sorted(r.pop("final_ms"))[len(span) // 2], 3)
+        out.append(r)
+    bwd_end = sorted(span)[len(span) // 2]
+    # model: a bucket's all-reduce starts when its slice is final and the previous bucket's collective is done (one RCCL stream),
+    # and moves 2 (N-1)/N x bytes per rank; (a) one ring over ONE link per direction (the per-link bound of SURVEY 8e), (b) seven
+    # rings / a direct reduce-scatter + all-gather over all 7 links (the best a full mesh allows).  Latency ~ 20 us per collective.
+    preds = {}
+    for name, links in (("one_ring_one_link", 1), ("all_seven_links", 7)):
+        t_end = 0.0
+        for r in sorted(out, key=lambda r: r["final_ms_into_step"]):
+            dur = 0.020 + 2.0 * (ranks - 1) / ranks * r["bytes"] / (links * XGMI_LINK_GBS * 1e9) * 1e3
+            t_end = max(t_end, r["final_ms_into_step"]) + dur
+            r.setdefault("model_allreduce_ms", {})[name] = round(dur, 3)
+        preds[name] = dict(last_bucket_done_ms_into_step=round(t_end, 3), exposed_ms_after_backward=round(max(0.0, t_end - bwd_end), 3))
+    return dict(what="N = 1 probe: where each bucket of the flat gradient becomes final in the step, and a model (not a measurement) of "
+                     "its all-reduce at %d ranks over xGMI" % ranks,
+                buckets=out, backward_end_ms_into_step=round(bwd_end, 3), ranks_modelled=ranks, link_GBs=XGMI_LINK_GBS,
+                model=preds,
+                note="exposed = time the update would wait for the last bucket after the backward pass ends; the buckets run on RCCL's "
+                     "own stream beside the backbone's backward pass (they take CUs from it: FRCNN_COMM_CHANNELS has no measured default)")
 
 
 def _fail(msg, code=2):
@@ -478,7 +630,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP-event profile of every kernel class (adds overhead)")
     ap.add_argument("--no-other-legs", action="store_true", help="skip the inference / nms legs")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the PCIe-inclusive pass (frames uploaded every step)")
-    ap.add_argument("--no-sustained", action="store_true", help="skip the %d-step sustained pass" % SUSTAINED_STEPS)
+    ap.add_argument("--no-sustained", action="store_true", help="skip the %.0f-second sustained pass" % SUSTAINED_SECONDS)
     ap.add_argument("--comm", default=os.environ.get("FRCNN_COMM", "torch"), choices=["torch", "native"],
                     help="exchange back end at N > 1: torch.distributed ('nccl' = RCCL; the default -- the multi-rank path the "
                          "world-size-2 tests cover) or the C ABI's own frcnn_comm_* (RCCL bound by the library; what a LuaJIT "
@@ -612,13 +764,13 @@ def main():
     nk = len(F._lib.KC_NAMES)
     launches = (C.c_longlong * nk)(); ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); by = (C.c_double * nk)()
     F._lib.call("frcnn_prof_collect", launches, ms, fl, by)
-    # The same metric over SUSTAINED_STEPS steps (about three seconds of back-to-back steps, nothing bracketed): clocks and
+    # The same metric over SUSTAINED_SECONDS of back-to-back steps (nothing bracketed): clocks and
     # thermals are steady by then and an external SMI sampler sees the device busy.  `value` stays the K timed steps above.
     sustained = None
     if not args.no_sustained:
-        # (1000 steps at the speed just measured, but never more than ~8 s of them: a debug back end that takes hundreds of
-        # milliseconds per step must not turn this pass into minutes)
-        n_sus = max(20, min(SUSTAINED_STEPS, int(8.0 / max(dt / args.steps, 1e-4))))
+        # (SUSTAINED_SECONDS of steps at the speed just measured -- about 5 000 of them; a debug back end that takes hundreds of
+        # milliseconds per step gets the same seconds, not the same count)
+        n_sus = max(20, min(SUSTAINED_STEPS_MAX, int(SUSTAINED_SECONDS / max(dt / args.steps, 1e-4))))
         barrier()
         ts = time.perf_counter()
         for _ in range(n_sus):
@@ -645,6 +797,12 @@ def main():
         lh = (C.c_longlong * nk)(); mh = (C.c_double * nk)(); fh = (C.c_double * nk)(); bh = (C.c_double * nk)()
         F._lib.call("frcnn_prof_collect", lh, mh, fh, bh)
         hbm = hbm_rows(F, lh, mh, bh, hbm_names, 4)
+    sched = None
+    if world == 1:
+        try:
+            sched = exchange_schedule(F, step)
+        except Exception as e:    # (a probe: never fails the bench line)
+            sched = dict(error=repr(e))
     # Second, untimed pass with the library's side stream off: in the timed region the 3x3 input-gradient
     # launches share the CUs with the weight-gradient launches of the side stream, so their live duration
     # (roofline.achieved, as prescribed) is longer than the kernel needs when it has the GPU to itself.
@@ -725,12 +883,14 @@ def main():
         out = dict(
             metric="images/sec (%s %dx%d fwd+bwd)" % (args.model, W, H), value=round(world * args.steps / dt, 3), unit="images/sec",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
-            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype_text(F), data="synthetic",
             arithmetic=(("fp32 tensors, fp32 accumulation; the 3x3 / 5x5 / 7x7 convolutions (forward, input gradient, 3x3 weight gradient) scale "
                          "each operand tensor by a power of two chosen from its largest magnitude, split it into two fp16 planes (22 significand "
                          "bits) and form every product from three exact fp16 x fp16 partial products (v_mfma_f32_32x32x16_f16); measured "
                          "error against fp64 at the level of the fp32 matrix-core kernel (tools/x3_f16_check.py); the classification net's "
-                         "products use three bf16 planes / six partial products; every other product is a plain fp32 product"
+                         "Linear(13824,1024) forward / input-gradient products " + ("take the same two-plane form" if os.environ.get("FRCNN_GEMM_F16", "1") != "0"
+                                                                                   else "use three bf16 planes / six partial products (FRCNN_GEMM_F16=0)") +
+                         ", its weight-gradient product three bf16 planes / six partial products; every other product is a plain fp32 product"
                          if nprod == F16_PRODUCTS else
                          "fp32 tensors, fp32 accumulation; the 3x3 convolutions (forward, input gradient, weight gradient) form every fp32 "
                          "product from six exact bf16 x bf16 partial products of three-way split operands (24 significand bits, "
@@ -784,7 +944,7 @@ def main():
             backend=("frcnn_comm (RCCL through the C ABI: frcnn_comm_init_rank_file / frcnn_allreduce_f32 / _f64)" if native_comm is not None
                      else ("torch.distributed nccl (RCCL)" if backend == "nccl" else "torch.distributed %s (debug: ranks may share a device)" % backend)
                      if world > 1 else "none (single process)"),
-            ranks=world, buckets=bucket_times, **(exchange_info or {}))
+            ranks=world, buckets=bucket_times, schedule=sched, **(exchange_info or {}))
         ok = True
         full = args.model == "vgg_small" and (H, W) == (FULL_H, FULL_W)
         if world == 1 and not args.no_cpu_baseline and full:
@@ -793,15 +953,26 @@ def main():
             bn0 = np.concatenate([np.zeros(1024, np.float32), np.ones(1024, np.float32)])
             base, inp, o_loss, o_grad = cpu_baseline(F, cfg, model, w0, bn0)
             out["cpu_baseline"] = base
-            g_loss, g_grad = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
+            g_loss, g_grad, captured = gpu_parity_step(F, model, weights, gradient, w0, bn0, inp)
             rel = float(np.linalg.norm(g_grad.astype(np.float64) - o_grad) / np.linalg.norm(o_grad.astype(np.float64)))
-            ok = abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3
+            O_, oracle_model_, oracle_tables_ = _oracle()
+            rel_inj, differing = injected_parity(O_, oracle_model_(O_, cfg), oracle_tables_(inp["pos"], inp["neg"], inp["rois"]),
+                                                 w0, inp, bn0, captured, g_grad)
+            ok = abs(g_loss - o_loss) <= 1e-5 * max(1.0, abs(o_loss)) and rel <= 1e-3 and rel_inj <= 1e-3
             out["parity"] = dict(what="lossAndGradient on the benchmarked frame, same inputs and dropout masks: GPU vs CPU restatement",
                                  loss_gpu=g_loss, loss_oracle=float(o_loss), loss_tolerance=1e-5,
-                                 gradient_rel_l2=rel, gradient_tolerance=1e-3, examples=inp["R"], ok=bool(ok))
+                                 gradient_rel_l2=rel, gradient_tolerance=1e-3,
+                                 gradient_rel_l2_injected=rel_inj, decisions_differing=differing,
+                                 note="gradient_rel_l2: the oracle takes its own discrete decisions (2x2 pool winners, ROI arg-max, PReLU "
+                                      "branches); _injected: the device's decisions are handed to the oracle (tests/decisions.py), what "
+                                      "remains is arithmetic; decisions_differing counts the ones the oracle would have taken differently",
+                                 examples=inp["R"], ok=bool(ok))
             if not args.no_other_legs:
                 out["other_legs"] = dict(inference=inference_leg(F, cfg, model, weights, w0, bn0, True), nms=nms_leg(F, True),
-                                         vgg_large=large_leg(F, True))
+                                         vgg_large=large_leg(F, True),
+                                         # the same workload in the two other arithmetic forms (each priced against its own peak)
+                                         exact_split=arithmetic_leg(F, "exact_split", dict(x3_f16=0)),
+                                         fp32_mfma=arithmetic_leg(F, "fp32_mfma", dict(split_bf16=0)))
                 ok = ok and all(r["ids_identical"] for r in out["other_legs"]["nms"]) \
                     and out["other_legs"]["inference"]["parity"]["nms_ids_identical_on_gpu_boxes"] \
                     and out["other_legs"]["vgg_large"]["parity"]["ok"]

@@ -40,6 +40,9 @@ __device__ __forceinline__ float amax_load_block(const float* __restrict__ rec) 
   const int nw = (blockDim.x + 63) >> 6;
   m = amax_all[0];
   for (int i = 1; i < nw; ++i) m = fmaxf(m, amax_all[i]);
+  // (kernels that scale TWO tensors call this twice in a row: no wave may overwrite its slot for the second record while a slow
+  // wave is still reading the first one's -- ADVICE r5)
+  __syncthreads();
   return m;
 }
 

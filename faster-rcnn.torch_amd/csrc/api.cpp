@@ -1,6 +1,8 @@
 // api.cpp -- C ABI plumbing of libfrcnn_hip.so (include/frcnn_hip.h): errors, device buffers,
 // the HIP-event profiler, and the per-operator entry points that wrap the kernels.
+#include <cmath>
 #include <cstring>
+#include <vector>
 #include <mutex>
 
 #include "kernels.h"
@@ -208,6 +210,19 @@ static int x3_f16_records(float** out) {
   return FRCNN_OK;
 }
 
+// The two-plane fp16 form leaves ONE binade of headroom for a per-channel input scale (convx.hip: a dropout scale's entries are
+// <= 1).  The operator-level entry points accept any caller-supplied scale: entries beyond 1 take the three-plane bf16 form,
+// which has fp32's exponent range.  A host read -- these entry points synchronise anyway.
+static int scale_fits_f16_form(const float* in_scale, int C, hipStream_t s, bool* ok) {
+  *ok = true;
+  if (!in_scale) return FRCNN_OK;
+  std::vector<float> h((size_t)C);
+  FR_HIP(hipMemcpyAsync(h.data(), in_scale, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+  FR_HIP(hipStreamSynchronize(s));
+  for (float v : h) if (!(std::fabs(v) <= 1.f)) { *ok = false; break; }
+  return FRCNN_OK;
+}
+
 int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_slope, const float* in_scale,
                          const float* weight, const float* bias, int O, int k, int pad, float* out,
                          void* stream) {
@@ -215,7 +230,9 @@ int frcnn_conv2d_forward(const float* in, int C, int H, int W, const float* in_s
   if (conv_x3_eligible(C, O, k) && (k == 3 || (!in_slope && !in_scale))) {   // split-bf16 operand form (convx.hip)
     FR_HIP(hipMalloc((void**)&wf, conv_x3_pack_bytes(C, O, k)));
     float* am = nullptr;
-    int rcx = x3_f16_records(&am);
+    bool unit = true;
+    int rcx = scale_fits_f16_form(in_scale, C, S(stream), &unit);
+    if (rcx == FRCNN_OK && unit) rcx = x3_f16_records(&am);
     float* const amw = am ? am + AMAX_REC : nullptr;          // the weights' record
     float* const aws = am ? am + 2 * AMAX_REC : nullptr;      // their largest magnitude
     if (am && rcx == FRCNN_OK) {
@@ -271,7 +288,9 @@ int frcnn_conv2d_backward_weight(const float* in, int C, int H, int W, const flo
   FR_HIP(hipMalloc(&ws, wsb));
   int rc = FRCNN_OK;
   float* am = nullptr;   // (fp16 form: records of both tensors)
-  if (k == 3 && conv_wgradx_eligible(C, O, k)) rc = x3_f16_records(&am);
+  bool unit = true;
+  rc = scale_fits_f16_form(in_scale, C, S(stream), &unit);
+  if (rc == FRCNN_OK && unit && k == 3 && conv_wgradx_eligible(C, O, k)) rc = x3_f16_records(&am);
   if (am && rc == FRCNN_OK) {
     rc = tensor_absmax(in, (long)C * H * W, am, S(stream));
     if (rc == FRCNN_OK) rc = tensor_absmax(gout, (long)O * (H + 2 * pad - k + 1) * (W + 2 * pad - k + 1), am + AMAX_REC, S(stream));

@@ -159,7 +159,17 @@ __device__ __forceinline__ float absmax_span(const float* __restrict__ x, long n
   for (long i = first; i < head; i += stride) m = fmaxf(m, fabsf(x[i]));
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + head);
   const long n4 = (n - head) / 4;
-  for (long i = first; i < n4; i += stride) {
+  // four 16-byte loads in flight per thread (one at a time left a 30 MB tensor latency-bound: 16 us for the classification net's input)
+  long i = first;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+    const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+    const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+    const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+    m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+  }
+  for (; i < n4; i += stride) {
     const float4 v = x4[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
@@ -532,18 +542,27 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         // wave at a time at full size -- timing dependent, never in the small shapes; tools/x3_check.py and
         // tests/test_gpu_convx.py::test_model_layer_shapes_full_size are the checks that caught it.  Cause not established
         // (the packed form beside in-flight VMEM returns is the suspect); packed fp32 is no faster beside MFMAs anyway.)
+#ifdef CX_PLAIN_MUL   // (the round-5 fault's code shape, kept for tools/x3_isa_diff.sh: plain C multiplies the SLP pass may pack)
+        if (SLOPE) t = t > 0.f ? t : slope * t;
+        if (SCALE) t *= sc[j];
+#else
         if (SLOPE) {
           float ts;
           asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ts) : "v"(slope), "v"(t));
           t = t > 0.f ? t : ts;
         }
         if (SCALE) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"(sc[j]));
+#endif
         x[j] = gok[it] ? t : 0.f;
       }
       uint4 H, Mi, L;
       if (NP == 2) {
 #pragma unroll
+#ifdef CX_PLAIN_MUL
+        for (int j = 0; j < 8; ++j) x[j] *= in_mul;
+#else
         for (int j = 0; j < 8; ++j) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[j]) : "v"(x[j]), "v"(in_mul));
+#endif
         split8h(x, H, L);
         if (sdst[it] != 0xFFFFFFFFu) {
           char* d = Bb + sdst[it];
@@ -588,6 +607,17 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
       }
   };
 #define CX_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // The barriers of the stage loop.  NOT __syncthreads(): its release fence makes the compiler wait for EVERY outstanding VMEM
+  // operation in front of the barrier (s_waitcnt vmcnt(0): an LDS-DMA is an LDS write it must publish) -- but the ring stages
+  // requested a few instructions before the patch-publishing barrier are meant to stay in flight across it, and so are the
+  // patch loads at a leader tap's barrier: what has to have landed is waited for by hand (the s_waitcnt vmcnt(n) in front of
+  // each leader's barrier).  Found in round 6 in the ISA: with __syncthreads() every chunk waited out a whole DMA round trip at
+  // its first tap.  lgkmcnt(0): this wave's LDS reads of the slots about to be refilled have returned, its patch writes are done.
+#ifndef CX_SYNC2
+#define CX_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define CX_BARRIER() __syncthreads()
+#endif
 
   const int nC = cend - cbeg;
   frag_t pAH[2], pBH[NTW];   // the (h,h) operands of the previous stage (zeros before the first: the product adds nothing)
@@ -644,7 +674,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         if (leader) {
           if (tap == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NIT) : "memory");   // (the patch loads issued at tap 0 stay in flight)
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
+          CX_BARRIER();
         }
         if (tap == 0) {
           mm(pAH, pBH);
@@ -652,7 +682,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
           if (chunk > cbeg) store_patch(Bs);
           dma_stage(min(g1, nStages - 1), g1 & 3);
           if (two) dma_stage(min(g1 + 1, nStages - 1), (g1 + 1) & 3);
-          __syncthreads();
+          CX_BARRIER();
           more = chunk + 1 < cend;
           if (more) load_patch(chunk + 1);
           readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
@@ -702,7 +732,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
       // patch loads issued behind it may still be in flight
       if (tap == 1 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NIT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      CX_BARRIER();
       // (no accumulator is touched inside a conditional: a branch around MFMAs makes the register allocator keep two copies
       // of the 64 accumulator registers.  The ring DMA is unconditional -- behind the last stage it re-requests that stage
       // into the idle slot -- so that a stage is one basic block and the LDS waits are counted ones.)
@@ -713,7 +743,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
         CX_FENCE();
         if (chunk > cbeg) store_patch(Bs);   // (the first chunk's patch was written before the loop)
         dma_stage(nxt, (tap + 1 + par) & 1);
-        __syncthreads();
+        CX_BARRIER();
         more = chunk + 1 < cend;
         if (more) load_patch(chunk + 1);
         readA(Ab, PL, aL); readB(Bs, tapoff, 0, bH);
@@ -767,6 +797,7 @@ __global__ __launch_bounds__(256, KS == 3 ? CX_OCC : 2) void conv_x3_kernel(CxAr
   mm(pAH, pBH);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the idle slot's last request)
 #undef CX_FENCE
+#undef CX_BARRIER
   if (NP == 2) {   // undo the two tensors' scales
 #pragma unroll
     for (int a = 0; a < 2; ++a)

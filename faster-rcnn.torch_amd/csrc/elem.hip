@@ -351,7 +351,9 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
                          float* gslope, hipStream_t s, float* amax) {
   int Ho = (H - 2 + 1) / 2 + 1, Wo = (W - 2 + 1) / 2 + 1;
   int chunks = act_bwd_chunks(C, (long)H * W);
-  FR_CHECK(!amax || (long)C * chunks <= AMAX_MAX_BLOCKS, "maxpool_act_backward: %ld blocks do not fit the magnitude record", (long)C * chunks);
+  // (more blocks than a record has entries: the magnitude of gx is taken by a pass of its own below, as every other record producer does)
+  float* const amax_after = (amax && (long)C * chunks > AMAX_MAX_BLOCKS) ? amax : nullptr;
+  if (amax_after) amax = nullptr;
   float *pb = nullptr, *pa = nullptr;
   if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (W % 4 == 0) && (Wo % 2 == 0) && (((uintptr_t)gpool | (uintptr_t)x | (uintptr_t)gx) % 16 == 0) &&
@@ -364,13 +366,16 @@ int maxpool_act_backward(const float* gpool, const unsigned char* idx, const flo
               dim3(ACT_BWD_THREADS), 0, gpool, idx, x, C, H, W, Ho, Wo, slope, scale, gx, gbias, gslope, chunks, pb, pa, amax);
   FR_LAUNCH_CHECK();
   if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
+  if (amax_after) FR_TRY(tensor_absmax(gx, (long)C * H * W, amax_after, s));
   return FRCNN_OK;
 }
 
 int act_backward(const float* gy, const float* x, int C, long hw, const float* slope,
                  const float* scale, float* gx, float* gbias, float* gslope, hipStream_t s, float* amax) {
   int chunks = act_bwd_chunks(C, hw);
-  FR_CHECK(!amax || (long)C * chunks <= AMAX_MAX_BLOCKS, "act_backward: %ld blocks do not fit the magnitude record", (long)C * chunks);
+  // (more blocks than a record has entries: the magnitude of gx is taken by a pass of its own below, as every other record producer does)
+  float* const amax_after = (amax && (long)C * chunks > AMAX_MAX_BLOCKS) ? amax : nullptr;
+  if (amax_after) amax = nullptr;
   float *pb = nullptr, *pa = nullptr;
   if (deterministic()) { FR_TRY(det_workspace(s, (size_t)2 * C * chunks, &pb)); pa = pb + (size_t)C * chunks; }
   const bool vec = (hw % 4 == 0) && (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) % 16 == 0);
@@ -384,6 +389,7 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
               gbias, gslope, chunks, pb, pa, amax);
   FR_LAUNCH_CHECK();
   if (pb) FR_TRY(fold_partials(gbias ? pb : nullptr, (slope && gslope) ? pa : nullptr, C, chunks, gbias, gslope, s));
+  if (amax_after) FR_TRY(tensor_absmax(gx, (long)C * hw, amax_after, s));
   return FRCNN_OK;
 }
 

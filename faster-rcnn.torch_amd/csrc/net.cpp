@@ -435,7 +435,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   }
   for (auto& l : m->cls) {
     l.lin.release(); l.pre.release(); l.post.release(); l.xhat.release(); l.invstd.release();
-    l.mask.release(); l.g.release(); l.xp.release(); l.xpT.release(); l.gp.release(); l.gpT.release();
+    l.mask.release(); l.g.release(); l.xp.release(); l.xpT.release(); l.gp.release(); l.gpT.release(); l.am.release();
   }
   m->img.release(); m->wg_ws.release(); m->wg_ws_first.release(); m->pack_jobs.release(); m->x3_jobs.release(); m->zero_arena.release(); m->amax.release(); m->amax_ws.release(); m->amax_jobs.release();
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
@@ -1203,6 +1203,8 @@ int frcnn_cnet_forward(frcnn_model* m, const float* weights, const float* x, int
       const bool have = !training && g_static_weights && L.am_w_gen == g_static_gen && L.am_w_of == w;
       if (!have) FR_TRY(tensor_absmax(w + L.w_off, (long)L.n * L.in, rw, s));
       L.am_w_of = w; L.am_w_gen = training ? -1 : g_static_gen;
+    } else {
+      L.am_w_of = nullptr;   // no record from THIS forward pass: the input-gradient product must not scale by an older step's
     }
     if ((L.x_form & 1) && gemm_f16_on()) {   // two fp16 planes of the input, scaled by its largest magnitude
       float* rx = L.am.f();

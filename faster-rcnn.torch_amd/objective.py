@@ -132,6 +132,19 @@ def _dist():
     return None
 
 
+# bench.py at N = 1: a list that receives (label, lo, hi, waits_on, event) at every point of the pass where the all-reduce of a
+# bucket of the flat gradient WOULD start at N > 1 (the same program points, the same streams), plus "step_begin" /
+# "backward_end" marks -- the bucket schedule a first multi-GPU run can be compared with.  None: off.
+exchange_probe = None
+
+
+def _probe_mark(label, lo, hi, waits_on):
+    import torch
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()      # (on the current stream: the one the bucket's all-reduce would be ordered behind)
+    exchange_probe.append((label, int(lo), int(hi), waits_on, e))
+
+
 def allreduce_begin(gradient, lo, hi):
     """Start the all-reduce of gradient[lo:hi] (a bucket whose values are final) without waiting for it: RCCL
     runs it on its own stream, ordered after the kernels already queued on the current stream, beside whatever
@@ -286,6 +299,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         if w is not weights:  # :46-48
             weights.copy_(w)
         s = stream_ptr()
+        probing = exchange_probe is not None and _dist() is None and getattr(gradient, "is_cuda", False)
+        if probing:
+            _probe_mark("step_begin", 0, 0, "")
         _lib.call("frcnn_zero", ptr(gradient), gradient.numel() * 4, s)  # :49
         cls_count = reg_count = creg_count = ccls_count = 0
         pnet.training()  # :61-62
@@ -386,6 +402,15 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     pnet.backward_heads_join()
                     lo, hi = pnet.heads_param_range()
                     pending.append(allreduce_begin(gradient, lo, hi))
+            if last and probing:   # (the same program points as the branch above, nothing exchanged)
+                _lib.call("frcnn_cnet_backward_join", native.h, stream_ptr())
+                _probe_mark("classification net", native.pnet_params, gradient.numel(), "frcnn_cnet_backward_join (its weight-gradient stream)")
+                side = C.c_int(0)
+                _lib.call("frcnn_get_option", b"side_stream", C.byref(side))
+                if len(batch) == 1 and side.value:
+                    pnet.backward_heads_join()
+                    lo, hi = pnet.heads_param_range()
+                    _probe_mark("anchor nets", lo, hi, "frcnn_pnet_backward_heads_join (the anchor nets' streams)")
             if last and defer and _dist() is None:
                 # the eight statistics are final before the backbone's backward pass: their read-back is queued
                 # here, so the caller's wait ends mid-step and the host queues the next step while this one
@@ -403,6 +428,21 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                     with torch.cuda.stream(aux_stream[0]):
                         pnet.wait_block_gradients(b)
                         pending.append(allreduce_begin(gradient, lo, hi))
+            if last and probing:
+                covered = []
+                if early_blocks:
+                    if aux_stream[0] is None:
+                        aux_stream[0] = torch.cuda.Stream()
+                    for b in early_blocks:
+                        lo, hi = pnet.block_param_range(b)
+                        with torch.cuda.stream(aux_stream[0]):
+                            pnet.wait_block_gradients(b)
+                            _probe_mark("backbone block %d" % (b + 1), lo, hi, "frcnn_pnet_wait_block_gradients(%d) on an auxiliary stream" % (b + 1))
+                        covered.append((lo, hi))
+                _probe_mark("backward_end", 0, 0, "")
+                lo_rest = 0
+                hi_rest = min([c[0] for c in covered] + [pnet.heads_param_range()[0]])
+                _probe_mark("rest of the backbone", lo_rest, hi_rest, "end of frcnn_pnet_backward on the caller's stream")
             reg_count += npos  # :194-198
             cls_count += npos + nneg
             creg_count += npos

@@ -1,8 +1,9 @@
 """Split-bf16 operand form of the 3x3 convolution (csrc/convx.hip, option "split_bf16"): fp32 tensors in and out, every
 product formed from six exact bf16 x bf16 partial products on the bf16 matrix cores.  The claim under test: it is an fp32
 convolution -- against the CPU oracle (fp64 accumulation) its error is within the tolerance of the fp32 matrix-core kernel
-(|a-b| <= 1e-4 max(1,|b|)) AND no larger than that kernel's own error on the same inputs (factor 2 on the
-root-mean-square error, measured here for both forms)."""
+(|a-b| <= 1e-4 max(1,|b|)) AND comparable with that kernel's own error on the same inputs: per case at most
+RMS_GATE (1.75) times its root-mean-square error, and over all cases of the file no larger on the geometric mean (MEAN_GATE;
+round 6 measured 0.97 -- see the comment at RMS_GATE).  Both split forms (two fp16 planes / three bf16 planes) run every case."""
 import numpy as np
 import pytest
 
@@ -53,6 +54,24 @@ def _rms(a, want):
     return float(np.sqrt(np.mean((a.astype(np.float64) - want) ** 2)))
 
 
+# The split forms must be no worse than the fp32 matrix-core kernel of conv.hip against the fp64 oracle.  Both accumulate in fp32 in
+# different orders, so on one small shape the ratio of the two RMS errors is a random draw around 1 (round 6, MI355X, the 83 cases of
+# this file: 0.68 ... 1.63, geometric mean 0.97; gpurun_out/exp2/convx_ratios.txt).  What is asserted (round 5
+# allowed 2.0 per case and nothing overall): every case <= RMS_GATE, and over the whole file the geometric mean <= MEAN_GATE
+# (test_zz_error_ratio_over_the_file) -- "no larger on average, never much larger".  MAX_GATE: the same for a maximum over ~10^5 outputs.
+RMS_GATE = 1.75
+MEAN_GATE = 1.05
+RATIOS = []
+
+
+def _gate(es, ed, what=""):
+    r = es / max(ed, 1e-30)
+    RATIOS.append(r)
+    print('rms ratio split/fp32-mfma: %.3f %s' % (r, what))
+    assert es <= RMS_GATE * ed + 1e-9, (es, ed, what)
+STRESS_ROUNDS = 25    # repetitions of every full-size launch shape (the round-5 staging fault was timing dependent)
+MAX_GATE = 1.5
+
 SHAPES = [
     # C, H, W, O, pad      (C % 16 == 0 and O % 128 == 0: the shapes the split form takes)
     (64, 57, 100, 128, 1),      # b2 widths on a 57x100 map: ragged 5 x 25 tiles
@@ -84,7 +103,7 @@ def test_forward_is_an_fp32_convolution(F, O, both_forms, x3_form, C_, H, W, O_,
     assert not np.array_equal(split, direct), "the option did not switch the kernel"
     assert_close(split, want, 1e-4, "split-bf16 conv fwd")
     es, ed = _rms(split, want), _rms(direct, want)
-    assert es <= 2.0 * ed + 1e-9, (es, ed)
+    _gate(es, ed)
 
 
 def test_wide_dynamic_range(F, O, both_forms, x3_form):
@@ -108,7 +127,7 @@ def test_wide_dynamic_range(F, O, both_forms, x3_form):
     rd = np.abs(direct - want) / mag
     print("max error / sum of magnitudes: split %.3e  fp32 MFMA %.3e" % (rs.max(), rd.max()))
     assert rs.max() <= 4e-6, rs.max()
-    assert rs.max() <= 2.0 * rd.max() + 1e-9, (rs.max(), rd.max())
+    assert rs.max() <= MAX_GATE * rd.max() + 1e-9, (rs.max(), rd.max())
 
 
 def test_fused_activation_of_the_producing_layer(F, O, both_forms, x3_form):
@@ -154,7 +173,7 @@ def test_input_gradient(F, O, both_forms, x3_form, C_, H, W, O_, pad):
     assert not np.array_equal(split, direct)
     assert_close(split, want, 1e-4, "split-bf16 conv dgrad")
     assert_close(split2, 2 * want, 2e-4, "split-bf16 conv dgrad accumulate")
-    assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
+    _gate(_rms(split, want), _rms(direct, want))
 
 
 def _tap_equal(got, tap, wmax, f16):
@@ -265,7 +284,7 @@ def test_weight_gradient(F, O, both_forms, x3_form, C_, H, W, O_, pad):
     assert not np.array_equal(split, direct), "the option did not switch the kernel"
     assert_close(split, gw_want, 1e-4, "split-bf16 conv wgrad")
     assert_close(split2, 2 * gw_want, 2e-4, "split-bf16 conv wgrad accumulates")
-    assert _rms(split, gw_want) <= 2.0 * _rms(direct, gw_want) + 1e-9
+    _gate(_rms(split, gw_want), _rms(direct, gw_want))
 
 
 @pytest.mark.parametrize("W", [34, 36, 48])   # 36 / 48: the 16-byte-segment loader (W % 4 = 0), 34: the per-element one
@@ -303,7 +322,7 @@ def test_anchor_net_kernel_sizes(F, O, both_forms, x3_form, C_, H, W, O_, k):
     split, direct = both_forms(fwd)
     assert not np.array_equal(split, direct), "the option did not switch the kernel"
     assert_close(split, want, 1e-4, "split-bf16 %dx%d conv fwd" % (k, k))
-    assert _rms(split, want) <= 2.0 * _rms(direct, want) + 1e-9
+    _gate(_rms(split, want), _rms(direct, want))
     if C_ % 128 == 0 and O_ % 16 == 0:   # input gradient: M = C
         Ho, Wo = H - k + 1, W - k + 1
         g = rng.randn(O_, Ho, Wo).astype(np.float32)
@@ -330,7 +349,7 @@ MODEL_LAYERS = [  # name, Cin, H, W, Cout, pad -- the 3x3 launches of a vgg_smal
 def test_model_layer_shapes_full_size(F, x3_form, name, C_, H, W, O_, pad):
     """Every 3x3 launch shape of the benchmarked step at FULL size -- forward without and with the fused input activation
     (PReLU slope + dropout scale: the <SLOPE, SCALE> instantiations), and the input gradient -- against the fp32 matrix-core
-    kernel on the same inputs, three times each.  The small shapes above did not catch a timing-dependent fault of the
+    kernel on the same inputs, STRESS_ROUNDS (25) times each (round 5 ran three: VERDICT r5 next 4).  The small shapes above did not catch a timing-dependent fault of the
     activation path that only showed with hundreds of blocks in flight (round 5: packed multiplies, convx.hip store_patch);
     the oracle is too slow for these sizes, the fp32 kernel (itself oracle-checked above and in test_gpu_conv.py) is not."""
     rng = np.random.RandomState(1)
@@ -354,7 +373,7 @@ def test_model_layer_shapes_full_size(F, x3_form, name, C_, H, W, O_, pad):
     try:
         want = [fwd(0), fwd(1), dgrad()]
         _option(F, "split_bf16", 1)
-        for _ in range(3):
+        for _ in range(STRESS_ROUNDS):
             for got, ref, what in zip([fwd(0), fwd(1), dgrad()], want, ("forward", "forward + fused activation", "input gradient")):
                 assert_close(got, ref, 2e-4, "%s %s, split form vs fp32 matrix-core kernel" % (name, what))
     finally:
@@ -386,3 +405,13 @@ def test_anchor_net_shapes_full_size(F, x3_form, k):
             assert_close(got, want, 2e-4, "%dx%d anchor net, split form vs fp32 matrix-core kernel" % (k, k))
     finally:
         _option(F, "split_bf16", before)
+
+
+def test_zz_error_ratio_over_the_file(F):
+    """Runs last (file order): over every comparison of this file the split forms' RMS error against the fp64 oracle is, on the
+    geometric mean, no larger than the fp32 matrix-core kernel's (MEAN_GATE leaves 5 % for the draw of one run)."""
+    if len(RATIOS) < 20:
+        pytest.skip("only %d comparisons ran (a filtered session)" % len(RATIOS))
+    gm = float(np.exp(np.mean(np.log(np.maximum(RATIOS, 1e-12)))))
+    print("split / fp32-MFMA RMS error over %d comparisons: geometric mean %.3f, min %.3f, max %.3f" % (len(RATIOS), gm, min(RATIOS), max(RATIOS)))
+    assert gm <= MEAN_GATE, (gm, len(RATIOS))
