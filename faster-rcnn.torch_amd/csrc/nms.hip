@@ -36,27 +36,40 @@ __global__ void nms_prep_kernel(const float* __restrict__ boxes, int n, const in
 }
 
 // rank[i] = #{ j : key[j] < key[i]  or (key[j] == key[i] and j < i) }; sorted[n-1-rank] = i.
-// 2-D grid: block (x, y) counts, for its 256 keys i, the keys j of slice y; partial counts meet in an integer
-// atomic (exact, order-independent), then nms_scatter_kernel writes the permutation.
-#define NMS_RANK_SLICE 1024
-__global__ void nms_rank_kernel(const float* __restrict__ key, int n, const int* __restrict__ n_dev, int* __restrict__ rank) {
-  __shared__ float sk[256];
+// 2-D grid: block (x, y) counts, for its 256 keys i, the 256 keys j of slice y (one LDS image, one barrier, 64 broadcast reads of
+// four keys); partial counts meet in an integer atomic (exact, order-independent), then nms_scatter_kernel writes the permutation.
+// Off the diagonal the tie rule is a constant (j < i for every pair of a block below the diagonal, never above it).  Round 6:
+// slices of 256 instead of 1024 keys -- a thread's 1 024 dependent compare steps were the whole 30 us of the launch at any n,
+// with one block per compute unit.
+#define NMS_RANK_SLICE 256
+__global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ key, int n, const int* __restrict__ n_dev, int* __restrict__ rank) {
+  __shared__ __attribute__((aligned(16))) float sk[NMS_RANK_SLICE];
   if (n_dev) n = min(*n_dev, n);
-  if ((int)(blockIdx.x * blockDim.x) >= n || (int)(blockIdx.y * NMS_RANK_SLICE) >= n) return;   // (uniform per block)
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ib = blockIdx.x, jb = blockIdx.y, t = threadIdx.x;
+  if (ib * 256 >= n || jb * NMS_RANK_SLICE >= n) return;   // (uniform per block)
+  const int i = ib * 256 + t, j = jb * NMS_RANK_SLICE + t;
   const float ki = i < n ? key[i] : 0.f;
-  const int jbeg = blockIdx.y * NMS_RANK_SLICE, jend = min(jbeg + NMS_RANK_SLICE, n);
+  sk[t] = j < n ? key[j] : __builtin_nanf("");   // (past the end: compares false both ways)
+  __syncthreads();
   int r = 0;
-  for (int j0 = jbeg; j0 < jend; j0 += 256) {
-    int j = j0 + threadIdx.x;
-    sk[threadIdx.x] = j < jend ? key[j] : 0.f;
-    __syncthreads();
-    const int lim = min(256, jend - j0);
-    for (int t = 0; t < lim; ++t) {
-      const float kj = sk[t];
-      r += (kj < ki || (kj == ki && (j0 + t) < i)) ? 1 : 0;
+  const float4* s4 = reinterpret_cast<const float4*>(sk);
+  if (jb < ib) {
+#pragma unroll 8
+    for (int q = 0; q < NMS_RANK_SLICE / 4; ++q) {
+      const float4 k = s4[q];
+      r += (k.x <= ki) + (k.y <= ki) + (k.z <= ki) + (k.w <= ki);
     }
-    __syncthreads();
+  } else if (jb > ib) {
+#pragma unroll 8
+    for (int q = 0; q < NMS_RANK_SLICE / 4; ++q) {
+      const float4 k = s4[q];
+      r += (k.x < ki) + (k.y < ki) + (k.z < ki) + (k.w < ki);
+    }
+  } else {
+    for (int q = 0; q < NMS_RANK_SLICE; ++q) {
+      const float kj = sk[q];
+      r += (kj < ki || (kj == ki && q < t)) ? 1 : 0;
+    }
   }
   if (i < n && r) atomicAdd(rank + i, r);
 }
@@ -115,77 +128,212 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, int ncols, cons
   mask[(size_t)rpos * nw + cb] = bits;
 }
 
-// Greedy scan in sorted order, 64 boxes per step, as a two-stage pipeline with ONE barrier per step.  In step g wave 0 resolves
-// the 64 x 64 diagonal block of group g serially in registers (the next step's diagonal words are already in flight), emits the
-// picks, and ORs word g + 1 of the rows it kept into `removed` -- the only word step g + 1 needs from them.  The other fifteen
-// waves meanwhile OR the REST of the mask rows (words >= g + 1) of the boxes kept in step g - 1.  So at the start of step g + 1 word
-// g + 1 holds every contribution: group g's by wave 0, group g - 1's by the background waves, older groups' by earlier steps.
-// (Round 4's scan had the two phases one after the other behind a barrier each: 1.5 us a step, 229 us a frame of Detector:detect.)
+// Greedy scan in sorted order, 64 boxes per step, ONE barrier per step; a step is as long as the instruction stream of its
+// longest wave (a wave issues one instruction every four cycles at best), so round 6 splits the step's work over three roles and
+// takes every memory round trip out of it:
+//   wave 0          resolves the 64 x 64 diagonal block of group g serially in scalar registers (one iteration per KEPT box), ORs
+//                   word g + 1 of the rows it keeps as it goes, emits the picks and publishes the kept set of the group;
+//   waves 1..NMS_NU ("helpers", one step behind): wave k ORs word (g - 1) + 1 + k of the rows kept in group g - 1 -- final one
+//                   barrier later, i.e. at step g + 1 <= the step that reads that word;
+//   wave NMS_NU + 1 ("emitter", one step behind, stores only): writes the sorted POSITIONS of the kept rows to pick[]; when the scan
+//                   is over the whole block turns positions into box ids (pick[i] = sorted[pick[i]] + 1).  Kept apart because on
+//                   gfx950 loads and stores share the vmcnt counter and may complete out of order: a wave with both in flight
+//                   makes the compiler wait for everything (vmcnt(0)) -- in the scan wave that was a full memory round trip;
+//   the other waves ("background") OR the words > h + 1 + NMS_NU of the rows kept in group h: requested in step h + 1 (a wave takes
+//                   whole rows, its lanes 64 consecutive words: no per-thread index arithmetic), ORed NMS_LEAD - 1 steps later.
+// Everything wave 0 and the helpers read from memory -- the diagonal word, the words behind it, the box ids of a group's 64 rows --
+// does not depend on any decision: it is requested NMS_LEAD - 1 steps ahead, branch-free (clamped addresses, masked at use) so that
+// the compiler's wait counts stay exact, and sits in registers when its step starts.  The step barrier is a bare s_barrier.
+// (Round 5: one wave did the scan AND the next word's ORs through the compiler's per-lane atomic loop, ~560 instructions = 1.3 us a
+// step whatever the block size: 170 us of a Detector:detect frame's 8 000-box scan.)
+#ifndef NMS_RED_THREADS
 #define NMS_RED_THREADS 1024
+#endif
+#define NMS_LEAD 4              // register sets: operands are requested NMS_LEAD - 1 steps before they are used
+#define NMS_NU NMS_LEAD         // helper waves = words behind word g + 1 that are ORed one step behind the scan
+#ifndef NMS_BG_ITEMS
+#define NMS_BG_ITEMS 4          // mask words a background lane requests per step (64-word pieces of the rows its wave takes)
+#endif
+#define NMS_EMIT_WAVE (NMS_NU + 1)
+#define NMS_BG_WAVES (NMS_RED_THREADS / 64 - 2 - NMS_NU)
+// the step barrier: a bare s_barrier behind lgkmcnt(0) (this wave's LDS atomics and list writes are done).  __syncthreads() also
+// carries a release fence for GLOBAL memory, which on gfx950 is `s_waitcnt vmcnt(0)`: it would wait for the pick store of the step
+// and, with it, for every operand requested ahead.  Nothing in global memory is exchanged between the waves of this kernel.
+#define NMS_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsigned long long* __restrict__ mask,
                                                                      const int* __restrict__ sorted, int n,
                                                                      const int* __restrict__ n_dev, int nwp,
                                                                      long long* __restrict__ pick, int* __restrict__ count) {
-  extern __shared__ unsigned long long removed[];  // [nw]
+  extern __shared__ unsigned long long removed[];  // [nw + NMS_NU + 1]
   if (n_dev) n = min(*n_dev, n);
   const int nw = (n + 63) >> 6;   // words of this run; nwp = pitch of the mask rows (the host-side bound)
   __shared__ int kept_list[2][64];
   __shared__ int nkept[2];
-  __shared__ int cnt;
-  for (int w = threadIdx.x; w < nw; w += blockDim.x) removed[w] = 0ull;
-  if (threadIdx.x == 0) { cnt = 0; nkept[0] = nkept[1] = 0; }
-  unsigned long long diag_next = 0ull;
-  if (threadIdx.x < 64 && (int)threadIdx.x < n) diag_next = mask[(size_t)threadIdx.x * nwp];
+  __shared__ unsigned long long keptw[2];
+  __shared__ int cntw[2], total;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int w = tid; w < nw + NMS_NU + 1; w += blockDim.x) removed[w] = 0ull;
+  if (tid < 2) { nkept[tid] = 0; keptw[tid] = 0ull; }
+  if (n <= 0) { if (tid == 0) *count = 0; return; }
   __syncthreads();
-  for (int g = 0; g < nw; ++g) {
-    if (threadIdx.x < 64) {  // wave 0: group g
-      const int row = g * 64 + threadIdx.x;
-      const unsigned long long diag = diag_next;
-      const int nrow = row + 64;
-      if (g + 1 < nw) diag_next = nrow < n ? mask[(size_t)nrow * nwp + g + 1] : 0ull;
-      // this row's word g + 1, requested before the serial part (needed only if the row is kept)
-      const unsigned long long urgent = (g + 1 < nw && row < n) ? mask[(size_t)row * nwp + g + 1] : 0ull;
-      // wave-uniform bit sets in scalar registers; one step per KEPT box (first clear bit), not per box
-      const unsigned long long w0 = removed[g];
-      unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
-                                (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
-      const int lim = min(64, n - g * 64);
-      if (lim < 64) word |= ~0ull << lim;          // positions past the last box count as removed
-      unsigned long long kept = 0ull;
-      const int dlo = (int)diag, dhi = (int)(diag >> 32);
-      while (~word) {
-        const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)~word) - 1);
-        kept |= 1ull << t;
-        const unsigned long long dt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, t) << 32) |
-                                      (unsigned)__builtin_amdgcn_readlane(dlo, t);
-        word |= dt | (1ull << t);
-      }
-      // emit picks in order; the kept rows' word g + 1 goes into `removed` now, the rest of their rows in the next step
-      const int base = cnt;
-      if ((kept >> threadIdx.x) & 1ull) {
-        const int before = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
-        pick[base + before] = (long long)sorted[row] + 1;  // 1-based like the Lua surface
-        kept_list[g & 1][before] = row;
-        if (urgent) atomicOr(&removed[g + 1], urgent);
-      }
-      if (threadIdx.x == 0) {
-        nkept[g & 1] = __popcll(kept);
-        cnt = base + __popcll(kept);
-      }
-    } else if (g > 0) {      // waves 1..15: the rest of the rows kept in step g - 1 (their word g went in during that step)
-      const int nk = nkept[(g - 1) & 1], W = nw - (g + 1);
-      const int items = nk * W;
-      const int* kl = kept_list[(g - 1) & 1];
-      for (int it = (int)threadIdx.x - 64; it < items; it += NMS_RED_THREADS - 64) {
-        const int q = it / W, w = g + 1 + (it - q * W);
-        const unsigned long long v = mask[(size_t)kl[q] * nwp + w];
-        if (v) atomicOr(&removed[w], v);
+  if (wave == 0) {
+    // ---- the scan.  Register set d: group g's diagonal word and word g + 1 of this lane's row
+    unsigned long long dg[NMS_LEAD], u0[NMS_LEAD];
+    auto request = [&](int d, int g) {
+      const int gc = min(g, nw - 1);
+      const int row = min(gc * 64 + lane, n - 1);   // (past the end: harmless repeats, masked when used)
+      const unsigned long long* mr = mask + (size_t)row * nwp;
+      dg[d] = mr[gc];
+      u0[d] = mr[min(gc + 1, nw - 1)];
+    };
+#pragma unroll
+    for (int d = 0; d < NMS_LEAD; ++d) { dg[d] = 0ull; u0[d] = 0ull; }
+#pragma unroll
+    for (int d = 0; d < NMS_LEAD - 1; ++d) request(d, d);
+    int cnt = 0;               // picks so far (uniform)
+    for (int g0 = 0; g0 < nw; g0 += NMS_LEAD) {
+#pragma unroll
+      for (int d = 0; d < NMS_LEAD; ++d) {
+        const int g = g0 + d;
+        if (g >= nw) break;    // (uniform)
+        const int row = g * 64 + lane;
+        const bool rok = row < n;
+        const unsigned long long diag = rok ? dg[d] : 0ull;
+        const unsigned long long nxt = (rok && g + 1 < nw) ? u0[d] : 0ull;
+        request((d + NMS_LEAD - 1) % NMS_LEAD, g + NMS_LEAD - 1);   // (into the set consumed in the previous step)
+        // wave-uniform bit sets in scalar registers; one iteration per KEPT box (first clear bit), not per box
+        const unsigned long long w0 = removed[g];
+        unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w0 >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
+        const int lim = min(64, n - g * 64);
+        if (lim < 64) word |= ~0ull << lim;          // positions past the last box count as removed
+        unsigned long long kept = 0ull, acc = 0ull;  // acc: word g + 1 of the kept rows, ORed as they are found
+        const int dlo = (int)diag, dhi = (int)(diag >> 32), nlo = (int)nxt, nhi = (int)(nxt >> 32);
+        while (~word) {
+          const int t = __builtin_amdgcn_readfirstlane(__ffsll((long long)~word) - 1);
+          kept |= 1ull << t;
+          const unsigned long long dt = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, t) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane(dlo, t);
+          acc |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(nhi, t) << 32) | (unsigned)__builtin_amdgcn_readlane(nlo, t);
+          word |= dt | (1ull << t);
+        }
+        if (lane == 0) {
+          if (acc) atomicOr(&removed[g + 1], acc);   // (the background waves OR into the same words)
+          keptw[g & 1] = kept;
+          nkept[g & 1] = __popcll(kept);
+          cntw[g & 1] = cnt;
+        }
+        if ((kept >> lane) & 1ull)     // the kept rows' sorted positions, in order: for the background waves and the emitter
+          kept_list[g & 1][__popcll(kept & ((1ull << lane) - 1ull))] = row;
+        cnt += __popcll(kept);
+        NMS_STEP_BARRIER();
       }
     }
-    __syncthreads();
+    if (lane == 0) total = cnt;
+  } else if (wave <= NMS_NU) {
+    // ---- helper k = wave: in step g, word (g - 1) + 1 + k = g + k of the rows kept in group g - 1
+    const int k = wave;
+    unsigned long long un[NMS_LEAD];
+    auto request = [&](int d, int g) {     // operands of step g
+      const int gc = min(max(g - 1, 0), nw - 1);
+      const int row = min(gc * 64 + lane, n - 1);
+      un[d] = mask[(size_t)row * nwp + min(gc + 1 + k, nw - 1)];
+    };
+#pragma unroll
+    for (int d = 0; d < NMS_LEAD; ++d) un[d] = 0ull;
+#pragma unroll
+    for (int d = 0; d < NMS_LEAD - 1; ++d) request(d, d);
+    for (int g0 = 0; g0 < nw; g0 += NMS_LEAD) {
+#pragma unroll
+      for (int d = 0; d < NMS_LEAD; ++d) {
+        const int g = g0 + d;
+        if (g >= nw) break;    // (uniform)
+        const unsigned long long v = un[d];
+        request((d + NMS_LEAD - 1) % NMS_LEAD, g + NMS_LEAD - 1);
+        if (g > 0 && g + k < nw) {
+          const unsigned long long kept = keptw[(g - 1) & 1];      // (published by the barrier that ended step g - 1)
+          if (((kept >> lane) & 1ull) && v) atomicOr(&removed[g + k], v);   // (a row of the kept set exists: < n)
+        }
+        NMS_STEP_BARRIER();
+      }
+    }
+  } else if (wave == NMS_EMIT_WAVE) {
+    // ---- emitter: in step g the picks of group g - 1 (stores only; the last group's after the loop)
+    for (int g = 0; g < nw; ++g) {
+      if (g > 0 && lane < nkept[(g - 1) & 1]) pick[cntw[(g - 1) & 1] + lane] = (long long)kept_list[(g - 1) & 1][lane];
+      NMS_STEP_BARRIER();
+    }
+    if (lane < nkept[(nw - 1) & 1]) pick[cntw[(nw - 1) & 1] + lane] = (long long)kept_list[(nw - 1) & 1][lane];
+  } else {
+    // ---- background: words in flight across barriers, one slot per step of lead
+    const int bwave = wave - 2 - NMS_NU;
+    unsigned long long bv[NMS_LEAD][NMS_BG_ITEMS];
+    int bw[NMS_LEAD][NMS_BG_ITEMS];      // the word each one belongs to (-1: none)
+#pragma unroll
+    for (int d = 0; d < NMS_LEAD; ++d)
+#pragma unroll
+      for (int j = 0; j < NMS_BG_ITEMS; ++j) { bv[d][j] = 0ull; bw[d][j] = -1; }
+    for (int g0 = 0; g0 < nw; g0 += NMS_LEAD) {
+#pragma unroll
+      for (int d = 0; d < NMS_LEAD; ++d) {
+        const int g = g0 + d;
+        if (g >= nw) break;    // (uniform)
+        // (a) the words requested NMS_LEAD - 1 steps ago (rows kept in group g - NMS_LEAD): slot d + 1
+        const int dc = (d + 1) % NMS_LEAD;   // (compile-time: the loop is unrolled)
+#pragma unroll
+        for (int j = 0; j < NMS_BG_ITEMS; ++j) {
+          if (bw[dc][j] >= 0 && bv[dc][j]) atomicOr(&removed[bw[dc][j]], bv[dc][j]);
+          bw[dc][j] = -1;
+        }
+        // (b) request words > (g - 1) + 1 + NMS_NU of the rows kept in group g - 1 into slot d: ORed in step g + NMS_LEAD - 1,
+        //     final from step g + NMS_LEAD = (g - 1) + 1 + NMS_NU + 1 on, the first step that reads such a word.  A wave takes
+        //     whole rows (kept row q = wave, wave + NMS_BG_WAVES, ...), its lanes 64 consecutive words of the row.  Branch-free:
+        //     a lane without a word reads the first word of the matrix and drops it.
+        {
+          const int wfirst = g + 1 + NMS_NU;
+          const int nk = __builtin_amdgcn_readfirstlane(g > 0 ? nkept[(g - 1) & 1] : 0);
+          const int W = nw - wfirst, nchunks = (W + 63) >> 6;
+          const int* kl = kept_list[(g - 1) & 1];
+          int q = W > 0 ? bwave : nk, c = 0;      // (q >= nk: nothing to do; q, c wave-uniform: scalar registers)
+          // three passes, so that the slots' LDS reads (the kept rows' numbers) are in flight together: one LDS round trip a step
+          int qs[NMS_BG_ITEMS], cs[NMS_BG_ITEMS], rs[NMS_BG_ITEMS];
+#pragma unroll
+          for (int j = 0; j < NMS_BG_ITEMS; ++j) {
+            qs[j] = q; cs[j] = c;
+            if (++c >= nchunks) { c = 0; q += NMS_BG_WAVES; }
+          }
+#pragma unroll
+          for (int j = 0; j < NMS_BG_ITEMS; ++j) rs[j] = kl[qs[j] < nk ? qs[j] : 0];
+#pragma unroll
+          for (int j = 0; j < NMS_BG_ITEMS; ++j) {
+            // the row's base is a scalar (one LDS word, broadcast), the lane adds its word: base + offset addressing
+            const unsigned long long* rowp = mask + (size_t)__builtin_amdgcn_readfirstlane(rs[j]) * nwp;
+            const int w = wfirst + cs[j] * 64 + lane;
+            const bool has = qs[j] < nk && w < nw;
+            bv[d][j] = rowp[has ? w : 0];         // (unconditional load: the number of loads of a step is fixed, the waits counted)
+            bw[d][j] = has ? w : -1;
+          }
+          while (q < nk) {   // more rows / longer rows than the registers hold: at once
+            const int w = wfirst + c * 64 + lane;
+            if (w < nw) {
+              const unsigned long long v = mask[(size_t)kl[q] * nwp + w];
+              if (v) atomicOr(&removed[w], v);
+            }
+            if (++c >= nchunks) { c = 0; q += NMS_BG_WAVES; }
+          }
+        }
+        NMS_STEP_BARRIER();
+      }
+    }
   }
-  if (threadIdx.x == 0) *count = cnt;
+  // ---- every wave: positions -> box ids, 1-based like the Lua surface (the emitter's stores are visible behind the fence)
+  __syncthreads();
+  const int cnt_all = total;
+  for (int i = tid; i < cnt_all; i += blockDim.x) pick[i] = (long long)sorted[(int)pick[i]] + 1;
+  if (tid == 0) *count = cnt_all;
 }
+#undef NMS_STEP_BARRIER
 
 size_t nms_workspace_bytes(int n) {
   size_t nw = (size_t)cdiv(n, 64);
@@ -208,7 +356,7 @@ int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode
   FR_CHECK(ws_bytes >= nms_workspace_bytes(n), "nms: workspace too small (%zu < %zu)", ws_bytes,
            nms_workspace_bytes(n));
   const int nw = cdiv(n, 64);
-  FR_CHECK((size_t)nw * 8 <= 64 * 1024, "nms: n=%d too large (max 524288)", n);
+  FR_CHECK((size_t)(nw + NMS_NU + 1) * 8 <= 64 * 1024, "nms: n=%d too large (max 523968)", n);
   char* base = (char*)(((uintptr_t)ws + 255) / 256 * 256);
   float* area = (float*)base;
   float* key = area + n;
@@ -224,7 +372,7 @@ int nms_device(const float* boxes, int n, int ncols, float overlap, int key_mode
   FR_LAUNCH(KC_NMS, 0, 8.0 * n, s, nms_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (const int*)rank, n, n_dev, sorted);
   FR_LAUNCH(KC_NMS, 3.5 * n * (double)n, 8.0 * n * nw / 2, s, nms_mask_kernel, dim3(nw, nw), dim3(64), 0,
             boxes, ncols, area, sorted, n, n_dev, nw, overlap, cls, mask);
-  FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(NMS_RED_THREADS), (size_t)nw * 8, mask,
+  FR_LAUNCH(KC_NMS, 0, 8.0 * n * nw / 2, s, nms_reduce_kernel, dim3(1), dim3(NMS_RED_THREADS), (size_t)(nw + NMS_NU + 1) * 8, mask,
             sorted, n, n_dev, nw, pick, count);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
