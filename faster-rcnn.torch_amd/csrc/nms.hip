@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NMS_RED_THREADS) void nms_reduce_kernel(const unsig
             if (++c >= nchunks) { c = 0; q += NMS_BG_WAVES; }
           }
 #pragma unroll
-          for (int j = 0; j < NMS_BG_ITEMS; ++j) rs[j] = kl[qs[j] < nk ? qs[j] : 0];
+          for (int j = 0; j < NMS_BG_ITEMS; ++j) rs[j] = qs[j] < nk ? kl[qs[j]] : 0;   // (no row: row 0 -- the list holds nothing defined there)
 #pragma unroll
           for (int j = 0; j < NMS_BG_ITEMS; ++j) {
             // the row's base is a scalar (one LDS word, broadcast), the lane adds its word: base + offset addressing

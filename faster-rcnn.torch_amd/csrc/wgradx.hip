@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
     bool ok[13];
     int oy0, ox0;   // origin of the tile the set holds
   };
+#ifdef WX_ONE_SET   // (experiment, round 6: one prefetch set -- 52 registers fewer, a block then fits beside a conv_x3 block; one tile less lead)
+  Pre pre[1];
+#else
   Pre pre[2];
+#endif
   // ---- the work that rides under the MFMAs, cut into MICRO-STEPS of about five VALU instructions.  Steps of item `it`
   // (0..3 gradient rows, 4..12 patch segments): load (one 16-byte segment, branch-free: a segment outside the image reads the
   // tensor's first elements and is zeroed later) | prepare (zero / activation) | split pair 0: level 1, levels 2 + 3 | split
@@ -406,10 +410,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   constexpr int NST = 4 * 5 + 9 * (9 - XPH0);   // staging steps of a whole tile
   static_for<NST>([&](auto sc) { stage_seq(std::integral_constant<int, 0>{}, sc, gdst, xdst, pre[0]); });
   __syncthreads();
+#ifdef WX_ONE_SET
+  load_origin(pre[0]);                                                // tile 1
+  static_for<13>([&](auto itc) { load_step(itc, pre[0]); });
+#else
   load_origin(pre[1]);                                                // tile 1
   static_for<13>([&](auto itc) { load_step(itc, pre[1]); });
   load_origin(pre[0]);                                                // tile 2
   static_for<13>([&](auto itc) { load_step(itc, pre[0]); });
+#endif
   read_row(0, 0);
   static_for<2 * NP>([&](auto sc) { cut_step(sc); });
 #pragma unroll
@@ -472,8 +481,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   };
   {
     int i = 0;
+#ifdef WX_ONE_SET
+    for (; i < nT; ++i) tile(i, pre[0]);
+#else
     for (; i + 1 < nT; i += 2) { tile(i, pre[1]); tile(i + 1, pre[0]); }
     if (i < nT) tile(i, pre[1]);
+#endif
   }
   // ---- bias gradient: the blocks of channel tile 0 saw every gradient tile of their filters exactly once
   if (p.gbias && ct == 0) {

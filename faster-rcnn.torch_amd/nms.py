@@ -30,12 +30,13 @@ def nms(boxes, overlap, scores=None):
         ncols = boxes.shape[1]
         wsb = _lib.load().frcnn_nms_workspace_bytes(n)
         ws = DeviceTensor.empty((wsb,), np.uint8)
-        pick = DeviceTensor.empty((n,), np.int64)
-        count = DeviceTensor.empty((1,), np.int32)
+        # picks and their count in ONE device buffer (the count behind the n ids): one read-back, one wait for the device
+        pick = DeviceTensor.empty((n + 1,), np.int64)
         _lib.call("frcnn_nms_device", ptr(boxes), n, ncols, C.c_float(overlap), key_mode, key_col, ptr(pick),
-                  ptr(count), ptr(ws), wsb, stream_ptr())
-        k = int(count.numpy()[0])
-        return pick.numpy()[:k].copy()
+                  C.c_void_p(pick.ptr + 8 * n), ptr(ws), wsb, stream_ptr())
+        host = pick.numpy()
+        k = int(host[n:].view(np.int32)[0])
+        return host[:k].copy()
     b = np.ascontiguousarray(boxes.detach().cpu().numpy() if hasattr(boxes, "detach") else boxes, dtype=np.float32)
     if b.size == 0:  # nms.lua:26-28
         return np.zeros(0, dtype=np.int64)
