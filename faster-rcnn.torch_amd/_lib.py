@@ -79,6 +79,15 @@ _SIGS = {
     "frcnn_rmsprop": ([vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
     "frcnn_scale_rmsprop": ([vp, vp, C.c_float, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
     "frcnn_scale_rmsprop_dev": ([vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
+    "frcnn_scale_rmsprop_slice": ([vp, vp, C.c_float, vp, C.c_longlong, C.c_longlong, C.c_float, C.c_float, C.c_float, vp], C.c_int),
+    "frcnn_model_update_stream": ([vp, C.POINTER(vp)], C.c_int),
+    "frcnn_model_update_fork": ([vp, vp], C.c_int),
+    "frcnn_model_update_join": ([vp, vp], C.c_int),
+    "frcnn_pnet_wait_backward_begun": ([vp, vp], C.c_int),
+    "frcnn_pnet_wait_heads_done": ([vp, vp], C.c_int),
+    "frcnn_pnet_wait_block_done": ([vp, C.c_int, vp], C.c_int),
+    "frcnn_pnet_refresh_packs": ([vp, vp, C.c_int, vp], C.c_int),
+    "frcnn_pnet_invalidate_packs": ([vp], C.c_int),
     "frcnn_model_create": ([C.POINTER(ModelDesc), C.POINTER(vp)], C.c_int),
     "frcnn_model_destroy": ([vp], C.c_int),
     "frcnn_model_param_count": ([vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], C.c_int),

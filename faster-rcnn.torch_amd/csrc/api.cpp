@@ -432,6 +432,10 @@ int frcnn_scale_rmsprop(float* x, float* g, float gscale, float* m, long long n,
                         void* stream) {
   return rmsprop_step(x, g, m, n, lr, alpha, eps, gscale, true, S(stream));
 }
+int frcnn_scale_rmsprop_slice(float* x, float* g, float gscale, float* m, long long lo, long long hi, float lr, float alpha,
+                              float eps, void* stream) {
+  return rmsprop_slice(x, g, m, lo, hi, lr, alpha, eps, gscale, gscale != 1.0f, S(stream));
+}
 int frcnn_scale_rmsprop_dev(float* x, float* g, const double* gcount_dev, float* m, long long n, float lr, float alpha,
                             float eps, void* stream) {
   FR_CHECK(gcount_dev, "frcnn_scale_rmsprop_dev: NULL divisor");

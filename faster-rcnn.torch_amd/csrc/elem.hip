@@ -565,6 +565,36 @@ int dropout_mask(float* mask, long n, float p, unsigned long long seed, hipStrea
 // m = alpha*m + (1-alpha)*g*g ; x -= lr * g / (sqrt(m) + eps).  5 streams of n floats: HBM-bound.
 // SCALE: g is first multiplied by gscale and written back (gradient:div(n), objective.lua:200, folded into the
 // optimiser's pass over the flat vectors: 6 streams instead of 2 + 5).
+// one element of the update: shared by the whole-vector kernel and the slice kernel, so that an update applied slice by slice
+// (frcnn_scale_rmsprop_slice: beside the backward pass, as slices of the gradient become final) leaves the same bits as one
+// pass over the whole vector wherever a slice boundary falls inside a 16-byte group
+template <bool SCALE>
+__device__ __forceinline__ void rmsprop_one(float& x, float& g, float& m, float lr, float alpha, float oma, float eps, float gscale) {
+#pragma clang fp contract(off)   // every operation rounded by itself: the same bits from either instantiation and either kernel
+  if (SCALE) g *= gscale;
+  m = alpha * m + oma * (g * g);
+  x = x - lr * g / (sqrtf(m) + eps);
+}
+template <bool SCALE>
+__device__ __forceinline__ void rmsprop_four(float4* x4, float4* g4, float4* m4, long i, float lr, float alpha, float oma, float eps, float gscale) {
+  float4 xv = x4[i], gv = g4[i], mv = m4[i];
+  rmsprop_one<SCALE>(xv.x, gv.x, mv.x, lr, alpha, oma, eps, gscale);
+  rmsprop_one<SCALE>(xv.y, gv.y, mv.y, lr, alpha, oma, eps, gscale);
+  rmsprop_one<SCALE>(xv.z, gv.z, mv.z, lr, alpha, oma, eps, gscale);
+  rmsprop_one<SCALE>(xv.w, gv.w, mv.w, lr, alpha, oma, eps, gscale);
+  if (SCALE) g4[i] = gv;
+  m4[i] = mv;
+  x4[i] = xv;
+}
+template <bool SCALE>
+__device__ __forceinline__ void rmsprop_scalar(float* x, float* g, float* m, long i, float lr, float alpha, float oma, float eps, float gscale) {
+  float xi = x[i], gi = g[i], mi = m[i];
+  rmsprop_one<SCALE>(xi, gi, mi, lr, alpha, oma, eps, gscale);
+  if (SCALE) g[i] = gi;
+  m[i] = mi;
+  x[i] = xi;
+}
+
 template <bool SCALE>
 __global__ void rmsprop_kernel(float* __restrict__ x, float* __restrict__ g, float* __restrict__ m,
                                long n, float lr, float alpha, float eps, float gscale,
@@ -577,28 +607,49 @@ __global__ void rmsprop_kernel(float* __restrict__ x, float* __restrict__ g, flo
   float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
   const float oma = 1.0f - alpha;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 xv = x4[i], gv = g4[i], mv = m4[i];
-    if (SCALE) {
-      gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
-      g4[i] = gv;
-    }
-    mv.x = alpha * mv.x + oma * (gv.x * gv.x); xv.x = xv.x - lr * gv.x / (sqrtf(mv.x) + eps);
-    mv.y = alpha * mv.y + oma * (gv.y * gv.y); xv.y = xv.y - lr * gv.y / (sqrtf(mv.y) + eps);
-    mv.z = alpha * mv.z + oma * (gv.z * gv.z); xv.z = xv.z - lr * gv.z / (sqrtf(mv.z) + eps);
-    mv.w = alpha * mv.w + oma * (gv.w * gv.w); xv.w = xv.w - lr * gv.w / (sqrtf(mv.w) + eps);
-    m4[i] = mv;
-    x4[i] = xv;
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    rmsprop_four<SCALE>(x4, g4, m4, i, lr, alpha, oma, eps, gscale);
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (SCALE) { gi *= gscale; g[i] = gi; }
-    float mi = alpha * m[i] + oma * (gi * gi);
-    m[i] = mi;
-    x[i] = x[i] - lr * gi / (sqrtf(mi) + eps);
+       i += (long)gridDim.x * blockDim.x)
+    rmsprop_scalar<SCALE>(x, g, m, i, lr, alpha, oma, eps, gscale);
+}
+
+// elements [lo, hi) of 16-byte aligned vectors: 16-byte groups where the slice covers them whole, the up to three elements
+// in front of the first and behind the last such group one by one (thread t < 8 of block 0)
+template <bool SCALE>
+__global__ void rmsprop_slice_kernel(float* __restrict__ x, float* __restrict__ g, float* __restrict__ m, long lo, long hi,
+                                     float lr, float alpha, float eps, float gscale) {
+  const long a = min(hi, (lo + 3) & ~3L), b = max(a, hi & ~3L);   // [lo, a) ragged | [a, b) whole groups | [b, hi) ragged
+  const long n4 = (b - a) >> 2;
+  float4* x4 = reinterpret_cast<float4*>(x + a);
+  float4* g4 = reinterpret_cast<float4*>(g + a);
+  float4* m4 = reinterpret_cast<float4*>(m + a);
+  const float oma = 1.0f - alpha;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    rmsprop_four<SCALE>(x4, g4, m4, i, lr, alpha, oma, eps, gscale);
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    const int t = threadIdx.x;
+    const long i = t < 4 ? lo + t : b + (t - 4);
+    if (t < 4 ? i < a : i < hi) rmsprop_scalar<SCALE>(x, g, m, i, lr, alpha, oma, eps, gscale);
   }
 }
+int rmsprop_slice(float* x, float* g, float* m, long lo, long hi, float lr, float alpha, float eps, float gscale, bool scale_first,
+                  hipStream_t s) {
+  FR_CHECK((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m) & 15) == 0, "rmsprop_slice: the vectors must be 16-byte aligned");
+  FR_CHECK(lo >= 0 && lo <= hi, "rmsprop_slice: bad range [%ld, %ld)", lo, hi);
+  if (lo == hi) return FRCNN_OK;
+  const long n = hi - lo;
+  // half the wave slots at most: a slice update runs BESIDE other launches (the backward pass) and must not keep them waiting for slots
+  static const int max_grid = getenv("FRCNN_SLICE_GRID") ? atoi(getenv("FRCNN_SLICE_GRID")) : 1024;
+  int grid = (int)std::min<long>(std::max<long>(1, cdivl(n / 4, 256)), max_grid);
+  if (scale_first)
+    FR_LAUNCH(KC_OPTIM, 0, n * 24.0, s, rmsprop_slice_kernel<true>, dim3(grid), dim3(256), 0, x, g, m, lo, hi, lr, alpha, eps, gscale);
+  else
+    FR_LAUNCH(KC_OPTIM, 0, n * 20.0, s, rmsprop_slice_kernel<false>, dim3(grid), dim3(256), 0, x, g, m, lo, hi, lr, alpha, eps, 1.f);
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, float eps, float gscale,
                  bool scale_first, hipStream_t s, const double* gcount_dev) {
   FR_CHECK((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m) & 15) == 0, "rmsprop_step: buffers must be 16-byte aligned");

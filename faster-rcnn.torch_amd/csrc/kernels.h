@@ -139,6 +139,10 @@ int dropout_channel_mask(float* scale, int C, float p, unsigned long long seed, 
 int fill_value(float* x, long n, float v, hipStream_t s);
 int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, float eps, float gscale,
                  bool scale_first, hipStream_t s, const double* gcount_dev = nullptr);
+// the same step on elements [lo, hi) only (any bounds; the vectors' bases 16-byte aligned): bit-identical to what rmsprop_step
+// leaves in those elements
+int rmsprop_slice(float* x, float* g, float* m, long lo, long hi, float lr, float alpha, float eps, float gscale, bool scale_first,
+                  hipStream_t s);
 
 // ---------------------------------------------------------------- gemm (gemm.hip)
 // C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.  defer: see GemmFold below.

@@ -73,6 +73,9 @@ struct Head {
   DevBuf spD, spHX, spHY, spGH, spCol, spDX;  // scratch of the sparse backward pass (per anchor net: they run concurrently)
   hipStream_t stream = nullptr;  // this anchor net's own stream (forward and sparse backward beside the other anchor nets)
   hipEvent_t done = nullptr;     // last work queued on `stream`
+  hipEvent_t gin_done = nullptr; // sparse backward: this net's contribution to the pooled map's gradient has been added (the
+                                 // backbone's backward pass waits for THIS; the parameter gradients behind it are joined at its end)
+  bool gin_recorded = false;
 };
 
 struct ClsLayer {
@@ -126,6 +129,16 @@ struct frcnn_model {
   int n_x3_all = 0, n_x3_fwd = 0, x3_grid_all = 0, x3_grid_fwd = 0;
   int n_pack_fwd = 0, n_pack_all = 0, n_pack_heads = 0, pack_grid_fwd = 0, pack_grid_all = 0, pack_grid_heads = 0;
   bool head_packs_fresh = false;   // head input-gradient packs match the weights of the last forward
+  // Packs by owner (round 6, the update that runs beside the backward pass): group b < nblocks = backbone block b, group nblocks =
+  // the anchor nets.  Each group has sub-tables of its own behind the model-wide ones in pack_jobs / amax_jobs / x3_jobs, so that
+  // frcnn_pnet_refresh_packs can renew one owner's packs as soon as ITS slice of the weight vector has been updated; a training
+  // forward whose groups are all fresh for the weight vector it is given skips the three model-wide launches.
+  struct PackGroup { int pk_off = 0, pk_n = 0, pk_grid = 0, am_off = 0, am_n = 0, am_grid = 0, x3_off = 0, x3_off16 = 0, x3_n = 0, x3_grid = 0; };
+  std::vector<PackGroup> groups;
+  unsigned fresh_mask = 0;         // bit g: group g's training packs were renewed by frcnn_pnet_refresh_packs since the last forward
+  const float* fresh_w = nullptr;  // ... from this weight vector
+  bool fresh_f16 = false;          // ... in this form
+  std::vector<hipEvent_t> block_rd_ev;   // block b's weights and packs have been read for the last time (caller's stream, frcnn_pnet_backward)
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
   hipStream_t cw = nullptr;        // the classification net's weight gradients / bias sums (beside its input-gradient chain)
   hipEvent_t cw_fork = nullptr, cw_done = nullptr;
@@ -133,6 +146,8 @@ struct frcnn_model {
   std::vector<hipEvent_t> cw_ev;   // one fork point per layer + one for the two heads
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  hipEvent_t bwd_ev = nullptr;     // the backbone's backward pass has begun on the caller's stream (anchor nets joined)
+  hipEvent_t upd_ev = nullptr, upd_join_ev = nullptr;   // fork / join points of the update stream (frcnn_model_update_*)
   bool heads_begun = false;        // anchor-net backward already running on the side stream
   bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
@@ -339,6 +354,27 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     m->pack_grid_heads = hd_jobs.empty() ? 0 : conv_pack_assign_blocks(hd_jobs.data(), m->n_pack_heads, 2048);
     both.insert(both.end(), fwd.begin(), fwd.end());
     both.insert(both.end(), hd_jobs.begin(), hd_jobs.end());
+    // per-owner sub-tables (training packs: forward and input-gradient images of the owner's convolutions)
+    m->groups.assign(m->blocks.size() + 1, frcnn_model::PackGroup());
+    for (size_t g = 0; g <= m->blocks.size(); ++g) {
+      std::vector<PackJob> gj;
+      if (g < m->blocks.size()) {
+        for (auto& c : m->convs) {
+          if (c.block != (int)g) continue;
+          if (!c.x_f) gj.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wf.f()));
+          if (!(c.block == 0 && c.step == 0) && !c.x_d) gj.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
+        }
+      } else {
+        for (auto& hd : m->heads) {
+          if (!hd.c3.x_f) gj.push_back(conv_pack_job(hd.c3.w_off, hd.c3.Cout, hd.c3.Cin, hd.c3.k, 0, hd.c3.wf.f()));
+          gj.push_back(conv_pack_job(hd.c1.w_off, hd.c1.Cout, hd.c1.Cin, hd.c1.k, 0, hd.c1.wf.f()));
+        }
+      }
+      auto& G = m->groups[g];
+      G.pk_off = (int)both.size(); G.pk_n = (int)gj.size();
+      G.pk_grid = gj.empty() ? 0 : conv_pack_assign_blocks(gj.data(), G.pk_n, 512);
+      both.insert(both.end(), gj.begin(), gj.end());
+    }
     FR_TRY(m->pack_jobs.ensure(both.size() * sizeof(PackJob)));
     FR_HIP(hipMemcpy(m->pack_jobs.p, both.data(), both.size() * sizeof(PackJob), hipMemcpyHostToDevice));
   }
@@ -361,6 +397,19 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       m->n_amax_jobs = (int)aj.size();
       m->amax_grid = tensor_absmax_assign_blocks(aj.data(), m->n_amax_jobs);
       FR_CHECK(m->amax_grid >= 0, "ensure_shapes: a weight tensor is too large for its magnitude record");
+      for (size_t g = 0; g <= m->blocks.size(); ++g) {   // per-owner sub-tables (see frcnn_model::groups)
+        std::vector<AmaxJob> gj;
+        auto addg = [&](Conv& c) {
+          if (c.x_f || c.x_d) gj.push_back(AmaxJob{c.w_off, (long)c.Cout * c.Cin * c.k * c.k, m->rec(c.am + 2), 0});
+        };
+        if (g < m->blocks.size()) { for (auto& c : m->convs) if (c.block == (int)g) addg(c); }
+        else for (auto& hd : m->heads) addg(hd.c3);
+        auto& G = m->groups[g];
+        G.am_off = (int)aj.size(); G.am_n = (int)gj.size();
+        G.am_grid = gj.empty() ? 0 : tensor_absmax_assign_blocks(gj.data(), G.am_n);
+        FR_CHECK(G.am_grid >= 0, "ensure_shapes: a weight tensor is too large for its magnitude record");
+        aj.insert(aj.end(), gj.begin(), gj.end());
+      }
       if (!aj.empty()) {
         FR_TRY(m->amax_jobs.ensure(aj.size() * sizeof(AmaxJob)));
         FR_HIP(hipMemcpy(m->amax_jobs.p, aj.data(), aj.size() * sizeof(AmaxJob), hipMemcpyHostToDevice));
@@ -390,6 +439,27 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
     all.insert(all.end(), fwd.begin(), fwd.end());
     all.insert(all.end(), all16.begin(), all16.end());
     all.insert(all.end(), fwd16.begin(), fwd16.end());
+    for (size_t g = 0; g <= m->blocks.size(); ++g) {   // per-owner sub-tables: [plain jobs][the same with the weight magnitude attached]
+      std::vector<PackXJob> gp, g16;
+      auto addg = [&](Conv& c) {
+        if (c.x_f) {
+          gp.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wx.p, c.Ho, c.Wo));
+          PackXJob j = gp.back(); j.amax = m->rec(c.am + 2); j.amax_w = m->amax_ws.f() + c.am; g16.push_back(j);
+        }
+        if (c.x_d) {
+          gp.push_back(conv_x3_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wxd.p, c.H, c.W));
+          PackXJob j = gp.back(); j.amax = m->rec(c.am + 2); j.amax_w = m->amax_ws.f() + c.am; g16.push_back(j);
+        }
+      };
+      if (g < m->blocks.size()) { for (auto& c : m->convs) if (c.block == (int)g) addg(c); }
+      else for (auto& hd : m->heads) addg(hd.c3);
+      auto& G = m->groups[g];
+      G.x3_n = (int)gp.size();
+      G.x3_grid = gp.empty() ? 0 : conv_x3_pack_assign_blocks(gp.data(), G.x3_n);
+      if (!g16.empty()) conv_x3_pack_assign_blocks(g16.data(), G.x3_n);
+      G.x3_off = (int)all.size(); all.insert(all.end(), gp.begin(), gp.end());
+      G.x3_off16 = (int)all.size(); all.insert(all.end(), g16.begin(), g16.end());
+    }
     if (!all.empty()) {
       FR_TRY(m->x3_jobs.ensure(all.size() * sizeof(PackXJob)));
       FR_HIP(hipMemcpy(m->x3_jobs.p, all.data(), all.size() * sizeof(PackXJob), hipMemcpyHostToDevice));
@@ -397,6 +467,7 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
   }
   m->H = H; m->W = W;
   m->eval_packs_gen = -1;   // (pack buffers and job tables were rebuilt)
+  m->fresh_mask = 0;
   return FRCNN_OK;
 }
 
@@ -441,10 +512,15 @@ int frcnn_model_destroy(frcnn_model* m) {
   for (auto e : m->fork_ev) (void)hipEventDestroy(e);
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
+    if (h.gin_done) (void)hipEventDestroy(h.gin_done);
     if (h.stream) (void)hipStreamDestroy(h.stream);
   }
   if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+  if (m->bwd_ev) (void)hipEventDestroy(m->bwd_ev);
+  if (m->upd_ev) (void)hipEventDestroy(m->upd_ev);
+  if (m->upd_join_ev) (void)hipEventDestroy(m->upd_join_ev);
+  for (auto e : m->block_rd_ev) (void)hipEventDestroy(e);
   for (auto e : m->cw_ev) (void)hipEventDestroy(e);
   if (m->cw_fork) (void)hipEventDestroy(m->cw_fork);
   if (m->cw_done) (void)hipEventDestroy(m->cw_done);
@@ -517,6 +593,42 @@ static int cw_join(frcnn_model* m, hipStream_t s) {
 int frcnn_cnet_backward_join(frcnn_model* m, void* stream) {
   FR_CHECK(m != nullptr, "cnet_backward_join: null model");
   return cw_join(m, S(stream));
+}
+
+// The update stream: a library-owned stream on which the host queues the optimiser's update of a slice of the flat vectors (and
+// the renewal of the packs made from it) while the caller's stream is still busy with the rest of the backward pass.  It is the
+// stream the classification net's weight gradients run on -- idle from the end of that stage to the end of the step -- so a
+// slice update queued on it is ordered behind those gradients by itself.
+static int ensure_update_stream(frcnn_model* m) {
+  if (!m->cw) {
+    FR_HIP(hipStreamCreateWithFlags(&m->cw, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&m->cw_done, hipEventDisableTiming));
+  }
+  if (!m->upd_ev) FR_HIP(hipEventCreateWithFlags(&m->upd_ev, hipEventDisableTiming));
+  if (!m->upd_join_ev) FR_HIP(hipEventCreateWithFlags(&m->upd_join_ev, hipEventDisableTiming));
+  return FRCNN_OK;
+}
+int frcnn_model_update_stream(frcnn_model* m, void** stream) {
+  FR_CHECK(m && stream, "model_update_stream: null argument");
+  FR_TRY(ensure_update_stream(m));
+  *stream = (void*)m->cw;
+  return FRCNN_OK;
+}
+// the update stream waits for everything queued on `stream` so far (the last readers of the weights about to be updated)
+int frcnn_model_update_fork(frcnn_model* m, void* stream) {
+  FR_CHECK(m != nullptr, "model_update_fork: null model");
+  FR_TRY(ensure_update_stream(m));
+  FR_HIP(hipEventRecord(m->upd_ev, S(stream)));
+  FR_HIP(hipStreamWaitEvent(m->cw, m->upd_ev, 0));
+  return FRCNN_OK;
+}
+// `stream` waits for everything queued on the update stream so far (before the next pass reads the weights and the packs)
+int frcnn_model_update_join(frcnn_model* m, void* stream) {
+  FR_CHECK(m != nullptr, "model_update_join: null model");
+  FR_TRY(ensure_update_stream(m));
+  FR_HIP(hipEventRecord(m->upd_join_ev, m->cw));
+  FR_HIP(hipStreamWaitEvent(S(stream), m->upd_join_ev, 0));
+  return FRCNN_OK;
 }
 
 int frcnn_get_option(const char* name, int* value) {
@@ -680,7 +792,11 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
   const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
   const bool reuse = !training && g_static_weights && m->eval_packs_gen == g_static_gen && m->eval_packs_w == w && m->f16_packed == f16;
   m->f16_packed = f16;
-  if (!reuse) {
+  // ... or every owner's packs were renewed from this weight vector since the last pass (frcnn_pnet_refresh_packs: the update
+  // ran beside the previous backward pass).  One-shot: the promise covers the pass that consumes it.
+  const bool fresh = training && !m->groups.empty() && m->fresh_mask == (1u << m->groups.size()) - 1 && m->fresh_w == w && m->fresh_f16 == f16;
+  m->fresh_mask = 0;
+  if (!reuse && !fresh) {
     if (training)
       FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
     else
@@ -869,6 +985,11 @@ static int backward_head(frcnn_model* m, Head& h, const float* w, float* grad, h
     // DX[P][ckk] = GH^T[P][n] * W[n][ckk], scattered back into the pooled-map gradient
     FR_TRY(gemm_f32(GH, 1, P, w + a.w_off, ckk, 1, DX, ckk, P, ckk, n, OUT_STORE, nullptr, s, ws_slot));
     FR_TRY(col2im_positions_add(DX, a.Cin, a.H, a.W, a.k, a.Wo, pos, P, in.gpooled.f(), s));
+    if (h.stream && s == h.stream) {   // (on its own stream: see Head::gin_done)
+      if (!h.gin_done) FR_HIP(hipEventCreateWithFlags(&h.gin_done, hipEventDisableTiming));
+      FR_HIP(hipEventRecord(h.gin_done, s));
+      h.gin_recorded = true;
+    }
     // 1x1 conv: gW1[18][n] += D[18][P] * HY[n][P]^T ; gb1 += rowsum(D)
     FR_TRY(gemm_f32(D, P, 1, HY, 1, P, grad + c.w_off, n, HEAD_OUT, n, P, OUT_ADD, nullptr, s, ws_slot));
     FR_TRY(channel_sum(D, HEAD_OUT, P, grad + c.b_off, s));
@@ -911,6 +1032,7 @@ static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream
 static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
   FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
   FR_HIP(hipEventRecord(m->chain_ev, m->side));
+  for (auto& h : m->heads) h.gin_recorded = false;
   std::vector<char> own(m->heads.size(), 0);   // (the hint is consumed by backward_head: decide before calling it)
   for (size_t i = 0; i < m->heads.size(); ++i) own[i] = m->heads[i].stream && head_is_sparse(m->heads[i]);
   // A dense-fallback net adds into the pooled-map gradient with plain read-modify-writes and uses the shared weight-gradient
@@ -997,10 +1119,74 @@ int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
   return FRCNN_OK;
 }
 
+// After frcnn_pnet_backward has been queued: `stream` waits until the caller's stream has joined the anchor nets and begun the
+// backbone's backward pass -- the stretch of the step that is bound by the matrix cores, beside which bandwidth-bound work
+// (the update of slices that are final already) costs least.  Everything the caller's stream ran before it is final too.
+int frcnn_pnet_wait_backward_begun(frcnn_model* m, void* stream) {
+  FR_CHECK(m->bwd_ev && m->block_ev_valid, "pnet_wait_backward_begun: call frcnn_pnet_backward first");
+  FR_HIP(hipStreamWaitEvent(S(stream), m->bwd_ev, 0));
+  return FRCNN_OK;
+}
+
+// After frcnn_pnet_backward has been queued: `stream` waits until the anchor nets' whole backward pass -- their parameter
+// gradients included, which may still be running beside the backbone's pass -- is over: their slice may then be updated.
+int frcnn_pnet_wait_heads_done(frcnn_model* m, void* stream) {
+  FR_CHECK(m->block_ev_valid, "pnet_wait_heads_done: call frcnn_pnet_backward first");
+  for (auto& h : m->heads)
+    if (h.stream && h.done) FR_HIP(hipStreamWaitEvent(S(stream), h.done, 0));
+  return FRCNN_OK;
+}
+
+// Stream `stream` waits until block `block`'s slice of the flat vectors may be UPDATED: its parameter gradients are final (block_ev)
+// and the caller's stream has queued -- hence, in stream order, finished -- the last launch that reads the block's weights, its
+// packs or its weight-magnitude scalars (the input-gradient launch of the block's first convolution).
+int frcnn_pnet_wait_block_done(frcnn_model* m, int block, void* stream) {
+  FR_CHECK(block >= 1 && block <= (int)m->blocks.size(), "pnet_wait_block_done: block %d out of range", block);
+  FR_CHECK(m->block_ev_valid && (size_t)block <= m->block_ev.size() && (size_t)block <= m->block_rd_ev.size(),
+           "pnet_wait_block_done: call frcnn_pnet_backward first");
+  FR_HIP(hipStreamWaitEvent(S(stream), m->block_ev[block - 1], 0));
+  FR_HIP(hipStreamWaitEvent(S(stream), m->block_rd_ev[block - 1], 0));
+  return FRCNN_OK;
+}
+
+// Renews the training packs of one owner (group = 0-based backbone block, or the number of blocks for the anchor nets) from the
+// weight vector w on `stream`: what the prologue of frcnn_pnet_forward does for the whole model, for the slice whose update has
+// just been queued on the same stream.  When every group has been renewed from the vector the next training-mode forward is
+// given, that forward skips its prologue.  The caller promises that nothing writes w between this call and that forward except
+// updates followed by their own refresh; frcnn_pnet_invalidate_packs withdraws the promise.
+int frcnn_pnet_refresh_packs(frcnn_model* m, const float* w, int group, void* stream) {
+  FR_CHECK(m->H > 0, "pnet_refresh_packs: call frcnn_pnet_forward first");
+  FR_CHECK(group >= 0 && group < (int)m->groups.size(), "pnet_refresh_packs: group %d out of range", group);
+  hipStream_t s = S(stream);
+  const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
+  if (m->fresh_mask && (m->fresh_w != w || m->fresh_f16 != f16)) m->fresh_mask = 0;
+  const frcnn_model::PackGroup& G = m->groups[group];
+  if (G.pk_n) FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + G.pk_off, G.pk_n, G.pk_grid, s));
+  if (f16 && G.am_n) FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p + G.am_off, G.am_n, G.am_grid, s));
+  if (G.x3_n) FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p + (f16 ? G.x3_off16 : G.x3_off), G.x3_n, G.x3_grid, s));
+  m->fresh_mask |= 1u << group; m->fresh_w = w; m->fresh_f16 = f16;
+  return FRCNN_OK;
+}
+
+int frcnn_pnet_invalidate_packs(frcnn_model* m) {
+  m->fresh_mask = 0;
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_wait_block_gradients(frcnn_model* m, int block, void* stream) {
   FR_CHECK(block >= 1 && block <= (int)m->blocks.size(), "pnet_wait_block_gradients: block %d out of range", block);
   FR_CHECK(m->block_ev_valid && (size_t)block <= m->block_ev.size(), "pnet_wait_block_gradients: call frcnn_pnet_backward first");
   FR_HIP(hipStreamWaitEvent(S(stream), m->block_ev[block - 1], 0));
+  return FRCNN_OK;
+}
+
+static int record_block_read(frcnn_model* m, int b, hipStream_t s) {
+  while (m->block_rd_ev.size() < m->blocks.size()) {
+    hipEvent_t e;
+    FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->block_rd_ev.push_back(e);
+  }
+  FR_HIP(hipEventRecord(m->block_rd_ev[b], s));
   return FRCNN_OK;
 }
 
@@ -1009,9 +1195,22 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
   FR_CHECK(m->H > 0 && m->training, "pnet_backward: needs a preceding training-mode forward "
                                     "(nn.SpatialDropout: backprop only defined while training)");
   const int nb = (int)m->blocks.size();
+  bool heads_tail = false;   // anchor nets still computing their parameter gradients on their own streams: joined at the end
   if (m->heads_begun) {   // started by frcnn_pnet_backward_heads_begin: wait for the side stream
     if (!m->heads_joined) {
-      FR_TRY(join_heads(m, s));
+      // What the backbone's pass needs from an anchor net is its contribution to the pooled map's gradient; a net on a stream
+      // of its own marks that point (Head::gin_done) and goes on with its parameter gradients beside the backbone's pass.
+      static const bool partial = !(getenv("FRCNN_HEADS_PARTIAL_JOIN") && atoi(getenv("FRCNN_HEADS_PARTIAL_JOIN")) == 0);
+      for (auto& h : m->heads) {
+        if (!h.stream) continue;
+        if (partial && h.gin_recorded) {
+          FR_HIP(hipStreamWaitEvent(s, h.gin_done, 0));
+          heads_tail = true;
+        } else {
+          FR_HIP(hipEventRecord(h.done, h.stream));
+          FR_HIP(hipStreamWaitEvent(s, h.done, 0));
+        }
+      }
       FR_HIP(hipEventRecord(m->join_ev, m->side));
       FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
     }
@@ -1025,6 +1224,9 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     Block& last = m->blocks.back();
     FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
   }
+  // from here on the caller's stream is busy with matrix-core work for the rest of the pass (frcnn_pnet_wait_backward_begun)
+  if (!m->bwd_ev) FR_HIP(hipEventCreateWithFlags(&m->bwd_ev, hipEventDisableTiming));
+  FR_HIP(hipEventRecord(m->bwd_ev, s));
   // The weight gradient of a layer and the input gradient that feeds the next act_backward are independent:
   // accGradParameters goes to a side stream, so its blocks fill the CUs that the tail of the updateGradInput
   // kernel (one wave of blocks, retiring unevenly) leaves idle, and the ~4 us dispatch gaps of one chain
@@ -1063,6 +1265,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
           m->block_ev.push_back(e);
         }
         FR_HIP(hipEventRecord(m->block_ev[b], s));
+        FR_TRY(record_block_read(m, b, s));
         break;
       }
       if (fused_here) {
@@ -1114,7 +1317,10 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
         }
         FR_HIP(hipEventRecord(m->block_ev[b], on_caller ? s : ws));
       }
-      if (b == 0 && st == 0) break;  // gradInput of the first conv is unused (objective.lua:189)
+      if (b == 0 && st == 0) {   // gradInput of the first conv is unused (objective.lua:189)
+        FR_TRY(record_block_read(m, b, s));
+        break;
+      }
       double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
@@ -1134,9 +1340,11 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
                           c.k - 1 - c.pad, gin, gmode, fl, s));
+      if (st == 0) FR_TRY(record_block_read(m, b, s));   // the block's weights, packs and weight magnitudes have had their last reader
     }
   }
   m->block_ev_valid = true;
+  if (heads_tail) FR_TRY(join_heads(m, s));   // the anchor nets' parameter gradients (see above)
   FR_TRY(cw_join(m, s));   // the classification net's weight gradients (frcnn_cnet_backward) belong to the same gradient vector
   if (use_side) {   // the caller's stream continues after every weight gradient has landed
     FR_HIP(hipEventRecord(m->join_ev, ws));

@@ -292,12 +292,17 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         prep.update(ex_anchor=ex_anchor, ex_roi=ex_roi, ex_idx=ex_idx, ex_class=ex_class, wins=wins, sp=sp, blob=blob)
         return prep
 
-    def run(w, defer):
+    def run(w, defer, eager=None):
         """Queues the whole pass.  Returns finish() -> (loss, gradient); with defer=True (single process) the
         accumulators travel to pinned host memory asynchronously and finish() only waits for that copy, so the
         caller may queue more work (the optimiser step) before it looks at the loss."""
         if w is not weights:  # :46-48
             weights.copy_(w)
+        if packs_promise[0] is not None and packs_promise[0] != getattr(weights, "_version", None):
+            # the packs renewed beside the previous pass were made from weights somebody has written since (torch counts
+            # in-place writes; the library's own updates do not go through torch): the forward pass re-packs
+            _lib.call("frcnn_pnet_invalidate_packs", native.h)
+        packs_promise[0] = None
         s = stream_ptr()
         probing = exchange_probe is not None and _dist() is None and getattr(gradient, "is_cuda", False)
         if probing:
@@ -310,6 +315,38 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         next_batch[0] = None
         pending = []
         early_copy = False
+        # The update beside the backward pass (include/frcnn_hip.h): single process, one image per step, the side streams on.
+        # eager = {m, lr, alpha, eps} from utilities.rmsprop; eager["done"] collects the slices updated on the update stream.
+        if eager is not None:
+            side = C.c_int(0)
+            _lib.call("frcnn_get_option", b"side_stream", C.byref(side))
+            if not (defer == "fold" and _dist() is None and len(batch) == 1 and side.value and w is weights
+                    and getattr(gradient, "is_cuda", False)):
+                eager = None
+        if eager is not None:
+            from .synthetic import clean_examples, output_map_sizes
+            x0 = batch[0]
+            held0 = prepared.get(id(x0))
+            if held0 is not None and held0[0] is x0:
+                n_ex = len(held0[1]["p"]) + len(held0[1]["n"])
+            else:
+                sizes0 = output_map_sizes(model, x0["img"].shape[1], x0["img"].shape[2])
+                n_ex = len(clean_examples(x0["positive"], sizes0)) + len(clean_examples(x0["negative"], sizes0))
+            eager["gscale"] = (1.0 / n_ex) if n_ex > 0 else 1.0   # gradient:div(cls_count), :200 (nothing to scale without examples)
+            eager["done"] = []
+            us = C.c_void_p()
+            _lib.call("frcnn_model_update_stream", native.h, C.byref(us))
+            nblk = int(native.desc.nblocks)
+
+            def eager_slice(lo, hi, on, group=None):
+                _lib.call("frcnn_scale_rmsprop_slice", ptr(weights), ptr(gradient), eager["gscale"], ptr(eager["m"]), lo, hi,
+                          eager["lr"], eager["alpha"], eager["eps"], on)
+                eager["done"].append((int(lo), int(hi)))
+                if group is not None:
+                    _lib.call("frcnn_pnet_refresh_packs", native.h, ptr(weights), group, on)
+                    eager["groups"].add(group)
+            eager["groups"] = set()
+            eager["slice"] = eager_slice
         dev_tail = (dev_tail_ok and defer == "fold" and _dist() is not None and getattr(gradient, "is_cuda", False))
         c4 = None
         if dev_tail:
@@ -420,6 +457,23 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 early_copy = True
             debug["E"] = E
             pnet.backward(img, delta_outputs)  # :189
+            if eager is not None:
+                # On the update stream, once the caller's stream is inside the backbone's backward pass (matrix-core bound: the
+                # bandwidth-bound update costs least beside it): the classification net's slice (55 % of the vector; its weight
+                # gradients ran on this very stream), the anchor nets' slice and packs, then each backbone block as the pass leaves it
+                # (that event follows the whole classification-net stage in stream order: its slice is final, its weights have
+                # had their last reader -- also for an image without examples; the anchor nets may still be adding up their
+                # parameter gradients)
+                _lib.call("frcnn_pnet_wait_backward_begun", native.h, us)
+                eager_slice(native.pnet_params, gradient.numel(), us)
+                _lib.call("frcnn_pnet_wait_heads_done", native.h, us)
+                lo, hi = pnet.heads_param_range()
+                eager_slice(lo, hi, us, nblk)
+                for b in range(nblk, 1, -1):   # deepest block first: the order in which the pass leaves them; block 1 ends the pass
+                    _lib.call("frcnn_pnet_wait_block_done", native.h, b, us)
+                    lo, hi = pnet.block_param_range(b - 1)
+                    eager_slice(lo, hi, us, b - 1)
+                _lib.call("frcnn_model_update_join", native.h, stream_ptr())
             if last and _dist() is not None and early_blocks and getattr(gradient, "is_cuda", False):
                 if aux_stream[0] is None:
                     aux_stream[0] = torch.cuda.Stream()
@@ -472,6 +526,9 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
                 acc_pin.copy_(acc_t, non_blocking=True)
                 acc_event.record()
             fin = lambda: finish(None, counts, pending, single)
+            if eager is not None:
+                assert cls_count == 0 or eager["gscale"] == 1.0 / cls_count, "example count bookkeeping diverged"
+                return (fin, eager["gscale"] if cls_count > 0 else None)
             return (fin, 1.0 / cls_count) if fold else fin
         if defer == "fold" and not single:   # the all-reduced count is known after finish(): scaling left to the caller
             res = finish(acc_dev.numpy(), counts, pending, single, fold=True)
@@ -480,6 +537,7 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
         return (lambda r: (lambda: r))(finish(acc_dev.numpy(), counts, pending, single))
 
     dp_gscale = [None]
+    packs_promise = [None]   # weights._version at the moment every pack group had been renewed beside a pass (else None)
     debug = dict(scratch=scratch, E=0)
     next_batch = [None]
     prefetch_batches = os.environ.get("FRCNN_PREFETCH_BATCH", "1") != "0"
@@ -528,8 +586,24 @@ def create_objective(model, weights, gradient, batch_iterator, stats):  # object
     lossAndGradient.begin = lambda w: (run(w, True), gradient)
     # begin_fold(w) -> (finish, gradient, gscale): gradient:div(cls_count) (:200) is left to the caller, who folds it
     # into the first pass of its update (frcnn_scale_rmsprop); gscale is None when there is nothing to scale
-    def begin_fold(w):
-        r = run(w, "fold")
+    def begin_fold(w, eager=None):
+        """eager = dict(m=, lr=, alpha=, eps=) (utilities.rmsprop): the pass may apply the optimiser's step to slices of the
+        vectors as they become final (the update beside the backward pass, include/frcnn_hip.h); eager["done"] then lists the
+        slices it has updated, eager["slice"](lo, hi, stream, group) updates another one, eager["groups"] the pack groups
+        already renewed, and the caller finishes with eager["complete"]()."""
+        r = run(w, "fold", eager)
+        if eager is not None and "done" in eager:
+            ngroups = int(native.desc.nblocks) + 1
+
+            def complete():
+                """The caller has updated the rest of the vector: renew the packs nobody has renewed yet (on the current
+                stream) and remember which weights every pack now belongs to."""
+                for g in range(ngroups):
+                    if g not in eager["groups"]:
+                        _lib.call("frcnn_pnet_refresh_packs", native.h, ptr(weights), g, stream_ptr())
+                        eager["groups"].add(g)
+                packs_promise[0] = getattr(weights, "_version", None)
+            eager["complete"] = complete
         return (r[0], gradient, r[1]) if isinstance(r, tuple) else (r, gradient, None)
     lossAndGradient.begin_fold = begin_fold
     lossAndGradient.debug = debug   # (tests: the scratch buffers and the example count of the image being processed)

@@ -33,6 +33,10 @@ def combine_and_flatten_parameters(pnet, cnet, seed=42, weights_host=None):
     return weights, gradient
 
 
+import os
+EAGER_DEFAULT = os.environ.get("FRCNN_EAGER_UPDATE", "0") == "1"
+
+
 def rmsprop(opfunc, x, state):
     """optim.rmsprop(opfunc, x, state) [ext]: state.learningRate (1e-2), state.alpha (0.99),
     state.epsilon (1e-8); m = alpha*m + (1-alpha)*g^2 ; x -= lr * g / (sqrt(m) + eps).
@@ -47,8 +51,26 @@ def rmsprop(opfunc, x, state):
         import time
         t_in = time.perf_counter()
     if begin is not None:   # create_objective's closure: the loss is read back AFTER the update has been queued,
-        finish, dfdx, gscale = begin(x)   # and gradient:div(n) rides on the update's own pass over the vectors
-        if hasattr(gscale, "ptr"):   # data parallel: the divisor is the all-reduced count, still on the device
+        # and gradient:div(n) rides on the update's own pass over the vectors.  state["eager"] (default off: measured neutral on
+        # one GPU, EXPERIMENTS.md round 6 -- the backward pass has no idle registers for the update to run in): the pass may
+        # apply this very step slice by slice, beside its own backward half, as slices of the gradient become final
+        eager = dict(m=state["m"], lr=lr, alpha=alpha, eps=eps) if state.get("eager", EAGER_DEFAULT) else None
+        finish, dfdx, gscale = begin(x, eager) if eager is not None else begin(x)
+        if eager is not None and "done" in eager:
+            # what the pass has not updated (the shallowest block: its gradients end the pass; everything, for an image without
+            # examples), on the caller's stream, followed by the packs made from it
+            done = sorted(eager["done"])
+            rest, at = [], 0
+            for lo, hi in done:
+                if lo > at:
+                    rest.append((at, lo))
+                at = max(at, hi)
+            if at < x.numel():
+                rest.append((at, x.numel()))
+            for lo, hi in rest:
+                eager["slice"](lo, hi, stream_ptr())
+            eager["complete"]()
+        elif hasattr(gscale, "ptr"):   # data parallel: the divisor is the all-reduced count, still on the device
             _lib.call("frcnn_scale_rmsprop_dev", ptr(x), ptr(dfdx), ptr(gscale.ptr), ptr(state["m"]), x.numel(), lr, alpha,
                       eps, stream_ptr())
         elif gscale is None:

@@ -250,6 +250,11 @@ int frcnn_scale_rmsprop(float *x, float *g, float gscale, float *m, long long n,
  * the accumulator vector: the update is queued behind the exchange without any host read-back. */
 int frcnn_scale_rmsprop_dev(float *x, float *g, const double *gcount_dev, float *m, long long n, float lr,
                             float alpha, float eps, void *stream);
+/* frcnn_scale_rmsprop on elements [lo, hi) of the vectors only (x, g, m = the 16-byte aligned STARTS of the flat vectors; any
+ * bounds; gscale = 1: the gradient is left unscaled): what main.lua:133 does to that slice, bit for bit.  See "the update beside
+ * the backward pass" below. */
+int frcnn_scale_rmsprop_slice(float *x, float *g, float gscale, float *m, long long lo, long long hi, float lr,
+                              float alpha, float eps, void *stream);
 
 /* ---- model runtime: models/model_utilities.lua:3-136 --------------------------------- */
 typedef struct {
@@ -346,6 +351,45 @@ int frcnn_pnet_backward(frcnn_model *, const float *weights, float *grad, void *
  * vector) is final.  The deepest block finishes first, long before the call's own stream reaches the end of the
  * pass: a data-parallel caller starts that slice's all-reduce behind this wait, beside the remaining backward pass. */
 int frcnn_pnet_wait_block_gradients(frcnn_model *, int block, void *stream);
+
+/* ---- the update beside the backward pass (round 6): optim.rmsprop's step (main.lua:133) applied slice by slice ----------
+ * main.lua:133 updates the whole flat vector after lossAndGradient (objective.lua:45-218) has returned, and the next
+ * pnet:forward (objective.lua:71) re-packs every weight tensor before its first convolution: two serial stretches of a step
+ * that is otherwise bound by the matrix cores.  Slices of the gradient are final long before the pass ends -- the classification
+ * net's (55 % of the vector) after cnet:backward (objective.lua:179), the anchor nets' once their part of pnet:backward has
+ * run, a backbone block's when the pass has left the block -- and the divisor of gradient:div (objective.lua:200) is a host
+ * number known before the pass.  A host that owns the optimiser may therefore queue
+ *     frcnn_scale_rmsprop_slice(x, g, 1/cls_count, m, lo, hi, ...)  [+ frcnn_pnet_refresh_packs(model, x, group, ...)]
+ * on the UPDATE STREAM as each slice becomes final, and frcnn_model_update_join before anything reads the weights again.  The
+ * result is bit-identical to frcnn_scale_rmsprop on the whole vector (same arithmetic per element, tests/test_gpu_eager.py).
+ *   frcnn_model_update_stream : the library-owned stream for this work (the one the classification net's weight gradients
+ *                               run on: a slice update queued there is ordered behind them by itself)
+ *   frcnn_model_update_fork   : the update stream waits for everything queued on `stream` so far (the last readers of the
+ *                               weights about to change, e.g. cnet:backward's input-gradient chain)
+ *   frcnn_model_update_join   : `stream` waits for everything queued on the update stream so far
+ *   frcnn_pnet_wait_backward_begun : after frcnn_pnet_backward has been queued: `stream` waits until the caller's stream has
+ *                               joined the anchor nets and begun the backbone's backward pass (objective.lua:189) -- the
+ *                               matrix-core-bound stretch of the step, beside which bandwidth-bound update work costs least
+ *   frcnn_pnet_wait_heads_done: after frcnn_pnet_backward has been queued: `stream` waits until the anchor nets' backward pass is
+ *                               over, parameter gradients included (they may run on beside the backbone's pass: the caller's
+ *                               stream only waits for their contribution to the pooled maps' gradients before it starts)
+ *   frcnn_pnet_wait_block_done: after frcnn_pnet_backward has been queued: `stream` waits until block `block` (1-based) may be
+ *                               updated -- its gradients are final AND the last launch reading its weights, packs or weight
+ *                               magnitudes has run (frcnn_pnet_wait_block_gradients only promises the first)
+ *   frcnn_pnet_refresh_packs  : renews on `stream` the packed weight images / weight magnitudes of one owner (group = 0-based
+ *                               backbone block, or nblocks for the anchor nets) from `weights`; when EVERY group has been
+ *                               renewed from the vector the next training-mode frcnn_pnet_forward is given, that forward skips
+ *                               its own re-pack.  The caller promises that between this call and that forward nothing writes
+ *                               the weights except updates followed by their refresh; frcnn_pnet_invalidate_packs withdraws
+ *                               the promise (a host that wrote the weights some other way calls it). */
+int frcnn_model_update_stream(frcnn_model *, void **stream_host);
+int frcnn_model_update_fork(frcnn_model *, void *stream);
+int frcnn_model_update_join(frcnn_model *, void *stream);
+int frcnn_pnet_wait_backward_begun(frcnn_model *, void *stream);
+int frcnn_pnet_wait_heads_done(frcnn_model *, void *stream);
+int frcnn_pnet_wait_block_done(frcnn_model *, int block, void *stream);
+int frcnn_pnet_refresh_packs(frcnn_model *, const float *weights, int group, void *stream);
+int frcnn_pnet_invalidate_packs(frcnn_model *);
 
 /* cnet:forward(cinput) (objective.lua:164, Detector.lua:101).  weights/grad point at the START
  * of the flat vectors.  bn_running: float[2*n] {mean,var} per BatchNorm layer (updated when

@@ -10,8 +10,15 @@ MARK = {"frcnn_pnet_forward_async_heads": "forward", "frcnn_roi_pool_forward": "
         "frcnn_pnet_backward_heads_join": "heads_joined", "frcnn_pnet_backward": "backward", "frcnn_rmsprop": "update",
         "frcnn_scale_rmsprop": "update"}
 marks = []
+JOIN = os.environ.get("PROBE_JOIN", "1") != "0"
 orig = F._lib.call
 def call(name, *a):
+    if name == "frcnn_pnet_backward" and rec[0] and JOIN:   # the wait for the anchor nets' backward chains, by itself
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(("pre_join", e))
+        import ctypes
+        j = ctypes.c_int(0)
+        orig("frcnn_pnet_backward_heads_join", a[0], a[3], ctypes.byref(j))
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(("heads_joined", e))
     r = orig(name, *a)
     if name in MARK and rec[0]:
         e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((MARK[name], e))
