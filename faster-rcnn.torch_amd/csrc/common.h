@@ -95,13 +95,13 @@ void prof_after(int klass, double flops, double bytes, hipStream_t s);
 
 // counter-based RNG of the throughput runs (dropout masks): element i of a stream draws splitmix64(seed*FNV + i)
 #ifdef __HIPCC__
-__device__ __forceinline__ unsigned long long frcnn_splitmix64(unsigned long long z) {
+__host__ __device__ __forceinline__ unsigned long long frcnn_splitmix64(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__device__ __forceinline__ float frcnn_keep_mask(unsigned long long seed, unsigned long long i, float p) {
+__host__ __device__ __forceinline__ float frcnn_keep_mask(unsigned long long seed, unsigned long long i, float p) {
   const unsigned long long r = frcnn_splitmix64(seed * 0x100000001B3ull + i);
   const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.f;  // keep with probability 1-p

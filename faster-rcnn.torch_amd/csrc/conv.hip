@@ -1324,6 +1324,57 @@ int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hip
   return FRCNN_OK;
 }
 
+// the fold through a WgradMap: wgrad_reduce4_kernel's walk (four consecutive (o', c') pairs of one tap per thread, 16-byte slab
+// loads, four split groups per block folded through LDS, the same summation order), the four results scattered through the map
+__global__ __launch_bounds__(256) void wgrad_reduce_map_kernel(const float* __restrict__ slab, int nSplit, int taps, int O, int C,
+                                                               float* __restrict__ gw, WgradMap map) {
+  __shared__ float4 sh[4][64];
+  const long OC = (long)O * C, total = (long)taps * OC;
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (long t0 = (long)blockIdx.x * 256; t0 < total; t0 += (long)gridDim.x * 256) {
+    const long t = t0 + 4 * tx;
+    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    auto add = [](float4& a, const float4 x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; };
+    if (t < total) {
+      int s = g;
+      for (; s + 12 < nSplit; s += 16) {
+        const float4 x0 = *reinterpret_cast<const float4*>(slab + (size_t)s * total + t);
+        const float4 x1 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 4) * total + t);
+        const float4 x2 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 8) * total + t);
+        const float4 x3 = *reinterpret_cast<const float4*>(slab + (size_t)(s + 12) * total + t);
+        add(a0, x0); add(a1, x1); add(a2, x2); add(a3, x3);
+      }
+      for (; s < nSplit; s += 4) add(a0, *reinterpret_cast<const float4*>(slab + (size_t)s * total + t));
+    }
+    sh[g][tx] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                            (a0.w + a1.w) + (a2.w + a3.w));
+    __syncthreads();
+    if (g == 0 && t < total) {
+      const int tap = (int)(t / OC);
+      const long oc = t - (long)tap * OC;
+      const int o = (int)(oc / C), c = (int)(oc - (long)o * C);   // (C % 4 == 0: the four pairs share their filter)
+      const int od = map.omap ? map.omap[o] : o;
+      const float4 p0 = sh[0][tx], p1 = sh[1][tx], p2 = sh[2][tx], p3 = sh[3][tx];
+      const float r[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                          (p0.w + p1.w) + (p2.w + p3.w)};
+      if (od >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cd = map.cmap ? map.cmap[c + e] : c + e;
+          if (cd >= 0) gw[((size_t)od * map.Cfull + cd) * taps + tap] += r[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+int wgrad_reduce_map(const float* slab, int nSplit, int taps, int O, int C, float* gw, const WgradMap& map, hipStream_t s) {
+  FR_CHECK(map.Cfull > 0 && C % 4 == 0 && ((uintptr_t)slab & 15) == 0, "wgrad_reduce_map: the full tensor's channel count is missing, or C %% 4 != 0");
+  const int rgrid = (int)std::min<long>(cdivl((long)taps * O * C, 256), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_map_kernel, dim3(rgrid), dim3(256), 0, s, slab, nSplit, taps, O, C, gw, map);
+  return FRCNN_OK;
+}
+
 size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad) {
   if (k == 3 && Cin % 64 == 0 && O % 64 == 0) {   // either form may run (option split_bf16): room for both
     WgradArgs b;
@@ -1371,13 +1422,14 @@ static int launch_wgrad(WgradArgs& a, int klass, double flops, float* gw, hipStr
 
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias,
-               const float* amax_in, const float* amax_g) {
+               const float* amax_in, const float* amax_g, const WgradMap* map) {
   WgradArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g;
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad;
   a.Ho = H + 2 * pad - k + 1; a.Wo = W + 2 * pad - k + 1;
   FR_CHECK(k == 1 || k == 3 || k == 5 || k == 7, "conv_wgrad: unsupported kernel size %d", k);
-  if (conv_wgradx_eligible(Cin, O, k)) return conv_wgradx(in, Cin, H, W, in_slope, in_scale, g, O, pad, gw, ws, ws_bytes, s, gbias, amax_in, amax_g);
+  if (conv_wgradx_eligible(Cin, O, k)) return conv_wgradx(in, Cin, H, W, in_slope, in_scale, g, O, pad, gw, ws, ws_bytes, s, gbias, amax_in, amax_g, map);
+  FR_CHECK(!map || (!map->omap && !map->cmap), "conv_wgrad: a gathered weight gradient needs a conv_wgradx shape");
   if (gbias) FR_TRY(channel_sum(g, O, (long)a.Ho * a.Wo, gbias, s));   // the fp32 kernels leave the bias half to a pass of its own
   FR_CHECK((long)Cin * H * W < (1L << 31) && (long)O * a.Ho * a.Wo < (1L << 31), "conv_wgrad: tensor too large for 32-bit offsets");
   g_wgrad_first_ok = (in_slope == nullptr && in_scale == nullptr);

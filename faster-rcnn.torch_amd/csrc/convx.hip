@@ -250,6 +250,11 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
   }
   const int nCh = KC / CX_CH, pairs = (M / BM) * nCh;
   const int tid = threadIdx.x;
+  if (j.bias_dst && blk == 0)   // the gathered bias vector of a forward pack (PackXJob)
+    for (int m = tid; m < j.O; m += 256) {
+      const int o = j.oidx ? j.oidx[m] : m;
+      j.bias_dst[m] = o >= 0 ? weights[j.bias_off + o] : 0.f;
+    }
   const int groups = BM / ROWS;   // work unit = ROWS filter rows of one pair: equal units, one per block (conv_x3_pack_assign_blocks)
   for (int u = blk; u < pairs * groups; u += nblk) {
     const int pr = u / groups;
@@ -258,7 +263,17 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
     {
       const int r0 = (u - pr * groups) * ROWS;
       // tile[r][kc16 * KK + tap] (source tap order), r = filter row inside this group of ROWS rows
-      if (j.mode == 0) {
+      if (j.oidx || j.cidx) {   // gathered filters / channels (PackXJob): runs of KK floats
+        const int Cs = j.Cs ? j.Cs : j.C;
+        for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
+          const int r = e / (CX_CH * KK), q = e - r * (CX_CH * KK);
+          const int kc = q / KK, tap = q - kc * KK;
+          const int mrow = mt * BM + r0 + r, krow = chunk * CX_CH + kc;      // the pack's M row / K channel
+          const int op = j.mode == 0 ? mrow : krow, cp = j.mode == 0 ? krow : mrow;   // ... as filter o' / channel c'
+          const int o = j.oidx ? j.oidx[op] : op, c = j.cidx ? j.cidx[cp] : cp;
+          tile[r * PITCH + q] = (o >= 0 && c >= 0) ? w[((size_t)o * Cs + c) * KK + tap] : 0.f;
+        }
+      } else if (j.mode == 0) {
         for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
           const int r = e / (CX_CH * KK), q = e - r * (CX_CH * KK);
           tile[r * PITCH + q] = w[((size_t)(mt * BM + r0 + r) * j.C + chunk * CX_CH) * KK + q];

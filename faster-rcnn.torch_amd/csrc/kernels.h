@@ -43,7 +43,14 @@ void set_split_bf16(int on);   // option "split_bf16": 1 (default) eligible 3x3 
 int get_split_bf16();
 bool conv_x3_eligible(int Cin, int M, int k);   // k == 3: Cin % 16 == 0, M % 64 == 0; k in {5, 7}: M % 128 == 0 (and the option is on)
 size_t conv_x3_pack_bytes(int Kchan, int M, int k);
-struct PackXJob { long w_off; long total; void* dst; const float* amax; float* amax_w; int O, C, k, mode, bm, blk_begin, nblk; };   // mode 0 forward, 1 input gradient; bm = filters per block
+struct PackXJob {
+  long w_off; long total; void* dst; const float* amax; float* amax_w; int O, C, k, mode, bm, blk_begin, nblk;   // mode 0 forward, 1 input gradient; bm = filters per block
+  // Optional gather (round 6, the channels a SpatialDropout keeps): the pack describes a convolution of O x C filters whose
+  // filter o' / channel c' is the tensor's filter oidx[o'] / channel cidx[c'] (device tables; a negative entry = a filter /
+  // channel of zeros; null = the identity), Cs = channels of the SOURCE tensor (its row pitch; 0 = C).  bias_dst (mode 0 with
+  // oidx): bias_dst[o'] = weights[bias_off + oidx[o']] (0 for a negative entry), written by the job's first block.
+  const int* oidx = nullptr; const int* cidx = nullptr; int Cs = 0; long bias_off = 0; float* bias_dst = nullptr;
+};
 PackXJob conv_x3_pack_job(long w_off, int O, int C, int k, int mode, void* dst, int Ho, int Wo);   // Ho x Wo: output map of the launch it feeds
 int conv_x3_pack_assign_blocks(PackXJob* jobs, int njobs);   // -> grid size
 int conv_x3_pack_multi(const float* weights, const PackXJob* jobs_dev, int njobs, int grid, hipStream_t s);
@@ -77,11 +84,18 @@ struct X3PostAct {
 // weight gradient in the same split-bf16 form (wgradx.hip): k == 3, Cin % 64 == 0, O % 64 == 0; conv_wgrad routes to it
 bool conv_wgradx_eligible(int Cin, int O, int k);
 size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad);
+// Where a weight gradient computed for O x Cin gathered filters / channels lands in the full tensor (round 6): filter o' is the
+// tensor's filter omap[o'], channel c' its channel cmap[c'] (device tables; negative = padding, nothing is written; null = the
+// identity), Cfull = channels of the full tensor.  gbias follows omap.
+struct WgradMap { const int* omap = nullptr; const int* cmap = nullptr; int Cfull = 0; };
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
                 int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias = nullptr,
-                const float* amax_in = nullptr, const float* amax_g = nullptr);   // both records (amax.h): the two-plane fp16 form
+                const float* amax_in = nullptr, const float* amax_g = nullptr,   // both records (amax.h): the two-plane fp16 form
+                const WgradMap* map = nullptr);
 // gw[o][c][tap] += sum_s slab[s][tap][o][c]   (the fold shared by the weight-gradient kernels)
 int wgrad_reduce(const float* slab, int nSplit, int taps, int OC, float* gw, hipStream_t s);
+// the same through a WgradMap: slab [s][tap][O][C] of the gathered problem, gw the full tensor
+int wgrad_reduce_map(const float* slab, int nSplit, int taps, int O, int C, float* gw, const WgradMap& map, hipStream_t s);
 // first layer of a one-convolution block: weight, bias and slope gradients straight from the pooled map's gradient
 bool conv_wgrad_first_pooled_eligible(int Cin, int O, int k, int Wo);
 int conv_wgrad_first_pooled(const float* in, int Cin, int H, int W, const float* gpool, const unsigned char* pidx, const float* x,
@@ -94,7 +108,8 @@ size_t conv_wgrad_workspace_bytes(int Cin, int H, int W, int O, int k, int pad);
 int conv_wgrad(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale,
                const float* g, int O, int k, int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s,
                float* gbias = nullptr,   // gbias: also gbias[o] += sum over pixels of g (in the same launch where the kernel can)
-               const float* amax_in = nullptr, const float* amax_g = nullptr);   // magnitude records of in / g: conv_wgradx's fp16 form
+               const float* amax_in = nullptr, const float* amax_g = nullptr,   // magnitude records of in / g: conv_wgradx's fp16 form
+               const WgradMap* map = nullptr);   // (conv_wgradx shapes only)
 
 // ---------------------------------------------------------------- deterministic mode (frcnn_set_option("deterministic", 1))
 // Default: per-block partial sums of the bias / slope gradients and the scatter-adds of the ROI-pooling and sparse anchor-net

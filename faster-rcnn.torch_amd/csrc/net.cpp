@@ -61,6 +61,17 @@ struct Block {
   DevBuf pidx;
   int Hp, Wp;
   int am = -1;                // magnitude record of `pooled`
+  // Channels a SpatialDropout keeps (round 6, option "drop_compact"): a block of >= 2 convolutions whose dropout sits behind its
+  // first one (models/model_utilities.lua:9-12) is, for the length of one training step, a NARROWER network -- the dropped
+  // channels of the first convolution's output are multiplied by zero on the way forward and on the way back, so neither they
+  // nor anything computed from them is needed.  With the keep vector known on the host, the step runs the first convolution
+  // with the kept filters only (its output, and that output's gradient, are stored COMPACT: kept channels first) and the second
+  // one with the kept input channels only; the packs gather the filters / channels, the weight gradients are scattered back.
+  // Same results as multiplying by the zeros (sums of exact zeros left out), 25-37 % less matrix work in these layers.
+  bool dc_on = false;         // this step runs the block compact
+  int nk = 0, nkM = 0, nkK = 0;   // channels kept; padded to a multiple of 64 (a filter / tile dimension) and of 16 (a K dimension)
+  const int* dc_idx = nullptr;    // device table of this step: entry i < nk = the i-th kept channel, nk <= i < C: -1
+  DevBuf dc_bias;             // the first convolution's bias, gathered (nkM entries, padding 0)
 };
 
 struct Head {
@@ -98,6 +109,11 @@ struct ClsLayer {
 
 using namespace frcnn;
 
+static int g_drop_compact = -1;   // option "drop_compact" (environment FRCNN_DROP_COMPACT), default on
+static int drop_compact_on() {
+  if (g_drop_compact < 0) g_drop_compact = getenv("FRCNN_DROP_COMPACT") ? (atoi(getenv("FRCNN_DROP_COMPACT")) != 0) : 1;
+  return g_drop_compact;
+}
 static int g_static_weights = 0;   // option "static_weights" (see forward_impl)
 static long g_static_gen = 0;      // bumped by every set_option("static_weights", v)
 
@@ -138,6 +154,13 @@ struct frcnn_model {
   unsigned fresh_mask = 0;         // bit g: group g's training packs were renewed by frcnn_pnet_refresh_packs since the last forward
   const float* fresh_w = nullptr;  // ... from this weight vector
   bool fresh_f16 = false;          // ... in this form
+  // per-step tables of the compact blocks (see Block::dc_on): a ring of page-locked host slots and device slots, one
+  // asynchronous copy per step: [PackXJob table of the step][kept-channel tables of the blocks]
+  static const int DC_RING = 4;
+  char* dc_pin = nullptr; DevBuf dc_dev; size_t dc_slot_bytes = 0, dc_idx_off = 0; unsigned dc_step = 0;
+  std::vector<PackXJob> x3_host, x3_host16;   // the model's training pack jobs as built by ensure_shapes (plain | fp16 form), host copies
+  std::vector<int> x3_conv;                   // ... the convolution each job belongs to (index into convs, -1: an anchor net)
+  DevBuf dbg_expand;                          // frcnn_model_debug_buffer: a compact tensor laid out dense
   std::vector<hipEvent_t> block_rd_ev;   // block b's weights and packs have been read for the last time (caller's stream, frcnn_pnet_backward)
   hipStream_t side = nullptr;      // accGradParameters stream (runs beside the updateGradInput chain)
   hipStream_t cw = nullptr;        // the classification net's weight gradients / bias sums (beside its input-gradient chain)
@@ -429,8 +452,30 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
         all16.push_back(j);
       }
     };
-    for (auto& c : m->convs) add(c);
-    for (auto& hd : m->heads) add(hd.c3);
+    m->x3_conv.clear();
+    for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+      const size_t n0 = all.size();
+      add(m->convs[ci]);
+      m->x3_conv.insert(m->x3_conv.end(), all.size() - n0, (int)ci);
+    }
+    for (auto& hd : m->heads) { const size_t n0 = all.size(); add(hd.c3); m->x3_conv.insert(m->x3_conv.end(), all.size() - n0, -1); }
+    m->x3_host = all; m->x3_host16 = all16;   // (host copies for the per-step tables of the compact blocks)
+    {  // ring of per-step tables: [PackXJob x jobs][int x channels of every block], see frcnn_model::dc_pin
+      size_t chans = 0;
+      for (size_t b = 0; b < m->blocks.size(); ++b) chans += (size_t)m->d.filters[b];
+      m->dc_idx_off = (all.size() * sizeof(PackXJob) + 255) / 256 * 256;
+      const size_t slot = (m->dc_idx_off + chans * 4 + 255) / 256 * 256;
+      if (slot != m->dc_slot_bytes) {
+        if (m->dc_pin) (void)hipHostFree(m->dc_pin);
+        m->dc_pin = nullptr;
+        FR_HIP(hipHostMalloc((void**)&m->dc_pin, slot * frcnn_model::DC_RING, hipHostMallocDefault));
+        m->dc_dev.release();
+        FR_TRY(m->dc_dev.ensure(slot * frcnn_model::DC_RING));
+        m->dc_slot_bytes = slot;
+      }
+      for (size_t b = 0; b < m->blocks.size(); ++b)
+        if (m->blocks[b].has_drop) FR_TRY(m->blocks[b].dc_bias.ensure((size_t)m->d.filters[b] * 4));
+    }
     m->n_x3_all = (int)all.size(); m->n_x3_fwd = (int)fwd.size();
     m->x3_grid_all = conv_x3_pack_assign_blocks(all.data(), m->n_x3_all);
     m->x3_grid_fwd = conv_x3_pack_assign_blocks(fwd.data(), m->n_x3_fwd);
@@ -499,7 +544,9 @@ int frcnn_model_destroy(frcnn_model* m) {
   if (!m) return FRCNN_OK;
   auto rel = [](Conv& c) { c.wf.release(); c.wd.release(); c.wx.release(); c.wxd.release(); c.x.release(); c.gx.release(); };
   for (auto& c : m->convs) rel(c);
-  for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); }
+  for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); b.dc_bias.release(); }
+  if (m->dc_pin) (void)hipHostFree(m->dc_pin);
+  m->dc_dev.release(); m->dbg_expand.release();
   for (auto& h : m->heads) {
     rel(h.c3); rel(h.c1); h.delta.release();
     h.spD.release(); h.spHX.release(); h.spHY.release(); h.spGH.release(); h.spCol.release(); h.spDX.release();
@@ -637,6 +684,7 @@ int frcnn_get_option(const char* name, int* value) {
   if (strcmp(name, "gemm_x_roles") == 0) { *value = get_gemm_x_roles(); return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "static_weights") == 0) { *value = g_static_weights; return FRCNN_OK; }
+  if (strcmp(name, "drop_compact") == 0) { *value = drop_compact_on(); return FRCNN_OK; }
   if (strcmp(name, "winograd") == 0) { *value = 0; return FRCNN_OK; }   // removed in round 3; kept as a name that reads 0
   if (strcmp(name, "cnet_wgrad_async") == 0) { *value = g_cnet_wgrad_async; return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
@@ -650,6 +698,7 @@ int frcnn_set_option(const char* name, int value) {
   if (strcmp(name, "side_stream") == 0) { g_side_stream = value ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
   if (strcmp(name, "static_weights") == 0) { g_static_weights = value != 0; ++g_static_gen; return FRCNN_OK; }
+  if (strcmp(name, "drop_compact") == 0) { g_drop_compact = value != 0; return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   if (strcmp(name, "x3_f16") == 0) { set_x3_f16(value); return FRCNN_OK; }           // takes effect with the next forward pass
@@ -758,6 +807,99 @@ static int head_forward(frcnn_model* m, Head& h, const float* w, hipStream_t s, 
   return FRCNN_OK;
 }
 
+// ---- compact blocks (Block::dc_on) --------------------------------------------------------------------------------------
+static bool any_compact(const frcnn_model* m) {
+  for (auto& b : m->blocks) if (b.dc_on) return true;
+  return false;
+}
+static bool fuse_act_on() { return !deterministic() && !(getenv("FRCNN_FUSE_ACT") && atoi(getenv("FRCNN_FUSE_ACT")) == 0); }
+
+// Decides, block by block, whether this training pass runs compact, from the keep vectors -- drawn here with the very hash the
+// device kernel uses (common.h frcnn_keep_mask: the vectors on the device and on the host are the same), or read back from the
+// caller's explicit masks (a synchronous copy: parity runs only) -- and fills the step's slot of the table ring with the kept
+// channels.  The job table follows in pack_compact.
+static int plan_compact(frcnn_model* m, int training, const float* const* drop_masks, unsigned long long seed) {
+  for (auto& b : m->blocks) { b.dc_on = false; b.dc_idx = nullptr; }
+  if (!training || !drop_compact_on() || !fuse_act_on() || !m->dc_pin) return FRCNN_OK;
+  const unsigned slot = m->dc_step % frcnn_model::DC_RING;
+  int* idx_host = (int*)(m->dc_pin + (size_t)slot * m->dc_slot_bytes + m->dc_idx_off);
+  const int* idx_dev = (const int*)((char*)m->dc_dev.p + (size_t)slot * m->dc_slot_bytes + m->dc_idx_off);
+  size_t at = 0;
+  std::vector<float> keep;
+  for (size_t b = 0; b < m->blocks.size(); ++b) {
+    Block& blk = m->blocks[b];
+    const int C = m->d.filters[b];
+    const size_t my = at;
+    at += (size_t)C;
+    if (!blk.has_drop || blk.nconv < 2) continue;
+    Conv &c0 = m->convs[blk.first_conv], &c1 = m->convs[blk.first_conv + 1];
+    if (!(c0.k == 3 && c1.k == 3 && c0.x_f && c1.x_f && c1.x_d && (b == 0 || c0.x_d))) continue;
+    keep.resize(C);
+    if (drop_masks && drop_masks[b]) {
+      FR_HIP(hipMemcpy(keep.data(), drop_masks[b], (size_t)C * 4, hipMemcpyDeviceToHost));
+    } else {
+      for (int i = 0; i < C; ++i) keep[i] = frcnn_keep_mask(seed * 131 + b, (unsigned long long)i, blk.p_drop);
+    }
+    int nk = 0;
+    bool binary = true;
+    for (int i = 0; i < C; ++i) {
+      if (keep[i] == 1.0f) idx_host[my + nk++] = i;
+      else if (keep[i] != 0.0f) binary = false;   // (a caller's scale vector that is no keep vector: the dense path multiplies by it)
+    }
+    if (!binary) continue;
+    for (int i = nk; i < C; ++i) idx_host[my + i] = -1;
+    const int nkM = std::min(C, (nk + 63) / 64 * 64), nkK = std::min(C, (nk + 15) / 16 * 16);
+    if (nk == 0 || nkK >= C) continue;                       // nothing to leave out (or nothing kept: the dense path handles the zeros)
+    if (!conv_x3_eligible(c0.Cin, nkM, 3) || !conv_x3_eligible(nkK, c1.Cout, 3) || !conv_x3_eligible(c1.Cout, nkM, 3) ||
+        (b > 0 && !conv_x3_eligible(nkK, c0.Cin, 3)) || !conv_wgradx_eligible(nkM, c1.Cout, 3) || !conv_wgradx_eligible(c0.Cin, nkM, 3))
+      continue;
+    blk.dc_on = true; blk.nk = nk; blk.nkM = nkM; blk.nkK = nkK; blk.dc_idx = idx_dev + my;
+  }
+  return FRCNN_OK;
+}
+
+// The step's pack-job table: the model's jobs, those of the compact blocks re-written for the kept filters / channels; one
+// asynchronous copy brings it and the kept-channel tables over, one launch packs.
+static int pack_compact(frcnn_model* m, const float* w, bool f16, hipStream_t s) {
+  const unsigned slot = m->dc_step % frcnn_model::DC_RING;
+  ++m->dc_step;
+  char* hslot = m->dc_pin + (size_t)slot * m->dc_slot_bytes;
+  char* dslot = (char*)m->dc_dev.p + (size_t)slot * m->dc_slot_bytes;
+  const std::vector<PackXJob>& src = f16 ? m->x3_host16 : m->x3_host;
+  PackXJob* jobs = (PackXJob*)hslot;
+  const int n = (int)src.size();
+  for (int i = 0; i < n; ++i) {
+    PackXJob j = src[i];
+    const int ci = m->x3_conv[i];
+    if (ci >= 0) {
+      const Conv& c = m->convs[ci];
+      const Block& blk = m->blocks[c.block];
+      if (blk.dc_on && c.step <= 1) {
+        // (b, 0): filters gathered -- forward M = nkM, input gradient K = nkK;  (b, 1): channels gathered -- forward K = nkK,
+        // input gradient M = nkM.  Entries beyond the kept ones are -1: rows / channels of zeros.
+        PackXJob g;
+        if (c.step == 0) {
+          const int O = j.mode == 0 ? blk.nkM : blk.nkK;
+          g = j.mode == 0 ? conv_x3_pack_job(c.w_off, O, c.Cin, c.k, 0, c.wx.p, c.Ho, c.Wo) : conv_x3_pack_job(c.w_off, O, c.Cin, c.k, 1, c.wxd.p, c.H, c.W);
+          g.oidx = blk.dc_idx; g.Cs = c.Cin;
+          if (j.mode == 0) { g.bias_off = c.b_off; g.bias_dst = blk.dc_bias.f(); }
+        } else {
+          const int C = j.mode == 0 ? blk.nkK : blk.nkM;
+          g = j.mode == 0 ? conv_x3_pack_job(c.w_off, c.Cout, C, c.k, 0, c.wx.p, c.Ho, c.Wo) : conv_x3_pack_job(c.w_off, c.Cout, C, c.k, 1, c.wxd.p, c.H, c.W);
+          g.cidx = blk.dc_idx; g.Cs = c.Cin;
+        }
+        g.amax = j.amax; g.amax_w = j.amax_w;
+        j = g;
+      }
+    }
+    jobs[i] = j;
+  }
+  const int grid = conv_x3_pack_assign_blocks(jobs, n);
+  FR_HIP(hipMemcpyAsync(dslot, hslot, m->dc_slot_bytes, hipMemcpyHostToDevice, s));
+  FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)dslot, n, grid, s));
+  return FRCNN_OK;
+}
+
 static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, int H, int W, int training,
                              const float* const* drop_masks, unsigned long long seed, void* stream, bool async_heads) {
   hipStream_t s = S(stream);
@@ -784,6 +926,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     }
   }
   FR_TRY(dropout_channel_masks(dj, s));
+  FR_TRY(plan_compact(m, training, drop_masks, seed));
   // weights change every optimiser step: refresh the packed copies (one table-driven launch each).  Option static_weights: an
   // evaluate-mode pass re-uses the packs of the previous evaluate-mode pass with the same weight vector -- the host's promise that
   // it has not written the weights in between (a training-mode pass, a shape change and every frcnn_set_option("static_weights", v)
@@ -794,7 +937,8 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
   m->f16_packed = f16;
   // ... or every owner's packs were renewed from this weight vector since the last pass (frcnn_pnet_refresh_packs: the update
   // ran beside the previous backward pass).  One-shot: the promise covers the pass that consumes it.
-  const bool fresh = training && !m->groups.empty() && m->fresh_mask == (1u << m->groups.size()) - 1 && m->fresh_w == w && m->fresh_f16 == f16;
+  const bool fresh = training && !m->groups.empty() && m->fresh_mask == (1u << m->groups.size()) - 1 && m->fresh_w == w && m->fresh_f16 == f16 &&
+                     !any_compact(m);   // (a compact block's packs depend on the step's keep vector)
   m->fresh_mask = 0;
   if (!reuse && !fresh) {
     if (training)
@@ -804,7 +948,9 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
     if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
       FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p, m->n_amax_jobs, m->amax_grid, s));
-    if (training)
+    if (training && any_compact(m))
+      FR_TRY(pack_compact(m, w, f16, s));   // the step's own table: the compact blocks' jobs gather the kept filters / channels
+    else if (training)
       FR_TRY(conv_x3_pack_multi(w, xjobs, m->n_x3_all, m->x3_grid_all, s));
     else
       FR_TRY(conv_x3_pack_multi(w, xjobs + m->n_x3_all, m->n_x3_fwd, m->x3_grid_fwd, s));
@@ -828,7 +974,14 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
                       (st == 0 && blk.has_drop) ? blk.scale.f() : nullptr, f16 ? m->rec(blk.am) : nullptr};
       // fp16 form: the next convolution reads c.x scaled by its largest magnitude, which the launch that writes c.x records
       const bool want_am = f16 && !last && m->convs[blk.first_conv + st + 1].x_f;
-      if (c.x_f)
+      if (c.x_f && blk.dc_on && st <= 1) {
+        // compact block: the first convolution computes its kept filters only (output stored compact), the second reads the
+        // kept channels only -- their dropout scale is 1
+        const int cin = st == 0 ? c.Cin : blk.nkK, mo = st == 0 ? blk.nkM : c.Cout;
+        FR_TRY(conv_x3(cur, cin, c.H, c.W, cur_slope, nullptr, c.wx.p, st == 0 ? blk.dc_bias.f() : w + c.b_off, mo, c.k, c.pad, c.x.f(),
+                       OUT_STORE, 0, s, 0, nullptr, f16 ? cur_am : nullptr, f16 ? m->amax_ws.f() + c.am : nullptr,
+                       want_am ? m->rec(c.am) : nullptr));
+      } else if (c.x_f)
         FR_TRY(conv_x3(cur, c.Cin, c.H, c.W, cur_slope, cur_scale, c.wx.p, w + c.b_off, c.Cout, c.k, c.pad, c.x.f(), OUT_STORE, 0, s, 0,
                        nullptr, f16 ? cur_am : nullptr, f16 ? m->amax_ws.f() + c.am : nullptr, want_am ? m->rec(c.am) : nullptr));
       else
@@ -913,6 +1066,22 @@ int frcnn_model_debug_buffer(frcnn_model* m, int kind, int index, void** ptr, lo
     case 0: {
       FR_CHECK(index >= 0 && index < (int)m->convs.size() && m->H > 0, "debug_buffer: backbone convolution %d (after a forward pass)", index);
       const Conv& c = m->convs[index]; b = &c.x; n = (size_t)c.Cout * c.Ho * c.Wo * 4;
+      const Block& k = m->blocks[c.block];
+      if (k.dc_on && c.step == 0) {   // stored compact in this pass (Block::dc_on): laid out dense here, zeros where nothing was computed
+        FR_HIP(hipDeviceSynchronize());
+        FR_TRY(m->dbg_expand.ensure(n));
+        FR_HIP(hipMemset(m->dbg_expand.p, 0, n));
+        std::vector<int> idx(c.Cout);
+        FR_HIP(hipMemcpy(idx.data(), k.dc_idx, (size_t)c.Cout * 4, hipMemcpyDeviceToHost));
+        const size_t row = (size_t)c.Ho * c.Wo * 4;
+        for (int i = 0; i < k.nk; ++i)
+          FR_HIP(hipMemcpy((char*)m->dbg_expand.p + (size_t)idx[i] * row, (const char*)c.x.p + (size_t)i * row, row, hipMemcpyDeviceToDevice));
+        b = &m->dbg_expand;
+      }
+    } break;
+    case 4: {   // the SpatialDropout scale vector of block `index` in the last pass (a keep vector while training)
+      FR_CHECK(index >= 0 && index < (int)m->blocks.size() && m->H > 0 && m->blocks[index].has_drop, "debug_buffer: block %d has no dropout", index);
+      const Block& k = m->blocks[index]; b = &k.scale; n = (size_t)m->d.filters[index] * 4;
     } break;
     case 1: {
       FR_CHECK(index >= 0 && index < (int)m->blocks.size() && m->H > 0, "debug_buffer: block %d (after a forward pass)", index);
@@ -1287,6 +1456,17 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       } else {
         in = b == 0 ? m->img.f() : m->blocks[b - 1].pooled.f();
       }
+      // compact block (Block::dc_on): the second convolution's weight gradient is computed for the kept input channels (its
+      // input IS the compact tensor; their dropout scale is 1), the first one's for the kept filters (its output gradient is
+      // compact); the fold scatters both into the full tensors, the bias gradient follows the filter map
+      const bool dc = blk.dc_on && st <= 1;
+      int wg_cin = c.Cin, wg_o = c.Cout;
+      WgradMap wmap;
+      if (dc) {
+        wmap.Cfull = c.Cin;
+        if (st == 1) { wg_cin = blk.nkM; wmap.cmap = blk.dc_idx; in_scale = nullptr; }
+        else { wg_o = blk.nkM; wmap.omap = blk.dc_idx; }
+      }
       // fp16 form of the weight-gradient launch: the records of both tensors exist when the forward launch that wrote `in` and
       // the backward launch that wrote c.gx kept them (the same two tensors feed c's forward and c's input gradient)
       const float* wa_in = nullptr; const float* wa_g = nullptr;
@@ -1300,13 +1480,13 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       const bool on_caller = use_side && b == 0 && st == 0;
       if (use_side && !on_caller) FR_TRY(fork_side(m, s, n_fork++));   // c.gx is final here
       if (on_caller) {
-        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws_first.p,
-                          m->wg_ws_first.bytes, s, fused_here ? grad + c.b_off : nullptr, wa_in, wa_g));
+        FR_TRY(conv_wgrad(in, wg_cin, c.H, c.W, in_slope, in_scale, c.gx.f(), wg_o, c.k, c.pad, grad + c.w_off, m->wg_ws_first.p,
+                          m->wg_ws_first.bytes, s, fused_here ? grad + c.b_off : nullptr, wa_in, wa_g, dc ? &wmap : nullptr));
         FR_HIP(hipEventRecord(m->join_ev, ws));          // (block 0's other convolutions, if any, are on the side stream)
         FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
       } else {
-        FR_TRY(conv_wgrad(in, c.Cin, c.H, c.W, in_slope, in_scale, c.gx.f(), c.Cout, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws,
-                          fused_here ? grad + c.b_off : nullptr, wa_in, wa_g));
+        FR_TRY(conv_wgrad(in, wg_cin, c.H, c.W, in_slope, in_scale, c.gx.f(), wg_o, c.k, c.pad, grad + c.w_off, m->wg_ws.p, m->wg_ws.bytes, ws,
+                          fused_here ? grad + c.b_off : nullptr, wa_in, wa_g, dc ? &wmap : nullptr));
       }
       if (st == 0) {   // every gradient of block b's parameters is final once this launch has run (its fork also
                        // covers the bias / slope sums that act_backward accumulates on the caller's stream)
@@ -1321,7 +1501,6 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
         FR_TRY(record_block_read(m, b, s));
         break;
       }
-      double fl = 2.0 * c.Cout * c.Cin * c.k * c.k * (double)c.Ho * c.Wo;
       float* gin = st > 0 ? m->convs[blk.first_conv + st - 1].gx.f() : m->blocks[b - 1].gpooled.f();
       const int gmode = st > 0 ? OUT_STORE : OUT_ADD;
       // fp16 form: the magnitude of c.gx was recorded by the launch that finished it (the pooling / activation backward above,
@@ -1329,14 +1508,19 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       const float* ag = nullptr;
       const float* aw = nullptr;
       if (c.x_d && m->f16_packed) { ag = m->rec(c.am + 1); aw = m->amax_ws.f() + c.am; }
+      // compact block: the second convolution's input gradient is computed for the kept channels only and stored compact (it
+      // passes through the first convolution's PReLU; the kept channels' dropout scale is 1); the first convolution's reads
+      // that compact gradient: K = the kept filters
+      const int dg_k = (dc && st == 0) ? blk.nkK : c.Cout, dg_m = (dc && st == 1) ? blk.nkM : c.Cin;
+      const double fl = 2.0 * dg_k * dg_m * c.k * c.k * (double)c.Ho * c.Wo;
       if (c.x_d && st > 0 && fuse_act && c.k == 3) {
         Conv& pc = m->convs[blk.first_conv + st - 1];
-        X3PostAct post{pc.x.f(), w + pc.a_off, (st - 1 == 0 && blk.has_drop) ? blk.scale.f() : nullptr, grad + pc.a_off};
-        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, &post, ag, aw,
+        X3PostAct post{pc.x.f(), w + pc.a_off, (st - 1 == 0 && blk.has_drop && !dc) ? blk.scale.f() : nullptr, grad + pc.a_off};
+        FR_TRY(conv_x3(c.gx.f(), dg_k, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, dg_m, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, &post, ag, aw,
                        (pc.x_d && m->f16_packed) ? m->rec(pc.am + 1) : nullptr));
         act_done = true;
       } else if (c.x_d)
-        FR_TRY(conv_x3(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, c.Cin, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, nullptr, ag, aw));
+        FR_TRY(conv_x3(c.gx.f(), dg_k, c.Ho, c.Wo, nullptr, nullptr, c.wxd.p, nullptr, dg_m, c.k, c.k - 1 - c.pad, gin, gmode, fl, s, 0, nullptr, ag, aw));
       else
         FR_TRY(conv_igemm(c.gx.f(), c.Cout, c.Ho, c.Wo, nullptr, nullptr, c.wd.f(), nullptr, c.Cin, c.k,
                           c.k - 1 - c.pad, gin, gmode, fl, s));

@@ -104,6 +104,7 @@ struct WgradXArgs {
   float* gbias;  // optional [O]: += sum over pixels of g (accGradParameters' bias half), taken from the staged gradient tiles
   const float* amax_in;   // NP = 2 (two-plane fp16 form): magnitude records of `in` and `g` (amax.h)
   const float* amax_g;
+  const int* omap;        // optional (WgradMap): filter o of this launch is the tensor's filter omap[o] (negative: none) -- for gbias
   int Cin, H, W, O, Ho, Wo, pad;
   int tilesX, tilesY, oTiles, cTiles, nSplit;
 };
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgradx_kernel(WgradXArgs p) {
   if (p.gbias && ct == 0) {
     float v = bsum;
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);      // the four quarters of one filter row are neighbouring lanes
-    if (sq == 0) unsafeAtomicAdd(p.gbias + o0 + srow, v);
+    const int od = p.omap ? p.omap[o0 + srow] : o0 + srow;
+    if (sq == 0 && od >= 0) unsafeAtomicAdd(p.gbias + od, v);
   }
   // ---- epilogue: D col = lane&31 -> c (contiguous in the slab), row -> o
   {
@@ -524,6 +526,8 @@ size_t conv_wgradx_workspace_bytes(int Cin, int H, int W, int O, int pad) {
   return (size_t)a.nSplit * 9 * O * Cin * 4 + 256;
 }
 
+static const WgradMap* g_wx_map = nullptr;   // (the map of the call being launched: host-side, single-threaded launch path)
+
 template <bool SLOPE, bool SCALE, int VEC, int NP = 3>
 static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s) {
   static bool attr_set = false;
@@ -537,7 +541,8 @@ static int launch_wgradx_v(WgradXArgs& a, double flops, float* gw, hipStream_t s
   if (prof_enabled(KC_CONV_WGRADX)) prof_before(KC_CONV_WGRADX, s);
   const size_t lds = 2 * (size_t)NP * (WX_GPLANE + WX_XPLANE);   // two images (> 80 KB: one block per CU)
   hipLaunchKernelGGL((conv_wgradx_kernel<SLOPE, SCALE, VEC, NP>), dim3(grid), dim3(256), lds, s, a);
-  FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
+  if (g_wx_map) FR_TRY(wgrad_reduce_map(a.slab, a.nSplit, 9, a.O, a.Cin, gw, *g_wx_map, s));
+  else FR_TRY(wgrad_reduce(a.slab, a.nSplit, 9, a.O * a.Cin, gw, s));
   if (prof_enabled(KC_CONV_WGRADX)) prof_after(KC_CONV_WGRADX, flops, bytes, s);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
@@ -565,10 +570,13 @@ static int launch_wgradx(WgradXArgs& a, double flops, float* gw, hipStream_t s) 
 }
 
 int conv_wgradx(const float* in, int Cin, int H, int W, const float* in_slope, const float* in_scale, const float* g, int O,
-                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias, const float* amax_in, const float* amax_g) {
+                int pad, float* gw, void* ws, size_t ws_bytes, hipStream_t s, float* gbias, const float* amax_in, const float* amax_g,
+                const WgradMap* map) {
   WgradXArgs a;
   a.in = in; a.in_slope = in_slope; a.in_scale = in_scale; a.g = g; a.gbias = gbias;
   a.amax_in = amax_in; a.amax_g = amax_g;
+  a.omap = map ? map->omap : nullptr;
+  struct MapScope { MapScope(const WgradMap* m) { g_wx_map = (m && (m->omap || m->cmap)) ? m : nullptr; } ~MapScope() { g_wx_map = nullptr; } } scope(map);
   FR_CHECK((amax_in != nullptr) == (amax_g != nullptr), "conv_wgradx: the fp16 form needs the magnitude records of both tensors");
   a.Cin = Cin; a.H = H; a.W = W; a.O = O; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
   FR_CHECK(Cin % 64 == 0 && O % 64 == 0, "conv_wgradx: %d channels x %d filters is not a split-bf16 shape", Cin, O);

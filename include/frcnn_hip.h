@@ -67,7 +67,16 @@ int frcnn_device_name(char *buf_host, int len);
  * "static_weights" (default 0): the host promises that it does not write the weight vector between evaluate-mode forward passes
  * (Detector:detect on a trained model); the library then re-uses the packed / split copies of the convolution weights instead of
  * remaking them per pass.  A training-mode pass, a change of the frame size and every frcnn_set_option("static_weights", v) call
- * drop the copies -- a host that has written the weights itself says so by setting the option again. */
+ * drop the copies -- a host that has written the weights itself says so by setting the option again.
+ * "drop_compact" (default 1; environment FRCNN_DROP_COMPACT): a training pass leaves out the channels an nn.SpatialDropout
+ * (models/model_utilities.lua:10-12) drops.  In a block of two or more convolutions the dropout follows the first one, so for the
+ * length of a step the dropped filters of the first convolution and the dropped input channels of the second multiply zeros --
+ * forward (objective.lua:71) and backward (:189).  With the keep vector known on the host (drawn with the hash the device kernel
+ * uses; an explicit mask is read back -- a synchronous copy, parity runs) the step computes the first convolution for the kept
+ * filters only, stores its output and that output's gradient compact, and runs the second convolution, both input gradients and
+ * both weight gradients on the kept channels (padded to the kernels' 16 / 64-channel granularity); packs gather, the weight-
+ * gradient folds scatter.  Results equal the dense pass's to rounding (sums of exact zeros are left out); the dropped filters'
+ * and channels' gradients stay the zeros objective.lua:49 put there.  0 = multiply by the zeros like the reference does. */
 int frcnn_set_option(const char *name, int value);
 int frcnn_get_option(const char *name, int *value_host);
 
@@ -308,10 +317,12 @@ int frcnn_pnet_output(frcnn_model *, int i, float **ptr_host, int *C_host, int *
  * (max-pool window winners, PReLU branches) to the CPU restatement so that gradients can be compared at the strict
  * tolerance (oracle/frcnn_oracle.h orc_set_decisions).  The pointer stays owned by the model and valid until the next
  * forward pass of another image size.
- *   kind 0: pre-activation output of backbone convolution `index` (float [O][Ho][Wo]; model_utilities.lua:8)
+ *   kind 0: pre-activation output of backbone convolution `index` (float [O][Ho][Wo]; model_utilities.lua:8).  A training pass
+ *           with option "drop_compact" does not compute the output channels the block's SpatialDropout (:10-12) drops: they read 0
  *   kind 1: arg-max of block `index`'s 2x2 ceil-mode max pool (unsigned char [C][Hp][Wp], value dy*2+dx; :23)
  *   kind 2: pre-activation output of anchor net `index`'s k x k convolution (float [n][Ho][Wo]; :31)
- *   kind 3: input of classification layer `index`'s PReLU (float [R][n]; :85-86), after frcnn_cnet_forward */
+ *   kind 3: input of classification layer `index`'s PReLU (float [R][n]; :85-86), after frcnn_cnet_forward
+ *   kind 4: the nn.SpatialDropout scale vector of block `index` in the last pass (float [C]; a 0/1 keep vector while training) */
 int frcnn_model_debug_buffer(frcnn_model *, int kind, int index, void **ptr_host, long long *bytes_host);
 /* delta_outputs[i] (objective.lua:78-84): gradient buffers with the shapes of the outputs. */
 int frcnn_pnet_delta(frcnn_model *, int i, float **ptr_host);

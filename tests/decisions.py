@@ -26,7 +26,7 @@ def capture(F, model, H, W, R=0, roi_idx=None):
     forward with R rows, if R > 0)."""
     nat = model["native"]
     layers = model["layers"]
-    d = dict(pool_idx=[], conv_pos=[], head_pos=[], cnet_pos=[], roi_idx=None)
+    d = dict(pool_idx=[], conv_pos=[], head_pos=[], cnet_pos=[], roi_idx=None, conv_ignore=[])
     h, w = H, W
     ci = 0
     block_hw = []
@@ -35,6 +35,14 @@ def capture(F, model, H, W, R=0, roi_idx=None):
             h = h + 2 * l["padH"] - l["kH"] + 1; w = w + 2 * l["padW"] - l["kW"] + 1
             x = _dev_array(F, nat, 0, ci, np.float32, (l["filters"], h, w))
             d["conv_pos"].append(np.ascontiguousarray((x > 0).astype(np.uint8)))
+            # Channels a SpatialDropout behind this convolution dropped in the pass (a training pass does not even compute them,
+            # option "drop_compact": they read 0): their PReLU branch is multiplied by the zero scale forward and backward, so it is
+            # no decision of the path -- count_differences leaves them out
+            ign = None
+            if _ == 0 and l.get("dropout", 0) > 0 and l["conv_steps"] >= 2 and model["pnet"].train:
+                keep = _dev_array(F, nat, 4, b, np.float32, (l["filters"],))
+                ign = keep == 0
+            d["conv_ignore"].append(ign)
             ci += 1
         hp, wp = _pool_out(h), _pool_out(w)
         code = _dev_array(F, nat, 1, b, np.uint8, (l["filters"], hp, wp)).astype(np.int32)
@@ -59,6 +67,8 @@ def blank_like(d):
     """Arrays of the same shapes for O.decisions(record=...)."""
     out = dict(slope_abs=np.zeros(48))   # (record only: the size of the terms each PReLU slope gradient sums)
     for k, v in d.items():
+        if k == "conv_ignore":
+            continue
         if isinstance(v, list):
             out[k] = [np.zeros_like(a) for a in v]
         else:
@@ -69,14 +79,27 @@ def blank_like(d):
 def count_differences(a, b):
     """-> dict(kind -> (differing, total)) between two decision sets."""
     res = {}
+    ignore = a.get("conv_ignore") or b.get("conv_ignore")
     for k in a:
-        if k == "slope_abs" or k not in b:
+        if k in ("slope_abs", "conv_ignore") or k not in b:
             continue
         va, vb = a[k], b[k]
         if va is None or vb is None:
             continue
         if not isinstance(va, list):
             va, vb = [va], [vb]
+        if k == "conv_pos" and ignore:   # (channels dropped by a SpatialDropout: see capture)
+            diff = tot = 0
+            for x, y, ign in zip(va, vb, ignore):
+                ne = x != y
+                if ign is not None:
+                    ne = ne[~ign]
+                    tot += int((~ign).sum()) * int(x[0].size)
+                else:
+                    tot += x.size
+                diff += int(ne.sum())
+            res[k] = (diff, tot)
+            continue
         res[k] = (int(sum((x != y).sum() for x, y in zip(va, vb))), int(sum(x.size for x in va)))
     return res
 

@@ -496,10 +496,13 @@ def test_fused_activation_backward_equals_unfused(F, setup, monkeypatch):
     model = s["model"]
     pnet, nat = model["pnet"], model["native"]
     rng = np.random.RandomState(9)
+    # (both passes dense: leaving out the dropped channels -- option drop_compact, tests/test_gpu_dropcompact.py -- needs the
+    # fused form, and its other rounding would flip a pooling winner now and then, which is not what this test compares)
     for (h, w) in ((H, W), (117, 155)):
         img = F.synthetic_image(h, w, 2)
         pnet.training()
         pnet.drop_masks = _masks(rng, model)
+        F._lib.call("frcnn_set_option", b"drop_compact", 0)
         try:
             outs = pnet.forward(img)
             deltas = [(rng.randn(*o.shape) / np.sqrt(o.numel())).astype(np.float32) for o in outs]
@@ -516,6 +519,7 @@ def test_fused_activation_backward_equals_unfused(F, setup, monkeypatch):
         finally:
             pnet.drop_masks = None
             monkeypatch.delenv("FRCNN_FUSE_ACT", raising=False)
+            F._lib.call("frcnn_set_option", b"drop_compact", 1)
         assert np.abs(res["1"][:nat.pnet_params]).max() > 0
         _compare_gradient(nat, res["1"], res["0"], 0, nat.pnet_params, tol_l2=1e-5, elementwise=False)
 
@@ -670,6 +674,7 @@ def test_deterministic_mode_is_bit_reproducible(F, setup):
     model["pnet"].drop_masks = _masks(rng, model)
     model["cnet"].drop_masks = [(rng.rand(R, 1024) > 0.5).astype(np.float32), (rng.rand(R, 512) > 0.5).astype(np.float32)]
     runs = {}
+    F._lib.call("frcnn_set_option", b"drop_compact", 0)   # (the deterministic pass is dense; "default" is compared with it to rounding)
     try:
         for tag, det in (("det_a", 1), ("det_b", 1), ("default", 0)):
             F._lib.call("frcnn_set_option", b"deterministic", det)
@@ -685,6 +690,7 @@ def test_deterministic_mode_is_bit_reproducible(F, setup):
             nat.bn_running.copy_(torch.from_numpy(bn0))
     finally:
         F._lib.call("frcnn_set_option", b"deterministic", 0)
+        F._lib.call("frcnn_set_option", b"drop_compact", 1)
         model["pnet"].drop_masks = None
         model["cnet"].drop_masks = None
         s["weights"].copy_(w0)

@@ -18,6 +18,12 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, pad)
     "L1c2": (64, 600, 1000, 64, 3, 1), "L2c1": (64, 300, 500, 128, 3, 1), "L2c2": (128, 300, 500, 128, 3, 1),
     "L3c1": (128, 150, 250, 256, 3, 1), "L3c2": (256, 150, 250, 256, 3, 1), "L4c1": (256, 75, 125, 512, 3, 1),
     "L4c2": (512, 75, 125, 512, 3, 1),
+    # a step's shapes behind SpatialDropout(0.4) with the dropped channels left out (k: as the K dimension, multiples of 16; m: as
+    # filters / a 64-channel tile dimension, multiples of 64)
+    "b2c2k": (80, 225, 400, 128, 3, 1), "b3c2k": (160, 113, 200, 256, 3, 1), "b4c2k": (240, 57, 100, 384, 3, 1),
+    "b2c1k": (64, 225, 400, 80, 3, 1), "b3c1k": (128, 113, 200, 160, 3, 1), "b4c1k": (256, 57, 100, 240, 3, 1),
+    "b3c1m": (128, 113, 200, 192, 3, 1), "b4c1m": (256, 57, 100, 256, 3, 1),
+    "b3c2m": (192, 113, 200, 256, 3, 1), "b4c2m": (256, 57, 100, 384, 3, 1),
     "bigk": (2048, 57, 100, 384, 3, 1), "a3": (384, 29, 50, 256, 5, 0), "a4": (384, 29, 50, 256, 7, 0), "a1x": (256, 55, 98, 18, 1, 0),
 }
 
@@ -66,6 +72,6 @@ def run(kind, name, reps=5):
 
 if __name__ == "__main__":
     kind = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
-    names = sys.argv[2:] or [n for n in LAYERS if not n.startswith("L")]
+    names = sys.argv[2:] or [n for n in LAYERS if not n.startswith("L") and not n[-1] in "km"]
     for n in names:
         run(kind, n)
