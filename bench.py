@@ -21,8 +21,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), carrying
   "other_legs"   -- BASELINE config 2 (Detector:detect, images/sec, with its own roofline / glue-time split) and nms()
                     alone at n = 300 ... 26 544, each with its CPU-restatement time and its id parity, BASELINE
                     config 5's one-GPU workload (vgg_large), and the headline workload in the two other arithmetic forms
-                    (exact_split: three bf16 planes, 24 bits; fp32_mfma: plain fp32 matrix-core products), measured after
-                    the timed region;
+                    (exact_split: three bf16 planes, 24 bits; fp32_mfma: plain fp32 matrix-core products) and with option
+                    drop_compact off (dense_dropout: the channels nn.SpatialDropout zeroes are multiplied out), measured
+                    after the timed region;
   "sustained"    -- the same metric over >= 12 s of back-to-back steps (~5 000; steady clocks, visible to an SMI sampler; not `value`);
   "roofline_hbm" -- the HBM-bound kernel classes of the step (RMSprop, ROI pooling, element-wise passes): algorithmic
                     bytes / HIP-event time against the 8 TB/s peak.
@@ -420,6 +421,16 @@ def dtype_text(F):
     if f16:
         return "f32 (conv / Linear(13824,1024) operands as 2 x fp16 split planes: 22 significand bits, 3 MFMA partial products; fp32 accumulate)"
     return "f32 (conv operands as 3 x bf16 split planes: 24 significand bits, 6 MFMA partial products; fp32 accumulate)"
+
+
+def dropout_text(F):
+    """What the pass does with the channels nn.SpatialDropout(0.4) drops (option drop_compact, include/frcnn_hip.h)."""
+    v = C.c_int(0)
+    F._lib.call("frcnn_get_option", b"drop_compact", C.byref(v))
+    return ("drop_compact = 1: the channels nn.SpatialDropout (models/model_utilities.lua:10-12) zeroes are left out of the step's "
+            "convolutions (same results as multiplying by the zeros; the roofline counts the FLOPs of the launches as run); "
+            "other_legs.dense_dropout times the step with the option off" if v.value else
+            "drop_compact = 0: the convolutions multiply the zeros of nn.SpatialDropout like the reference does")
 
 
 def arithmetic_leg(F, name, options, steps=20):
@@ -909,9 +920,11 @@ def main():
                                  % (W, H, "duplo" if args.model == "vgg_small" else "imagenet"),
                         with_h2d_upload=upload_leg,
                         images_per_gpu_per_step=1,
+                        dropout=dropout_text(F),
                         examples_per_image=[len(b["positive"]) + len(b["negative"]) for b in it.pool], global_batch=world, parallelism="dp%d" % world,
-                        conv_gflop_per_image=round(train_flops / 1e9, 2),
-                        whole_step_conv_tflops=round(train_flops / 1e12 / (dt / args.steps), 2),
+                        conv_gflop_per_image=round(train_flops / 1e9, 2),   # (the dense algorithm: every channel multiplied out)
+                        conv_gflop_per_image_as_run=round(sum(fl[F._lib.KC_NAMES.index(n)] for n in CONV_CLASSES) / 1e9 / sampled, 2),
+                        whole_step_conv_tflops=round(sum(fl[F._lib.KC_NAMES.index(n)] for n in CONV_CLASSES) / 1e12 / sampled / (dt / args.steps), 2),
                         conv_kernel_ms_per_step=round(conv_ms, 3), kernel_classes=classes,
                         kernel_classes_serial_pass=iso_classes,
                         last_loss=stats["pcls"][-1] + stats["preg"][-1] if stats["pcls"] else None),
@@ -979,7 +992,9 @@ def main():
                                          vgg_large=large_leg(F, True),
                                          # the same workload in the two other arithmetic forms (each priced against its own peak)
                                          exact_split=arithmetic_leg(F, "exact_split", dict(x3_f16=0)),
-                                         fp32_mfma=arithmetic_leg(F, "fp32_mfma", dict(split_bf16=0)))
+                                         fp32_mfma=arithmetic_leg(F, "fp32_mfma", dict(split_bf16=0)),
+                                         # ... and with the dropped channels of nn.SpatialDropout multiplied out like the reference does
+                                         dense_dropout=arithmetic_leg(F, "dense_dropout", dict(drop_compact=0)))
                 ok = ok and all(r["ids_identical"] for r in out["other_legs"]["nms"]) \
                     and out["other_legs"]["inference"]["parity"]["nms_ids_identical_on_gpu_boxes"] \
                     and out["other_legs"]["vgg_large"]["parity"]["ok"]

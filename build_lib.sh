@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unuse
 X3FLAGS="-fno-slp-vectorize -save-temps=obj"
 mkdir -p ../build
 pids=(); names=()
-for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip image.hip convx.hip wgradx.hip gemmx.hip detect.hip api.cpp net.cpp anchors.cpp comm.cpp; do
+for f in conv.hip elem.hip gemm.hip roi.hip rpn.hip nms.hip cnet.hip image.hip convx.hip wgradx.hip gemmx.hip detect.hip heads.hip api.cpp net.cpp anchors.cpp comm.cpp; do
   o=../build/${f%.*}.o
   if [ "$FORCE" = "1" ] || [ ! -f $o ] || [ $f -nt $o ] || [ kernels.h -nt $o ] || [ common.h -nt $o ] || [ amax.h -nt $o ] || [ ../../include/frcnn_hip.h -nt $o ]; then
     case $f in *.cpp) X="-x hip";; convx.hip|wgradx.hip) X="$X3FLAGS";; *) X="";; esac
@@ -29,6 +29,6 @@ for b in convx wgradx; do
 done
 python3 ../../tools/x3_isa_check.py ../build/isa/convx.s ../build/isa/wgradx.s \
   || { echo "build_lib.sh: error: the split kernels' ISA check failed" >&2; exit 1; }
-OBJS=""; for f in conv elem gemm roi rpn nms cnet image convx wgradx gemmx detect api net anchors comm; do OBJS="$OBJS ../build/$f.o"; done
+OBJS=""; for f in conv elem gemm roi rpn nms cnet image convx wgradx gemmx detect heads api net anchors comm; do OBJS="$OBJS ../build/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT || { echo "build_lib.sh: error: link failed" >&2; exit 1; }
 echo "built $OUT"

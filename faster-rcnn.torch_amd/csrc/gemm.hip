@@ -18,6 +18,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GBK 32
 #endif
 
+struct GemmGroup { GemmJob job[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int tm[GEMM_GROUP_MAX], tn[GEMM_GROUP_MAX]; int n; };
+
 struct GemmArgs {
   const float* A; long sAm, sAk;
   const float* B; long sBk, sBn;
@@ -118,16 +120,15 @@ struct TileLoader {
   }
 };
 
-// Block tile TM x TN (64 or 128 each), 2x2 waves, wave tile (TM/2) x (TN/2) of 32x32 MFMA tiles.
+// Block tile TM x TN (64 or 128 each), 2x2 waves, wave tile (TM/2) x (TN/2) of 32x32 MFMA tiles.  (bx, by, bz) = the block's
+// column tile, row tile and K split: blockIdx for a launch of ONE product, decoded from a job table for a grouped launch.
 template <int TM, int TN, bool AK, bool BK_, bool AV, bool BV>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, int bx, int by, int bz, float* As, float* Bs) {
   constexpr int PA = TM + 1, PB = TN + 1, MT = TM / 64, NT = TN / 64;
-  __shared__ float As[GBK * PA];
-  __shared__ float Bs[GBK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, li = lane & 31;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int kbeg = blockIdx.z * p.kPerSplit;
+  const int m0 = by * TM, n0 = bx * TN;
+  const int kbeg = bz * p.kPerSplit;
   const int kend = min(kbeg + p.kPerSplit, p.K);
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -164,8 +165,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int n = n0 + wn * (TN / 2) + j * 32 + li;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      gemm_store_tile(acc[i][j], p, m0 + wm * (TM / 2) + i * 32 + 4 * h, n, (int)blockIdx.z);
+      gemm_store_tile(acc[i][j], p, m0 + wm * (TM / 2) + i * 32 + 4 * h, n, bz);
   }
+}
+
+template <int TM, int TN, bool AK, bool BK_, bool AV, bool BV>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  __shared__ float As[GBK * (TM + 1)];
+  __shared__ float Bs[GBK * (TN + 1)];
+  gemm_tile<TM, TN, AK, BK_, AV, BV>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Several independent products in ONE launch (the anchor nets' sparse training path, net.cpp): job j owns the blocks
+// start[j] .. start[j + 1], numbered column tile fastest, then row tile, then K split.  64 x 64 tiles, scalar loads (the
+// operands sit at any offset of the flat parameter vector); every job of a launch has the same operand orientations.
+template <bool AK, bool BK_>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup g) {
+  __shared__ float As[GBK * (GB + 1)];
+  __shared__ float Bs[GBK * (GB + 1)];
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.start[j + 1]) ++j;
+  const int b = blockIdx.x - g.start[j];
+  const int tiles = g.tn[j] * g.tm[j];
+  const int bz = b / tiles, r = b - bz * tiles;
+  GemmArgs p;
+  const GemmJob& q = g.job[j];
+  p.A = q.A; p.sAm = q.sAm; p.sAk = q.sAk; p.B = q.B; p.sBk = q.sBk; p.sBn = q.sBn; p.C = q.C; p.ldc = q.ldc; p.bias = nullptr;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.kPerSplit = q.kPerSplit; p.out_mode = q.out_mode;
+  gemm_tile<GB, GB, AK, BK_, false, false>(p, r % g.tn[j], r / g.tn[j], bz, As, Bs);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -452,6 +479,40 @@ int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long 
     FR_LAUNCH(KC_ELEMWISE, 0, total * 4.0 * (splitK + 1), s, gemm_reduce_kernel, dim3(rgrid), dim3(256), 0, (const float*)p.C,
               splitK, M, N, bias_n, user_C, ldc, out_mode == OUT_ADD ? 1 : 0);
   }
+  FR_LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// Grouped launch (see gemm_group_kernel).  A job with splits > 1 writes [split][M][N] partial-sum slabs to its C (out_mode is
+// ignored: the caller folds them); otherwise C (=|+=) the product.
+int gemm_f32_group(GemmJob* jobs, int n, hipStream_t s) {
+  FR_CHECK(n >= 1 && n <= GEMM_GROUP_MAX, "gemm_f32_group: %d jobs", n);
+  GemmGroup g;
+  g.n = n;
+  int at = 0;
+  double flops = 0, bytes = 0;
+  const bool ak = jobs[0].sAk == 1, bk = jobs[0].sBk == 1;
+  for (int j = 0; j < n; ++j) {
+    GemmJob& q = jobs[j];
+    // (the orientation flags only choose which index runs along a wave's lanes when a tile is loaded -- the addresses use the
+    // strides -- so a job whose unit stride is an accident of a dimension of 1 is still computed correctly under job 0's flags)
+    const int splits = std::max(1, q.splits);
+    q.kPerSplit = cdiv(cdiv(q.K, splits), GBK) * GBK;
+    const int ns = (q.M > 0 && q.N > 0) ? cdiv(q.K, q.kPerSplit) : 0;
+    if (splits > 1) { FR_CHECK(ns == splits, "gemm_f32_group: %d splits of K = %d leave one empty", splits, q.K); q.out_mode = 3; }
+    g.job[j] = q;
+    g.tm[j] = cdiv(q.M, GB); g.tn[j] = cdiv(q.N, GB);
+    g.start[j] = at;
+    at += g.tm[j] * g.tn[j] * ns;
+    flops += 2.0 * q.M * q.N * (double)q.K;
+    bytes += 4.0 * ((double)q.M * q.K + (double)q.K * q.N + (double)q.M * q.N);
+  }
+  g.start[n] = at;
+  if (at == 0) return FRCNN_OK;
+  if (ak && bk) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_group_kernel<true, true>), dim3(at), dim3(256), 0, g);
+  else if (ak) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_group_kernel<true, false>), dim3(at), dim3(256), 0, g);
+  else if (bk) FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_group_kernel<false, true>), dim3(at), dim3(256), 0, g);
+  else FR_LAUNCH(KC_GEMM, flops, bytes, s, (gemm_group_kernel<false, false>), dim3(at), dim3(256), 0, g);
   FR_LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -159,9 +159,38 @@ int rmsprop_step(float* x, float* g, float* m, long n, float lr, float alpha, fl
 int rmsprop_slice(float* x, float* g, float* m, long lo, long hi, float lr, float alpha, float eps, float gscale, bool scale_first,
                   hipStream_t s);
 
+// ---------------------------------------------------------------- anchor nets, sampled positions only (heads.hip)
+#define FRCNN_HEAD_OUT 18   // 3 * (2 + 4) planes of an anchor net's 1 x 1 convolution (model_utilities.lua:33)
+struct HeadJob {
+  int Cin, H, W, k, Ho, Wo, n;         // input map, kernel size, output map of the k x k valid convolution, its filters
+  int P; const int* pos;               // sampled positions (y * Wo + x), device
+  const float* in; float* gin;         // the input map and its gradient
+  const float *bias3, *slope, *bias1;  // parameters: k x k bias, PReLU slope, 1 x 1 bias
+  float *gbias3, *gslope, *gbias1;     // ... their gradients
+  float* out; const float* delta;      // the 1 x 1 convolution's output map [18][Ho Wo] and its gradient map
+  float *COL, *HX, *HY, *OUT, *D, *GH, *DX;   // scratch: [P][ckk], [n][P], [n][P], [18][P], [18][P], [n][P], [P][ckk]
+  const float* hx_slab; int hx_splits; // partial sums of HX over K splits, [split][n][P]
+};
+struct HeadJobs { HeadJob j[4]; int n; };
+int heads_im2col(const HeadJobs& g, hipStream_t s);
+int heads_bias_act(const HeadJobs& g, hipStream_t s);
+int heads_scatter(const HeadJobs& g, hipStream_t s);
+int heads_gather_delta(const HeadJobs& g, hipStream_t s);
+int heads_act_backward(const HeadJobs& g, hipStream_t s);
+int heads_col2im(const HeadJobs& g, hipStream_t s);
+
 // ---------------------------------------------------------------- gemm (gemm.hip)
 // C[M][N] (=|+=) A[M][K] * B[K][N] with explicit element strides.  defer: see GemmFold below.
 struct GemmFold;
+// several independent fp32 products in one launch (gemm.hip gemm_group_kernel): C[M][N] (=|+=) A * B with explicit strides
+#define GEMM_GROUP_MAX 4
+struct GemmJob {
+  const float* A; long sAm, sAk; const float* B; long sBk, sBn; float* C; long ldc;
+  int M, N, K, out_mode;   // OUT_STORE | OUT_ADD
+  int splits = 1;          // > 1: C receives [split][M][N] partial sums over K instead (the caller folds them)
+  int kPerSplit = 0;       // (set by the launcher)
+};
+int gemm_f32_group(GemmJob* jobs, int n, hipStream_t s);
 int gemm_f32(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C,
              long ldc, int M, int N, int K, int out_mode, const float* bias_n, hipStream_t s, int ws_slot = 0,
              GemmFold* defer = nullptr);

@@ -82,6 +82,7 @@ struct Head {
   const int* sp_pos = nullptr; // optional one-shot hint: delta is zero outside these positions
   int sp_count = -1;
   DevBuf spD, spHX, spHY, spGH, spCol, spDX;  // scratch of the sparse backward pass (per anchor net: they run concurrently)
+  DevBuf spOut, spSlab;       // sparse training path (heads.hip): the 18 output planes at the sampled positions; K-split partial sums of HX
   hipStream_t stream = nullptr;  // this anchor net's own stream (forward and sparse backward beside the other anchor nets)
   hipEvent_t done = nullptr;     // last work queued on `stream`
   hipEvent_t gin_done = nullptr; // sparse backward: this net's contribution to the pooled map's gradient has been added (the
@@ -113,6 +114,23 @@ static int g_drop_compact = -1;   // option "drop_compact" (environment FRCNN_DR
 static int drop_compact_on() {
   if (g_drop_compact < 0) g_drop_compact = getenv("FRCNN_DROP_COMPACT") ? (atoi(getenv("FRCNN_DROP_COMPACT")) != 0) : 1;
   return g_drop_compact;
+}
+// The library's streams are the PROCESS's, not a model's: the runtime multiplexes every stream onto four hardware queues
+// (GPU_MAX_HW_QUEUES; five or more run this step 1.6x slower, tools/r6_hwq.sh), two streams on one queue serialise, and a second
+// model with six streams of its own (bench.py's legs, a training and an evaluation model side by side) made both slower.
+// Slot 0: the side stream (weight gradients), 1: the classification net's weight gradients / the update stream, 2..6: anchor nets.
+static int pool_stream(int slot, hipStream_t* out) {
+  static hipStream_t pool[8] = {};
+  if (!pool[slot]) FR_HIP(hipStreamCreateWithFlags(&pool[slot], hipStreamNonBlocking));
+  *out = pool[slot];
+  return FRCNN_OK;
+}
+
+// ---- the anchor nets' sparse training path (heads.hip) ---------------------------------------------------------------------
+static int g_sparse_heads = -1;   // option "sparse_heads" (environment FRCNN_SPARSE_HEADS), default on
+static int sparse_heads_on() {
+  if (g_sparse_heads < 0) g_sparse_heads = getenv("FRCNN_SPARSE_HEADS") ? (atoi(getenv("FRCNN_SPARSE_HEADS")) != 0) : 1;
+  return g_sparse_heads;
 }
 static int g_static_weights = 0;   // option "static_weights" (see forward_impl)
 static long g_static_gen = 0;      // bumped by every set_option("static_weights", v)
@@ -171,6 +189,12 @@ struct frcnn_model {
   hipEvent_t join_ev = nullptr;
   hipEvent_t bwd_ev = nullptr;     // the backbone's backward pass has begun on the caller's stream (anchor nets joined)
   hipEvent_t upd_ev = nullptr, upd_join_ev = nullptr;   // fork / join points of the update stream (frcnn_model_update_*)
+  bool heads_deferred = false;     // training pass: the anchor nets' forward part has not been launched yet (frcnn_pnet_forward_async_heads
+                                   // leaves it to the call that knows the sampled positions: heads.hip)
+  bool heads_sparse_fwd = false;   // ... and was then computed at the sampled positions only
+  const float* last_w = nullptr;   // weight vector of the last forward pass
+  hipEvent_t heads_gin_ev = nullptr;   // sparse path: the anchor nets' contributions to the pooled maps' gradients have been added (side stream)
+  bool heads_gin = false;
   bool heads_begun = false;        // anchor-net backward already running on the side stream
   bool heads_joined = false;       // ... and the caller's stream already waits for it
   bool side_busy = false;          // work was forked to the side stream and not joined yet
@@ -548,7 +572,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   if (m->dc_pin) (void)hipHostFree(m->dc_pin);
   m->dc_dev.release(); m->dbg_expand.release();
   for (auto& h : m->heads) {
-    rel(h.c3); rel(h.c1); h.delta.release();
+    rel(h.c3); rel(h.c1); h.delta.release(); h.spOut.release(); h.spSlab.release();
     h.spD.release(); h.spHX.release(); h.spHY.release(); h.spGH.release(); h.spCol.release(); h.spDX.release();
   }
   for (auto& l : m->cls) {
@@ -560,21 +584,19 @@ int frcnn_model_destroy(frcnn_model* m) {
   for (auto& h : m->heads) {
     if (h.done) (void)hipEventDestroy(h.done);
     if (h.gin_done) (void)hipEventDestroy(h.gin_done);
-    if (h.stream) (void)hipStreamDestroy(h.stream);
   }
   if (m->chain_ev) (void)hipEventDestroy(m->chain_ev);
   if (m->join_ev) (void)hipEventDestroy(m->join_ev);
   if (m->bwd_ev) (void)hipEventDestroy(m->bwd_ev);
+  if (m->heads_gin_ev) (void)hipEventDestroy(m->heads_gin_ev);
   if (m->upd_ev) (void)hipEventDestroy(m->upd_ev);
   if (m->upd_join_ev) (void)hipEventDestroy(m->upd_join_ev);
   for (auto e : m->block_rd_ev) (void)hipEventDestroy(e);
   for (auto e : m->cw_ev) (void)hipEventDestroy(e);
   if (m->cw_fork) (void)hipEventDestroy(m->cw_fork);
   if (m->cw_done) (void)hipEventDestroy(m->cw_done);
-  if (m->cw) (void)hipStreamDestroy(m->cw);
   if (m->loss_ev) (void)hipEventDestroy(m->loss_ev);
   for (auto e : m->block_ev) (void)hipEventDestroy(e);
-  if (m->side) (void)hipStreamDestroy(m->side);
   m->delta_last.release(); m->feat_g.release(); m->logits.release(); m->lsm.release(); m->glog.release();
   m->gtmp.release();
   delete m;
@@ -648,7 +670,7 @@ int frcnn_cnet_backward_join(frcnn_model* m, void* stream) {
 // slice update queued on it is ordered behind those gradients by itself.
 static int ensure_update_stream(frcnn_model* m) {
   if (!m->cw) {
-    FR_HIP(hipStreamCreateWithFlags(&m->cw, hipStreamNonBlocking));
+    FR_TRY(pool_stream(1, &m->cw));
     FR_HIP(hipEventCreateWithFlags(&m->cw_done, hipEventDisableTiming));
   }
   if (!m->upd_ev) FR_HIP(hipEventCreateWithFlags(&m->upd_ev, hipEventDisableTiming));
@@ -685,6 +707,7 @@ int frcnn_get_option(const char* name, int* value) {
   if (strcmp(name, "deterministic") == 0) { *value = deterministic() ? 1 : 0; return FRCNN_OK; }
   if (strcmp(name, "static_weights") == 0) { *value = g_static_weights; return FRCNN_OK; }
   if (strcmp(name, "drop_compact") == 0) { *value = drop_compact_on(); return FRCNN_OK; }
+  if (strcmp(name, "sparse_heads") == 0) { *value = sparse_heads_on(); return FRCNN_OK; }
   if (strcmp(name, "winograd") == 0) { *value = 0; return FRCNN_OK; }   // removed in round 3; kept as a name that reads 0
   if (strcmp(name, "cnet_wgrad_async") == 0) { *value = g_cnet_wgrad_async; return FRCNN_OK; }
   if (strcmp(name, "split_bf16") == 0) { *value = get_split_bf16(); return FRCNN_OK; }
@@ -699,6 +722,7 @@ int frcnn_set_option(const char* name, int value) {
   if (strcmp(name, "deterministic") == 0) { set_deterministic(value != 0); return FRCNN_OK; }
   if (strcmp(name, "static_weights") == 0) { g_static_weights = value != 0; ++g_static_gen; return FRCNN_OK; }
   if (strcmp(name, "drop_compact") == 0) { g_drop_compact = value != 0; return FRCNN_OK; }
+  if (strcmp(name, "sparse_heads") == 0) { g_sparse_heads = value != 0; return FRCNN_OK; }
   if (strcmp(name, "gemm_x_roles") == 0) { set_gemm_x_roles(value); return FRCNN_OK; }   // takes effect at the next cnet pass
   if (strcmp(name, "split_bf16") == 0) { set_split_bf16(value); return FRCNN_OK; }   // takes effect for models shaped afterwards
   if (strcmp(name, "x3_f16") == 0) { set_x3_f16(value); return FRCNN_OK; }           // takes effect with the next forward pass
@@ -710,7 +734,7 @@ int frcnn_set_option(const char* name, int value) {
 
 static int ensure_side(frcnn_model* m) {
   if (!m->side) {
-    FR_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    FR_TRY(pool_stream(0, &m->side));
     FR_HIP(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&m->loss_ev, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&m->chain_ev, hipEventDisableTiming));
@@ -726,7 +750,7 @@ static int ensure_side(frcnn_model* m) {
     size_t hi = 0;
     for (auto& h : m->heads) {
       // (five workspace slots for streams of their own, head_slot(): a sixth anchor net shares the side stream and its slot)
-      if (head_streams && hi++ < 5) FR_HIP(hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+      if (head_streams && hi < 5) { FR_TRY(pool_stream(2 + (int)hi, &h.stream)); ++hi; }
       FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
     }
   }
@@ -909,6 +933,10 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
   m->heads_begun = false; m->heads_joined = false; m->loss_pending = false;
   const bool use_side = side_enabled();
   async_heads = async_heads && use_side && training;
+  // training through the objective: the anchor nets wait for the call that knows the sampled positions (heads.hip)
+  m->heads_deferred = async_heads && sparse_heads_on() && !deterministic() && m->heads.size() <= 4;
+  m->heads_sparse_fwd = false; m->heads_gin = false;
+  m->last_w = w;
   // SpatialDropout scales (device-drawn ones: one launch for all blocks)
   DropoutJobs dj;
   dj.n = 0;
@@ -1005,7 +1033,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     cur_scale = nullptr;
     cur_am = f16 ? m->rec(blk.am) : nullptr;   // the pooled map feeds the next block and the anchor nets on it
     // anchor nets on an earlier block's map run beside the following blocks, each on its own stream
-    if (use_side && b + 1 < m->blocks.size()) {
+    if (use_side && b + 1 < m->blocks.size() && !m->heads_deferred) {
       FR_TRY(ensure_side(m));
       for (size_t i = 0; i < m->heads.size(); ++i) {
         Head& h = m->heads[i];
@@ -1016,7 +1044,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     }
   }
   // heads on the LAST block's map: the heaviest stays on the caller's stream, the others run beside it
-  {
+  if (!m->heads_deferred) {
     const int last = (int)m->blocks.size() - 1;
     int heavy = -1;
     for (size_t i = 0; i < m->heads.size(); ++i)
@@ -1090,6 +1118,12 @@ int frcnn_model_debug_buffer(frcnn_model* m, int kind, int index, void** ptr, lo
     case 2: {
       FR_CHECK(index >= 0 && index < (int)m->heads.size() && m->H > 0, "debug_buffer: anchor net %d (after a forward pass)", index);
       const Conv& c = m->heads[index].c3; b = &c.x; n = (size_t)c.Cout * c.Ho * c.Wo * 4;
+      if ((m->heads_sparse_fwd || m->heads_deferred) && m->last_w) {
+        // the training pass computed this map at the sampled positions only (heads.hip), or not yet: the dense convolution, now
+        FR_HIP(hipDeviceSynchronize());
+        FR_TRY(head_forward(m, m->heads[index], m->last_w, nullptr, 0));
+        FR_HIP(hipDeviceSynchronize());
+      }
     } break;
     case 3: {
       FR_CHECK(index >= 0 && index < (int)m->cls.size() && m->R > 0, "debug_buffer: classification layer %d (after frcnn_cnet_forward)", index);
@@ -1223,10 +1257,127 @@ static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
   return FRCNN_OK;
 }
 
+// The forward part a training pass deferred (frcnn_model::heads_deferred), as the dense convolutions after all: every anchor net
+// on its own stream behind everything queued on `s` (the pooled maps are final there).
+static int heads_forward_dense(frcnn_model* m, const float* w, hipStream_t s) {
+  FR_TRY(ensure_side(m));
+  for (size_t i = 0; i < m->heads.size(); ++i) {
+    FR_TRY(fork_to(m, s, head_stream(m, i), 16 + i));
+    FR_TRY(head_forward(m, m->heads[i], w, head_stream(m, i), head_slot(m, i)));
+  }
+  m->heads_deferred = false;
+  return FRCNN_OK;
+}
+
+static bool heads_all_sparse(const frcnn_model* m) {
+  for (auto& h : m->heads) if (!head_is_sparse(h)) return false;
+  return !m->heads.empty() && m->heads.size() <= 4;
+}
+
+// The job table of the sparse path: the anchor nets that have sampled positions in this pass
+static int heads_jobs(frcnn_model* m, const float* w, float* grad, HeadJobs& g) {
+  g.n = 0;
+  for (auto& h : m->heads) {
+    const int P = h.sp_count;
+    if (P <= 0) continue;
+    Block& in = m->blocks[h.input];
+    Conv &a = h.c3, &c = h.c1;
+    const size_t n = (size_t)a.Cout, ckk = (size_t)a.Cin * a.k * a.k, cap = SPARSE_MAX_POS;
+    FR_TRY(h.spD.ensure((size_t)HEAD_OUT * cap * 4)); FR_TRY(h.spOut.ensure((size_t)HEAD_OUT * cap * 4));
+    FR_TRY(h.spHX.ensure(n * cap * 4)); FR_TRY(h.spHY.ensure(n * cap * 4)); FR_TRY(h.spGH.ensure(n * cap * 4));
+    FR_TRY(h.spCol.ensure(ckk * cap * 4)); FR_TRY(h.spDX.ensure(ckk * cap * 4));
+    HeadJob& j = g.j[g.n++];
+    j.Cin = a.Cin; j.H = a.H; j.W = a.W; j.k = a.k; j.Ho = a.Ho; j.Wo = a.Wo; j.n = a.Cout;
+    j.P = P; j.pos = h.sp_pos;
+    j.in = in.pooled.f(); j.gin = in.gpooled.f();
+    j.bias3 = w + a.b_off; j.slope = w + a.a_off; j.bias1 = w + c.b_off;
+    j.gbias3 = grad ? grad + a.b_off : nullptr; j.gslope = grad ? grad + a.a_off : nullptr; j.gbias1 = grad ? grad + c.b_off : nullptr;
+    j.out = c.x.f(); j.delta = h.delta.f();
+    j.COL = h.spCol.f(); j.HX = h.spHX.f(); j.HY = h.spHY.f(); j.OUT = h.spOut.f(); j.D = h.spD.f(); j.GH = h.spGH.f(); j.DX = h.spDX.f();
+    // K splits of HX = W COL^T: K = ckk is long, the tile grid (n / 64) x (P / 64) small -- about a thousand blocks in all
+    const long tiles = (long)cdiv((int)n, 64) * cdiv(P, 64);
+    int splits = (int)std::max<long>(1, std::min<long>(std::min<long>((long)ckk / 256, 64), 256 / tiles));
+    const int per = cdiv(cdiv((int)ckk, splits), 32) * 32;
+    splits = cdiv((int)ckk, per);
+    FR_TRY(h.spSlab.ensure((size_t)splits * n * P * 4));
+    j.hx_slab = h.spSlab.f(); j.hx_splits = splits;
+  }
+  return FRCNN_OK;
+}
+
+// forward at the sampled positions: the output maps are written THERE only (objective.lua:91-140 reads nothing else)
+static int heads_sparse_forward(frcnn_model* m, const float* w, const HeadJobs& g, hipStream_t s) {
+  if (g.n == 0) return FRCNN_OK;
+  FR_TRY(heads_im2col(g, s));
+  GemmJob q[4];
+  for (int i = 0; i < g.n; ++i) {   // HX[n][P] = W[n][ckk] COL[P][ckk]^T, K-split partial sums
+    const HeadJob& j = g.j[i];
+    const Head* hd = nullptr;
+    for (auto& h : m->heads) if (h.spCol.f() == j.COL) hd = &h;
+    const int ckk = j.Cin * j.k * j.k;
+    q[i] = GemmJob{w + hd->c3.w_off, (long)ckk, 1, j.COL, 1, (long)ckk, const_cast<float*>(j.hx_slab), (long)j.P, j.n, j.P, ckk, OUT_STORE, j.hx_splits};
+    if (j.hx_splits == 1) q[i].splits = 1;
+  }
+  // (a single split still goes through the slab: heads_bias_act folds `hx_splits` of them)
+  for (int i = 0; i < g.n; ++i) if (q[i].splits == 1) { q[i].out_mode = OUT_STORE; }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  FR_TRY(heads_bias_act(g, s));
+  for (int i = 0; i < g.n; ++i) {   // OUT[18][P] = W1[18][n] HY[n][P]
+    const HeadJob& j = g.j[i];
+    const Head* hd = nullptr;
+    for (auto& h : m->heads) if (h.spCol.f() == j.COL) hd = &h;
+    q[i] = GemmJob{w + hd->c1.w_off, (long)j.n, 1, j.HY, (long)j.P, 1, j.OUT, (long)j.P, HEAD_OUT, j.P, j.n, OUT_STORE, 1};
+  }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  FR_TRY(heads_scatter(g, s));
+  return FRCNN_OK;
+}
+
+// backward at the sampled positions (the arithmetic of backward_head's sparse branch; HX, HY and COL are the forward pass's)
+static int heads_sparse_backward(frcnn_model* m, const float* w, float* grad, const HeadJobs& g, hipStream_t s) {
+  if (g.n == 0) return FRCNN_OK;
+  auto head_of = [&](const HeadJob& j) -> const Head* {
+    for (auto& h : m->heads) if (h.spCol.f() == j.COL) return &h;
+    return nullptr;
+  };
+  FR_TRY(heads_gather_delta(g, s));                    // D, gb1
+  GemmJob q[4];
+  for (int i = 0; i < g.n; ++i) {                      // GH[n][P] = W1^T[n][18] D[18][P]
+    const HeadJob& j = g.j[i]; const Head* hd = head_of(j);
+    q[i] = GemmJob{w + hd->c1.w_off, 1, (long)j.n, j.D, (long)j.P, 1, j.GH, (long)j.P, j.n, j.P, HEAD_OUT, OUT_STORE, 1};
+  }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  FR_TRY(heads_act_backward(g, s));                    // PReLU backward, gb3, gslope
+  for (int i = 0; i < g.n; ++i) {                      // DX[P][ckk] = GH^T[P][n] W[n][ckk]
+    const HeadJob& j = g.j[i]; const Head* hd = head_of(j);
+    const int ckk = j.Cin * j.k * j.k;
+    q[i] = GemmJob{j.GH, 1, (long)j.P, w + hd->c3.w_off, (long)ckk, 1, j.DX, (long)ckk, j.P, ckk, j.n, OUT_STORE, 1};
+  }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  FR_TRY(heads_col2im(g, s));                          // the pooled maps' gradients
+  if (!m->heads_gin_ev) FR_HIP(hipEventCreateWithFlags(&m->heads_gin_ev, hipEventDisableTiming));
+  FR_HIP(hipEventRecord(m->heads_gin_ev, s));          // what the backbone's backward pass waits for; the parameter gradients follow
+  m->heads_gin = true;
+  for (int i = 0; i < g.n; ++i) {                      // gW1[18][n] += D[18][P] HY[n][P]^T
+    const HeadJob& j = g.j[i]; const Head* hd = head_of(j);
+    q[i] = GemmJob{j.D, (long)j.P, 1, j.HY, 1, (long)j.P, grad + hd->c1.w_off, (long)j.n, HEAD_OUT, j.n, j.P, OUT_ADD, 1};
+  }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  for (int i = 0; i < g.n; ++i) {                      // gW[n][ckk] += GH[n][P] COL[P][ckk]
+    const HeadJob& j = g.j[i]; const Head* hd = head_of(j);
+    const int ckk = j.Cin * j.k * j.k;
+    q[i] = GemmJob{j.GH, (long)j.P, 1, j.COL, (long)ckk, 1, grad + hd->c3.w_off, (long)ckk, j.n, ckk, j.P, OUT_ADD, 1};
+  }
+  FR_TRY(gemm_f32_group(q, g.n, s));
+  for (auto& h : m->heads) { h.sp_count = -1; h.sp_pos = nullptr; }   // one-shot hints
+  return FRCNN_OK;
+}
+
 int frcnn_pnet_backward_heads_begin(frcnn_model* m, const float* w, float* grad, void* stream) {
   hipStream_t s = S(stream);
   FR_CHECK(m->H > 0 && m->training, "pnet_backward_heads_begin: needs a preceding training-mode forward");
   if (!side_enabled() || m->heads_begun) return FRCNN_OK;   // frcnn_pnet_backward does everything
+  if (m->heads_deferred) FR_TRY(heads_forward_dense(m, w, s));   // (this entry point has no sparse forward: the outputs were the caller's to read)
   FR_TRY(fork_side(m, s, m->blocks.size() + 1));             // delta_outputs[1..nheads] are final on s
   FR_TRY(join_heads(m, m->side));                            // (anchor nets of an asynchronous forward still in flight)
   FR_TRY(backward_heads_fanout(m, w, grad));
@@ -1255,6 +1406,24 @@ int frcnn_pnet_anchor_loss_begin(frcnn_model* m, const float* w, float* grad, co
     FR_TRY(loss_accumulate(ex_loss, E, acc, s));
     return FRCNN_OK;
   }
+  if (m->heads_deferred && heads_all_sparse(m)) {
+    // The sparse path (heads.hip): forward at the sampled positions, the losses, the backward part -- one chain of grouped
+    // launches on the side stream, behind everything queued on `s` (pooled maps, example tables, zeroed delta buffers)
+    HeadJobs g;
+    FR_TRY(heads_jobs(m, w, grad, g));
+    FR_TRY(fork_side(m, s, m->blocks.size() + 1));
+    FR_TRY(heads_sparse_forward(m, w, g, m->side));
+    m->heads_deferred = false; m->heads_sparse_fwd = true;
+    FR_TRY(rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, m->side));
+    FR_TRY(loss_accumulate(ex_loss, E, acc, m->side));
+    FR_HIP(hipEventRecord(m->loss_ev, m->side));
+    m->loss_pending = true;
+    FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
+    FR_TRY(heads_sparse_backward(m, w, grad, g, m->side));
+    m->heads_begun = true;
+    return FRCNN_OK;
+  }
+  if (m->heads_deferred) FR_TRY(heads_forward_dense(m, w, s));   // more positions than the sparse path takes: the dense convolutions after all
   FR_TRY(fork_side(m, s, m->blocks.size() + 1));   // example tables and zeroed delta buffers are final on s
   FR_TRY(join_heads(m, m->side));                  // the anchor nets' outputs (each on its own stream) are final
   FR_TRY(rpn_loss(L, deltas, ex_idx, ex_anchor, ex_roi, ex_class, npos, nneg, bgclass, ex_loss, crtarget, cctarget, m->side));
@@ -1303,6 +1472,10 @@ int frcnn_pnet_wait_heads_done(frcnn_model* m, void* stream) {
   FR_CHECK(m->block_ev_valid, "pnet_wait_heads_done: call frcnn_pnet_backward first");
   for (auto& h : m->heads)
     if (h.stream && h.done) FR_HIP(hipStreamWaitEvent(S(stream), h.done, 0));
+  if (m->side) {   // (the sparse training path runs the anchor nets on the side stream: everything queued there so far)
+    FR_TRY(ensure_update_stream(m));
+    FR_TRY(chain(m->side, S(stream), m->upd_ev));
+  }
   return FRCNN_OK;
 }
 
@@ -1370,8 +1543,12 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
       // What the backbone's pass needs from an anchor net is its contribution to the pooled map's gradient; a net on a stream
       // of its own marks that point (Head::gin_done) and goes on with its parameter gradients beside the backbone's pass.
       static const bool partial = !(getenv("FRCNN_HEADS_PARTIAL_JOIN") && atoi(getenv("FRCNN_HEADS_PARTIAL_JOIN")) == 0);
+      if (partial && m->heads_gin) {   // the sparse path's one chain on the side stream: its input-gradient part, the rest at the end
+        FR_HIP(hipStreamWaitEvent(s, m->heads_gin_ev, 0));
+        heads_tail = true;
+      }
       for (auto& h : m->heads) {
-        if (!h.stream) continue;
+        if (!h.stream || m->heads_gin) continue;
         if (partial && h.gin_recorded) {
           FR_HIP(hipStreamWaitEvent(s, h.gin_done, 0));
           heads_tail = true;
@@ -1380,11 +1557,19 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
           FR_HIP(hipStreamWaitEvent(s, h.done, 0));
         }
       }
-      FR_HIP(hipEventRecord(m->join_ev, m->side));
-      FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+      if (!(partial && m->heads_gin)) {
+        FR_HIP(hipEventRecord(m->join_ev, m->side));
+        FR_HIP(hipStreamWaitEvent(s, m->join_ev, 0));
+      }
     }
     m->heads_begun = false; m->heads_joined = false; m->side_busy = false;
   } else {
+    if (m->heads_deferred) {   // nobody asked for the anchor nets' outputs; their backward part below needs the forward part unless no net has a position
+      bool any = false;
+      for (auto& h : m->heads) any = any || h.sp_count != 0;
+      if (any) FR_TRY(heads_forward_dense(m, w, s));
+      m->heads_deferred = false;
+    }
     FR_TRY(join_side(m, s));   // anchor nets of frcnn_pnet_forward_async_heads still in flight (image without examples)
     FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, s));
     FR_TRY(backward_heads(m, w, grad, s, 0));
@@ -1528,7 +1713,7 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     }
   }
   m->block_ev_valid = true;
-  if (heads_tail) FR_TRY(join_heads(m, s));   // the anchor nets' parameter gradients (see above)
+  if (heads_tail && !m->heads_gin) FR_TRY(join_heads(m, s));   // the anchor nets' parameter gradients (see above; the sparse path's are on the side stream, joined below)
   FR_TRY(cw_join(m, s));   // the classification net's weight gradients (frcnn_cnet_backward) belong to the same gradient vector
   if (use_side) {   // the caller's stream continues after every weight gradient has landed
     FR_HIP(hipEventRecord(m->join_ev, ws));
@@ -1676,7 +1861,7 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
   FR_TRY(cw_join(m, s));
   const bool async = g_cnet_wgrad_async && !deterministic();
   if (async && !m->cw) {
-    FR_HIP(hipStreamCreateWithFlags(&m->cw, hipStreamNonBlocking));
+    FR_TRY(pool_stream(1, &m->cw));
     FR_HIP(hipEventCreateWithFlags(&m->cw_done, hipEventDisableTiming));
   }
   while (async && m->cw_ev.size() < m->cls.size() + 1) {
