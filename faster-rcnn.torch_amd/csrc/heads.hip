@@ -51,7 +51,15 @@ __global__ __launch_bounds__(256) void hd_bias_act_kernel(HeadJobs g) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int c = (int)(t / j.P);
     float v = j.bias3[c];
-    for (int s = 0; s < j.hx_splits; ++s) v += j.hx_slab[(size_t)s * total + t];
+    int s = 0;
+    for (; s + 7 < j.hx_splits; s += 8) {   // (eight independent loads in flight; summed in split order)
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = j.hx_slab[(size_t)(s + u) * total + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += x[u];
+    }
+    for (; s < j.hx_splits; ++s) v += j.hx_slab[(size_t)s * total + t];
     j.HX[t] = v;
     j.HY[t] = v > 0.f ? v : a * v;
   }
@@ -134,7 +142,7 @@ static int hd_grid(const HeadJobs& g, int mode) {   // blocks along x: enough fo
     const long t = mode == 0 ? (long)j.P * j.Cin * j.k * j.k : mode == 1 ? (long)j.n * j.P : (long)FRCNN_HEAD_OUT * j.P;
     most = std::max(most, t);
   }
-  return (int)std::min<long>(cdivl(most, 256), 1024);
+  return (int)std::min<long>(cdivl(most, 256), 4096);
 }
 
 int heads_im2col(const HeadJobs& g, hipStream_t s) {

@@ -189,6 +189,8 @@ struct frcnn_model {
   hipEvent_t join_ev = nullptr;
   hipEvent_t bwd_ev = nullptr;     // the backbone's backward pass has begun on the caller's stream (anchor nets joined)
   hipEvent_t upd_ev = nullptr, upd_join_ev = nullptr;   // fork / join points of the update stream (frcnn_model_update_*)
+  bool head_x3_fresh = true;       // the anchor nets' split-operand packs and weight magnitudes match the last forward pass's weights
+  int am_bb_off = 0, am_bb_n = 0, am_bb_grid = 0;   // AmaxJob sub-table: the backbone's weight tensors only
   bool heads_deferred = false;     // training pass: the anchor nets' forward part has not been launched yet (frcnn_pnet_forward_async_heads
                                    // leaves it to the call that knows the sampled positions: heads.hip)
   bool heads_sparse_fwd = false;   // ... and was then computed at the sampled positions only
@@ -214,6 +216,7 @@ struct frcnn_model {
 };
 
 static int pool_out(int n) { return (n - 2 + 1) / 2 + 1; }
+static int refresh_group(frcnn_model* m, const float* w, int group, hipStream_t s);
 
 static void build_layout(frcnn_model* m) {
   const frcnn_model_desc& d = m->d;
@@ -444,6 +447,14 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       m->n_amax_jobs = (int)aj.size();
       m->amax_grid = tensor_absmax_assign_blocks(aj.data(), m->n_amax_jobs);
       FR_CHECK(m->amax_grid >= 0, "ensure_shapes: a weight tensor is too large for its magnitude record");
+      {   // the backbone's tensors only (a training pass that leaves the anchor nets to the sparse path, heads.hip)
+        std::vector<AmaxJob> gj;
+        for (auto& c : m->convs)
+          if (c.x_f || c.x_d) gj.push_back(AmaxJob{c.w_off, (long)c.Cout * c.Cin * c.k * c.k, m->rec(c.am + 2), 0});
+        m->am_bb_off = (int)aj.size(); m->am_bb_n = (int)gj.size();
+        m->am_bb_grid = gj.empty() ? 0 : tensor_absmax_assign_blocks(gj.data(), m->am_bb_n);
+        aj.insert(aj.end(), gj.begin(), gj.end());
+      }
       for (size_t g = 0; g <= m->blocks.size(); ++g) {   // per-owner sub-tables (see frcnn_model::groups)
         std::vector<AmaxJob> gj;
         auto addg = [&](Conv& c) {
@@ -732,6 +743,7 @@ int frcnn_set_option(const char* name, int value) {
   return FRCNN_OK;
 }
 
+static int ensure_head_streams(frcnn_model* m);
 static int ensure_side(frcnn_model* m) {
   if (!m->side) {
     FR_TRY(pool_stream(0, &m->side));
@@ -746,13 +758,20 @@ static int ensure_side(frcnn_model* m) {
     // anchor nets' and the classification net's -- are about equally long, so shortening ONE of them changes nothing; with
     // the classification net's weight gradients off its chain as well (g_cnet_wgrad_async) the step goes from 3.11 to
     // 3.02 ms, with either change alone it stays at 3.11.  On by default since then.
-    static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 1;
-    size_t hi = 0;
-    for (auto& h : m->heads) {
-      // (five workspace slots for streams of their own, head_slot(): a sixth anchor net shares the side stream and its slot)
-      if (head_streams && hi < 5) { FR_TRY(pool_stream(2 + (int)hi, &h.stream)); ++hi; }
-      FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
-    }
+    for (auto& h : m->heads) FR_HIP(hipEventCreateWithFlags(&h.done, hipEventDisableTiming));
+  }
+  return FRCNN_OK;
+}
+
+// The anchor nets' own streams, made when the DENSE path first needs them (round 6): a stream that exists takes a share of a
+// hardware queue whether it is used or not, and the sparse training path (heads.hip) runs every anchor net on the side stream.
+static int ensure_head_streams(frcnn_model* m) {
+  static const int head_streams = getenv("FRCNN_HEAD_STREAMS") ? atoi(getenv("FRCNN_HEAD_STREAMS")) : 1;
+  size_t hi = 0;
+  for (auto& h : m->heads) {
+    // (five workspace slots for streams of their own, head_slot(): a sixth anchor net shares the side stream and its slot)
+    if (head_streams && hi < 5 && !h.stream) FR_TRY(pool_stream(2 + (int)hi, &h.stream));
+    ++hi;
   }
   return FRCNN_OK;
 }
@@ -891,10 +910,11 @@ static int pack_compact(frcnn_model* m, const float* w, bool f16, hipStream_t s)
   char* dslot = (char*)m->dc_dev.p + (size_t)slot * m->dc_slot_bytes;
   const std::vector<PackXJob>& src = f16 ? m->x3_host16 : m->x3_host;
   PackXJob* jobs = (PackXJob*)hslot;
-  const int n = (int)src.size();
-  for (int i = 0; i < n; ++i) {
+  int n = 0;
+  for (int i = 0; i < (int)src.size(); ++i) {
     PackXJob j = src[i];
     const int ci = m->x3_conv[i];
+    if (ci < 0 && !m->head_x3_fresh) continue;   // an anchor net's pack in a pass that runs the anchor nets sparse
     if (ci >= 0) {
       const Conv& c = m->convs[ci];
       const Block& blk = m->blocks[c.block];
@@ -916,7 +936,7 @@ static int pack_compact(frcnn_model* m, const float* w, bool f16, hipStream_t s)
         j = g;
       }
     }
-    jobs[i] = j;
+    jobs[n++] = j;
   }
   const int grid = conv_x3_pack_assign_blocks(jobs, n);
   FR_HIP(hipMemcpyAsync(dslot, hslot, m->dc_slot_bytes, hipMemcpyHostToDevice, s));
@@ -937,6 +957,7 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
   m->heads_deferred = async_heads && sparse_heads_on() && !deterministic() && m->heads.size() <= 4;
   m->heads_sparse_fwd = false; m->heads_gin = false;
   m->last_w = w;
+  if (use_side && !m->heads_deferred) { FR_TRY(ensure_side(m)); FR_TRY(ensure_head_streams(m)); }
   // SpatialDropout scales (device-drawn ones: one launch for all blocks)
   DropoutJobs dj;
   dj.n = 0;
@@ -974,7 +995,13 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
     else
       FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
     const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
-    if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
+    // (a training pass that leaves the anchor nets to the sparse path packs nothing of theirs: frcnn_model::head_x3_fresh)
+    static const bool skip_on = !(getenv("FRCNN_HEAD_PACK_SKIP") && atoi(getenv("FRCNN_HEAD_PACK_SKIP")) == 0);
+    const bool skip_heads = skip_on && training && m->heads_deferred && any_compact(m) && m->am_bb_n > 0;
+    m->head_x3_fresh = !skip_heads;
+    if (f16 && skip_heads)
+      FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p + m->am_bb_off, m->am_bb_n, m->am_bb_grid, s));
+    else if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
       FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p, m->n_amax_jobs, m->amax_grid, s));
     if (training && any_compact(m))
       FR_TRY(pack_compact(m, w, f16, s));   // the step's own table: the compact blocks' jobs gather the kept filters / channels
@@ -1121,6 +1148,7 @@ int frcnn_model_debug_buffer(frcnn_model* m, int kind, int index, void** ptr, lo
       if ((m->heads_sparse_fwd || m->heads_deferred) && m->last_w) {
         // the training pass computed this map at the sampled positions only (heads.hip), or not yet: the dense convolution, now
         FR_HIP(hipDeviceSynchronize());
+        if (!m->head_x3_fresh) { FR_TRY(refresh_group(m, m->last_w, (int)m->blocks.size(), nullptr)); m->head_x3_fresh = true; }
         FR_TRY(head_forward(m, m->heads[index], m->last_w, nullptr, 0));
         FR_HIP(hipDeviceSynchronize());
       }
@@ -1233,6 +1261,7 @@ static int backward_heads(frcnn_model* m, const float* w, float* grad, hipStream
 // event = chain_ev); every anchor net with a sparse hint then runs on its own stream beside the others, the dense
 // fallback (shared weight-gradient workspace) stays on the side stream.
 static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
+  FR_TRY(ensure_head_streams(m));
   FR_TRY(fill_zero((char*)m->zero_arena.p + m->delta_bytes, m->gpool_bytes, m->side));
   FR_HIP(hipEventRecord(m->chain_ev, m->side));
   for (auto& h : m->heads) h.gin_recorded = false;
@@ -1261,6 +1290,11 @@ static int backward_heads_fanout(frcnn_model* m, const float* w, float* grad) {
 // on its own stream behind everything queued on `s` (the pooled maps are final there).
 static int heads_forward_dense(frcnn_model* m, const float* w, hipStream_t s) {
   FR_TRY(ensure_side(m));
+  FR_TRY(ensure_head_streams(m));
+  if (!m->head_x3_fresh) {   // the pass packed nothing of the anchor nets (it meant to run them sparse)
+    FR_TRY(refresh_group(m, w, (int)m->blocks.size(), s));
+    m->head_x3_fresh = true;
+  }
   for (size_t i = 0; i < m->heads.size(); ++i) {
     FR_TRY(fork_to(m, s, head_stream(m, i), 16 + i));
     FR_TRY(head_forward(m, m->heads[i], w, head_stream(m, i), head_slot(m, i)));
@@ -1496,16 +1530,21 @@ int frcnn_pnet_wait_block_done(frcnn_model* m, int block, void* stream) {
 // just been queued on the same stream.  When every group has been renewed from the vector the next training-mode forward is
 // given, that forward skips its prologue.  The caller promises that nothing writes w between this call and that forward except
 // updates followed by their own refresh; frcnn_pnet_invalidate_packs withdraws the promise.
-int frcnn_pnet_refresh_packs(frcnn_model* m, const float* w, int group, void* stream) {
-  FR_CHECK(m->H > 0, "pnet_refresh_packs: call frcnn_pnet_forward first");
-  FR_CHECK(group >= 0 && group < (int)m->groups.size(), "pnet_refresh_packs: group %d out of range", group);
-  hipStream_t s = S(stream);
+static int refresh_group(frcnn_model* m, const float* w, int group, hipStream_t s) {
   const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
-  if (m->fresh_mask && (m->fresh_w != w || m->fresh_f16 != f16)) m->fresh_mask = 0;
   const frcnn_model::PackGroup& G = m->groups[group];
   if (G.pk_n) FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + G.pk_off, G.pk_n, G.pk_grid, s));
   if (f16 && G.am_n) FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p + G.am_off, G.am_n, G.am_grid, s));
   if (G.x3_n) FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)m->x3_jobs.p + (f16 ? G.x3_off16 : G.x3_off), G.x3_n, G.x3_grid, s));
+  return FRCNN_OK;
+}
+int frcnn_pnet_refresh_packs(frcnn_model* m, const float* w, int group, void* stream) {
+  FR_CHECK(m->H > 0, "pnet_refresh_packs: call frcnn_pnet_forward first");
+  FR_CHECK(group >= 0 && group < (int)m->groups.size(), "pnet_refresh_packs: group %d out of range", group);
+  const bool f16 = get_x3_f16() && m->n_amax_jobs > 0;
+  if (m->fresh_mask && (m->fresh_w != w || m->fresh_f16 != f16)) m->fresh_mask = 0;
+  FR_TRY(refresh_group(m, w, group, S(stream)));
+  if (group == (int)m->blocks.size()) m->head_x3_fresh = true;
   m->fresh_mask |= 1u << group; m->fresh_w = w; m->fresh_f16 = f16;
   return FRCNN_OK;
 }
