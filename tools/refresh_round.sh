@@ -54,7 +54,7 @@ python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
   [ -x tools/bin/lds_dma_probe ] || hipcc --offload-arch=gfx950 -O3 tools/lds_dma_probe.hip -o tools/bin/lds_dma_probe >/dev/null 2>&1
   timeout 60 tools/bin/lds_dma_probe 2>/dev/null
   echo "# training step with options -- python bench.py --no-cpu-baseline --steps 40 (images/s, ms/step, roofline.frac live)"
-  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_X3_F16=0" "FRCNN_SPLIT_BF16=0" "FRCNN_GEMM_X=0" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=0" "FRCNN_CNET_WGRAD_ASYNC=0" "FRCNN_FUSE_ACT=0" "FRCNN_FIRST_POOLED=0"; do
+  for e in "FRCNN_SPLIT_BF16=1" "FRCNN_DROP_COMPACT=0" "FRCNN_SPARSE_HEADS=0" "FRCNN_DROP_COMPACT=0 FRCNN_SPARSE_HEADS=0" "FRCNN_EAGER_UPDATE=1" "FRCNN_X3_F16=0" "FRCNN_SPLIT_BF16=0" "FRCNN_GEMM_X=0" "FRCNN_DETERMINISTIC=1" "FRCNN_SIDE_STREAM=0" "FRCNN_HEAD_STREAMS=0" "FRCNN_CNET_WGRAD_ASYNC=0" "FRCNN_FUSE_ACT=0" "FRCNN_FIRST_POOLED=0"; do
     echo -n "$e: "; env $e python bench.py --no-cpu-baseline --no-sustained --steps 40 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
   done
   echo "# config 5 shapes on one GPU -- python bench.py --model vgg_large --height 600 --width 1000 --steps 10 --no-cpu-baseline"
