@@ -850,7 +850,8 @@ def main():
         if m2[kdom] > 0:
             a2 = (f2[kdom] / 1e12) / (m2[kdom] / 1e3)
             iso = dict(achieved=round(a2, 2), frac=round(a2 / peak_dom, 4), avg_launch_ms=round(m2[kdom] / max(l2[kdom], 1), 4),
-                       note="same kernel with frcnn_set_option('side_stream', 0): no concurrent weight-gradient launches")
+                       note="same kernel with frcnn_set_option('side_stream', 0): no concurrent weight-gradient launches; with the side stream off the "
+                            "anchor nets run as dense convolutions (option sparse_heads needs it), so this pass has their four conv_x3 launches too")
     # objective.lua:66 uploads every frame (`x.img:cuda()`); the bench contract keeps inputs resident in HBM for `value`.
     # The PCIe-inclusive rate is measured here, outside the timed region: the same step fed by an iterator whose frames
     # live in page-locked host memory and cross PCIe every step (copy stream + ring of device buffers, one step ahead).

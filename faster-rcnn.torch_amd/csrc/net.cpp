@@ -176,6 +176,7 @@ struct frcnn_model {
   // asynchronous copy per step: [PackXJob table of the step][kept-channel tables of the blocks]
   static const int DC_RING = 4;
   char* dc_pin = nullptr; DevBuf dc_dev; size_t dc_slot_bytes = 0, dc_idx_off = 0; unsigned dc_step = 0;
+  hipEvent_t dc_ev[DC_RING] = {};             // slot s's copy to the device has run (a host that queues more than DC_RING passes ahead waits here)
   std::vector<PackXJob> x3_host, x3_host16;   // the model's training pack jobs as built by ensure_shapes (plain | fp16 form), host copies
   std::vector<int> x3_conv;                   // ... the convolution each job belongs to (index into convs, -1: an anchor net)
   DevBuf dbg_expand;                          // frcnn_model_debug_buffer: a compact tensor laid out dense
@@ -502,6 +503,7 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       const size_t slot = (m->dc_idx_off + chans * 4 + 255) / 256 * 256;
       if (slot != m->dc_slot_bytes) {
         if (m->dc_pin) (void)hipHostFree(m->dc_pin);
+  for (auto e : m->dc_ev) if (e) (void)hipEventDestroy(e);
         m->dc_pin = nullptr;
         FR_HIP(hipHostMalloc((void**)&m->dc_pin, slot * frcnn_model::DC_RING, hipHostMallocDefault));
         m->dc_dev.release();
@@ -581,6 +583,7 @@ int frcnn_model_destroy(frcnn_model* m) {
   for (auto& c : m->convs) rel(c);
   for (auto& b : m->blocks) { b.scale.release(); b.pooled.release(); b.gpooled.release(); b.pidx.release(); b.dc_bias.release(); }
   if (m->dc_pin) (void)hipHostFree(m->dc_pin);
+  for (auto e : m->dc_ev) if (e) (void)hipEventDestroy(e);
   m->dc_dev.release(); m->dbg_expand.release();
   for (auto& h : m->heads) {
     rel(h.c3); rel(h.c1); h.delta.release(); h.spOut.release(); h.spSlab.release();
@@ -865,6 +868,7 @@ static int plan_compact(frcnn_model* m, int training, const float* const* drop_m
   for (auto& b : m->blocks) { b.dc_on = false; b.dc_idx = nullptr; }
   if (!training || !drop_compact_on() || !fuse_act_on() || !m->dc_pin) return FRCNN_OK;
   const unsigned slot = m->dc_step % frcnn_model::DC_RING;
+  if (m->dc_ev[slot]) FR_HIP(hipEventSynchronize(m->dc_ev[slot]));   // (the slot's previous copy, DC_RING passes ago: long done unless the host never looks back)
   int* idx_host = (int*)(m->dc_pin + (size_t)slot * m->dc_slot_bytes + m->dc_idx_off);
   const int* idx_dev = (const int*)((char*)m->dc_dev.p + (size_t)slot * m->dc_slot_bytes + m->dc_idx_off);
   size_t at = 0;
@@ -940,6 +944,8 @@ static int pack_compact(frcnn_model* m, const float* w, bool f16, hipStream_t s)
   }
   const int grid = conv_x3_pack_assign_blocks(jobs, n);
   FR_HIP(hipMemcpyAsync(dslot, hslot, m->dc_slot_bytes, hipMemcpyHostToDevice, s));
+  if (!m->dc_ev[slot]) FR_HIP(hipEventCreateWithFlags(&m->dc_ev[slot], hipEventDisableTiming));
+  FR_HIP(hipEventRecord(m->dc_ev[slot], s));
   FR_TRY(conv_x3_pack_multi(w, (const PackXJob*)dslot, n, grid, s));
   return FRCNN_OK;
 }
@@ -1333,7 +1339,8 @@ static int heads_jobs(frcnn_model* m, const float* w, float* grad, HeadJobs& g) 
     int splits = (int)std::max<long>(1, std::min<long>(std::min<long>((long)ckk / 256, 64), 256 / tiles));
     const int per = cdiv(cdiv((int)ckk, splits), 32) * 32;
     splits = cdiv((int)ckk, per);
-    FR_TRY(h.spSlab.ensure((size_t)splits * n * P * 4));
+    FR_TRY(h.spSlab.ensure(n * 4096 * 4));   // (splits * P <= 64 * 64 whatever P: allocated once)
+    FR_CHECK((size_t)splits * P <= 4096, "heads_jobs: %d K splits of %d positions", splits, P);
     j.hx_slab = h.spSlab.f(); j.hx_splits = splits;
   }
   return FRCNN_OK;
