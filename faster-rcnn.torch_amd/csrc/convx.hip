@@ -263,15 +263,22 @@ __device__ __forceinline__ void pack_x_job(const float* __restrict__ weights, co
     {
       const int r0 = (u - pr * groups) * ROWS;
       // tile[r][kc16 * KK + tap] (source tap order), r = filter row inside this group of ROWS rows
-      if (j.oidx || j.cidx) {   // gathered filters / channels (PackXJob): runs of KK floats
+      if (j.oidx || j.cidx) {   // gathered filters / channels (PackXJob): one (row, channel) pair per thread and turn, its KK taps in a run
         const int Cs = j.Cs ? j.Cs : j.C;
-        for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {
-          const int r = e / (CX_CH * KK), q = e - r * (CX_CH * KK);
-          const int kc = q / KK, tap = q - kc * KK;
+        for (int e = tid; e < ROWS * CX_CH; e += 256) {
+          const int r = e / CX_CH, kc = e - r * CX_CH;
           const int mrow = mt * BM + r0 + r, krow = chunk * CX_CH + kc;      // the pack's M row / K channel
           const int op = j.mode == 0 ? mrow : krow, cp = j.mode == 0 ? krow : mrow;   // ... as filter o' / channel c'
           const int o = j.oidx ? j.oidx[op] : op, c = j.cidx ? j.cidx[cp] : cp;
-          tile[r * PITCH + q] = (o >= 0 && c >= 0) ? w[((size_t)o * Cs + c) * KK + tap] : 0.f;
+          float* dst = tile + r * PITCH + kc * KK;
+          if (o >= 0 && c >= 0) {
+            const float* src = w + ((size_t)o * Cs + c) * KK;
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) dst[tap] = src[tap];
+          } else {
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) dst[tap] = 0.f;
+          }
         }
       } else if (j.mode == 0) {
         for (int e = tid; e < ROWS * CX_CH * KK; e += 256) {

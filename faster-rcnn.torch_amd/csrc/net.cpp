@@ -192,6 +192,7 @@ struct frcnn_model {
   hipEvent_t upd_ev = nullptr, upd_join_ev = nullptr;   // fork / join points of the update stream (frcnn_model_update_*)
   bool head_x3_fresh = true;       // the anchor nets' split-operand packs and weight magnitudes match the last forward pass's weights
   int am_bb_off = 0, am_bb_n = 0, am_bb_grid = 0;   // AmaxJob sub-table: the backbone's weight tensors only
+  int pk_bb_off = 0, pk_bb_n = 0, pk_bb_grid = 0;   // PackJob sub-table: the backbone's training packs only
   bool heads_deferred = false;     // training pass: the anchor nets' forward part has not been launched yet (frcnn_pnet_forward_async_heads
                                    // leaves it to the call that knows the sampled positions: heads.hip)
   bool heads_sparse_fwd = false;   // ... and was then computed at the sampled positions only
@@ -424,6 +425,16 @@ static int ensure_shapes(frcnn_model* m, int H, int W) {
       auto& G = m->groups[g];
       G.pk_off = (int)both.size(); G.pk_n = (int)gj.size();
       G.pk_grid = gj.empty() ? 0 : conv_pack_assign_blocks(gj.data(), G.pk_n, 512);
+      both.insert(both.end(), gj.begin(), gj.end());
+    }
+    {   // the backbone's training packs only (a pass that runs the anchor nets sparse: frcnn_model::head_x3_fresh)
+      std::vector<PackJob> gj;
+      for (auto& c : m->convs) {
+        if (!c.x_f) gj.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 0, c.wf.f()));
+        if (!(c.block == 0 && c.step == 0) && !c.x_d) gj.push_back(conv_pack_job(c.w_off, c.Cout, c.Cin, c.k, 1, c.wd.f()));
+      }
+      m->pk_bb_off = (int)both.size(); m->pk_bb_n = (int)gj.size();
+      m->pk_bb_grid = gj.empty() ? 0 : conv_pack_assign_blocks(gj.data(), m->pk_bb_n, 512);
       both.insert(both.end(), gj.begin(), gj.end());
     }
     FR_TRY(m->pack_jobs.ensure(both.size() * sizeof(PackJob)));
@@ -996,15 +1007,17 @@ static int pnet_forward_impl(frcnn_model* m, const float* w, const float* img, i
                      !any_compact(m);   // (a compact block's packs depend on the step's keep vector)
   m->fresh_mask = 0;
   if (!reuse && !fresh) {
-    if (training)
-      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
-    else
-      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
-    const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
     // (a training pass that leaves the anchor nets to the sparse path packs nothing of theirs: frcnn_model::head_x3_fresh)
     static const bool skip_on = !(getenv("FRCNN_HEAD_PACK_SKIP") && atoi(getenv("FRCNN_HEAD_PACK_SKIP")) == 0);
     const bool skip_heads = skip_on && training && m->heads_deferred && any_compact(m) && m->am_bb_n > 0;
     m->head_x3_fresh = !skip_heads;
+    if (training && skip_heads) {
+      if (m->pk_bb_n) FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->pk_bb_off, m->pk_bb_n, m->pk_bb_grid, s));
+    } else if (training)
+      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p, m->n_pack_all, m->pack_grid_all, s));
+    else
+      FR_TRY(conv_pack_weights_multi(w, (const PackJob*)m->pack_jobs.p + m->n_pack_all, m->n_pack_fwd, m->pack_grid_fwd, s));
+    const PackXJob* xjobs = (const PackXJob*)m->x3_jobs.p + (f16 ? m->n_x3_all + m->n_x3_fwd : 0);
     if (f16 && skip_heads)
       FR_TRY(tensor_absmax_multi(w, (const AmaxJob*)m->amax_jobs.p + m->am_bb_off, m->am_bb_n, m->am_bb_grid, s));
     else if (f16)   // the weight tensors' magnitudes first: their packs are scaled by them
