@@ -12,6 +12,7 @@
 //
 // Flat parameter order (utilities.lua:136-147): see frcnn_model_param_table.
 #include <array>
+#include <vector>
 #include <cmath>
 #include <cstring>
 
@@ -188,6 +189,8 @@ struct frcnn_model {
   std::vector<hipEvent_t> cw_ev;   // one fork point per layer + one for the two heads
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
+  bool update_armed = false;       // a host has asked for the update stream (frcnn_model_update_stream): the passes record the
+                                   // events its waits need (bwd_ev, block_rd_ev) -- each costs the caller's stream a marker packet
   hipEvent_t bwd_ev = nullptr;     // the backbone's backward pass has begun on the caller's stream (anchor nets joined)
   hipEvent_t upd_ev = nullptr, upd_join_ev = nullptr;   // fork / join points of the update stream (frcnn_model_update_*)
   bool head_x3_fresh = true;       // the anchor nets' split-operand packs and weight magnitudes match the last forward pass's weights
@@ -705,6 +708,7 @@ static int ensure_update_stream(frcnn_model* m) {
 int frcnn_model_update_stream(frcnn_model* m, void** stream) {
   FR_CHECK(m && stream, "model_update_stream: null argument");
   FR_TRY(ensure_update_stream(m));
+  m->update_armed = true;
   *stream = (void*)m->cw;
   return FRCNN_OK;
 }
@@ -1515,7 +1519,8 @@ int frcnn_pnet_backward_heads_join(frcnn_model* m, void* stream, int* joined) {
 // backbone's backward pass -- the stretch of the step that is bound by the matrix cores, beside which bandwidth-bound work
 // (the update of slices that are final already) costs least.  Everything the caller's stream ran before it is final too.
 int frcnn_pnet_wait_backward_begun(frcnn_model* m, void* stream) {
-  FR_CHECK(m->bwd_ev && m->block_ev_valid, "pnet_wait_backward_begun: call frcnn_pnet_backward first");
+  FR_CHECK(m->update_armed && m->bwd_ev && m->block_ev_valid,
+           "pnet_wait_backward_begun: call frcnn_model_update_stream before the pass and frcnn_pnet_backward first");
   FR_HIP(hipStreamWaitEvent(S(stream), m->bwd_ev, 0));
   return FRCNN_OK;
 }
@@ -1538,8 +1543,8 @@ int frcnn_pnet_wait_heads_done(frcnn_model* m, void* stream) {
 // packs or its weight-magnitude scalars (the input-gradient launch of the block's first convolution).
 int frcnn_pnet_wait_block_done(frcnn_model* m, int block, void* stream) {
   FR_CHECK(block >= 1 && block <= (int)m->blocks.size(), "pnet_wait_block_done: block %d out of range", block);
-  FR_CHECK(m->block_ev_valid && (size_t)block <= m->block_ev.size() && (size_t)block <= m->block_rd_ev.size(),
-           "pnet_wait_block_done: call frcnn_pnet_backward first");
+  FR_CHECK(m->update_armed && m->block_ev_valid && (size_t)block <= m->block_ev.size() && (size_t)block <= m->block_rd_ev.size(),
+           "pnet_wait_block_done: call frcnn_model_update_stream before the pass and frcnn_pnet_backward first");
   FR_HIP(hipStreamWaitEvent(S(stream), m->block_ev[block - 1], 0));
   FR_HIP(hipStreamWaitEvent(S(stream), m->block_rd_ev[block - 1], 0));
   return FRCNN_OK;
@@ -1582,6 +1587,7 @@ int frcnn_pnet_wait_block_gradients(frcnn_model* m, int block, void* stream) {
 }
 
 static int record_block_read(frcnn_model* m, int b, hipStream_t s) {
+  if (!m->update_armed) return FRCNN_OK;
   while (m->block_rd_ev.size() < m->blocks.size()) {
     hipEvent_t e;
     FR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1638,8 +1644,10 @@ int frcnn_pnet_backward(frcnn_model* m, const float* w, float* grad, void* strea
     FR_TRY(add_inplace(last.gpooled.f(), m->delta_last.f(), (long)m->d.filters[nb - 1] * last.Hp * last.Wp, s));
   }
   // from here on the caller's stream is busy with matrix-core work for the rest of the pass (frcnn_pnet_wait_backward_begun)
-  if (!m->bwd_ev) FR_HIP(hipEventCreateWithFlags(&m->bwd_ev, hipEventDisableTiming));
-  FR_HIP(hipEventRecord(m->bwd_ev, s));
+  if (m->update_armed) {
+    if (!m->bwd_ev) FR_HIP(hipEventCreateWithFlags(&m->bwd_ev, hipEventDisableTiming));
+    FR_HIP(hipEventRecord(m->bwd_ev, s));
+  }
   // The weight gradient of a layer and the input gradient that feeds the next act_backward are independent:
   // accGradParameters goes to a side stream, so its blocks fill the CUs that the tail of the updateGradInput
   // kernel (one wave of blocks, retiring unevenly) leaves idle, and the ~4 us dispatch gaps of one chain
