@@ -64,3 +64,49 @@ def test_sparse_anchor_nets_equal_the_dense_convolutions(F, size, negatives):
         assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b), (off, cnt, kind, np.linalg.norm(a - b) / np.linalg.norm(b))
     lo, hi = model["pnet"].heads_param_range()
     assert np.abs(ga[lo:hi]).max() > 0
+
+
+def _batch_step(F, sparse, compact):
+    """Two images in one step (the gradient accumulates over them, objective.lua:64-198), the second without any example: its
+    anchor nets are never launched in the sparse mode, its backward pass finds nothing to do for them."""
+    import torch
+    H, W = 225, 400
+    cfg = dict(F.duplo_cfg)
+    model = F.vgg_small(cfg)
+    w, g = F.combine_and_flatten_parameters(model["pnet"], model["cnet"], seed=6)
+    anchors = F.Anchors(model["pnet"], cfg["scales"])
+    rois = F.synthetic_rois(cfg, W, H, 3, 7, 5)
+    pos, neg = F.assemble_examples(anchors, cfg, rois, W, H, F.MT19937(29), negatives=48)
+    sizes = F.output_map_sizes(model, H, W)
+    pos, neg = F.clean_examples(pos, sizes), F.clean_examples(neg, sizes)
+    batch = [dict(img=F.synthetic_image(H, W, 7), positive=pos, negative=neg),
+             dict(img=F.synthetic_image(H, W, 8), positive=[], negative=[])]
+    f = F.create_objective(model, w, g, _One(batch), dict(pcls=[], preg=[], dcls=[], dreg=[]))
+    E = len(pos) + len(neg)
+    rng = np.random.RandomState(2)
+    F._lib.call("frcnn_set_option", b"sparse_heads", 1 if sparse else 0)
+    F._lib.call("frcnn_set_option", b"drop_compact", 1 if compact else 0)
+    try:
+        model["pnet"].drop_masks = [None if l["dropout"] <= 0 else (rng.rand(l["filters"]) > l["dropout"]).astype(np.float32)
+                                    for l in model["layers"]]
+        model["cnet"].drop_masks = [(rng.rand(E, l["n"]) > 0.5).astype(np.float32) for l in model["class_layers"]]
+        loss, grad = f(w)
+        torch.cuda.synchronize()
+        return loss, grad.cpu().numpy().copy(), model
+    finally:
+        F._lib.call("frcnn_set_option", b"sparse_heads", 1)
+        F._lib.call("frcnn_set_option", b"drop_compact", 1)
+        model["pnet"].drop_masks = None
+        model["cnet"].drop_masks = None
+
+
+def test_two_images_one_of_them_without_examples(F):
+    la, ga, model = _batch_step(F, True, False)
+    lb, gb, _ = _batch_step(F, False, False)
+    lc, gc, _ = _batch_step(F, True, True)
+    assert np.isfinite(la) and abs(la - lb) <= 1e-6 * abs(lb) and abs(lc - lb) <= 1e-6 * abs(lb)
+    nb = np.linalg.norm(gb.astype(np.float64))
+    assert np.linalg.norm(ga.astype(np.float64) - gb) <= 2e-5 * nb          # sparse against dense anchor nets: rounding
+    assert np.linalg.norm(gc.astype(np.float64) - gb) <= 1e-3 * nb          # ... and the dropped channels left out (decision flips)
+    lo, hi = model["pnet"].heads_param_range()
+    assert np.abs(ga[lo:hi]).max() > 0
