@@ -114,6 +114,21 @@ def conv_flops_per_image(model, H, W):
     return fwd, 3 * fwd - first
 
 
+def backbone_x3_dense_flops(model, H, W):
+    """FLOPs of the launches the conv_x3 class runs in a training step -- forward and input gradient of every backbone convolution
+    but the first -- by the DENSE algorithm's formula, whatever option drop_compact leaves out."""
+    import math
+    tot, h, w, cin, first = 0.0, H, W, 3, True
+    for l in model["layers"]:
+        for _ in range(l["conv_steps"]):
+            if not first:
+                tot += 2 * 2.0 * l["filters"] * cin * l["kW"] * l["kH"] * h * w
+            first = False
+            cin = l["filters"]
+        h = int(math.ceil((h - 2) / 2.0)) + 1; w = int(math.ceil((w - 2) / 2.0)) + 1
+    return tot
+
+
 def _host_info():
     model = "unknown"
     try:
@@ -957,7 +972,14 @@ def main():
                                     if split_on else None),
                           sampled_steps=sampled, launches_per_step=launches[k] / sampled, avg_launch_ms=round(ms[k] / max(launches[k], 1), 4),
                           algorithmic_bytes_per_launch=round(by[k] / max(launches[k], 1)),
-                          algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso),
+                          algorithmic_gflop_per_launch=round(fl[k] / 1e9 / max(launches[k], 1), 3), isolated=iso,
+                          dense_equivalent=(dict(gflop_per_step=round(backbone_x3_dense_flops(model, H, W) / 1e9, 2),
+                                                 tflops=round(backbone_x3_dense_flops(model, H, W) / 1e12 / (ms[k] / 1e3 / sampled), 2),
+                                                 frac=round(backbone_x3_dense_flops(model, H, W) / 1e12 / (ms[k] / 1e3 / sampled) / peak, 4),
+                                                 note="the same launches priced by the DENSE algorithm's FLOP formula (SURVEY 8d): what option "
+                                                      "drop_compact leaves out -- products with the zeros of nn.SpatialDropout -- counted as if "
+                                                      "computed.  Not a matrix-core utilisation: `frac` above counts the launches as run")
+                                            if split_on and launches[k] / sampled == 12.0 else None)),
             roofline_hbm=hbm,
             sustained=sustained,
         )
