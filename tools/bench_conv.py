@@ -52,9 +52,10 @@ def run(kind, name, reps=5):
 
     def once():
         if kind == "wgrad":
-            F._lib.call("frcnn_conv2d_backward_weight", F.ptr(x), Cin, H, W, None, None, F.ptr(g), O, k, pad, F.ptr(gw), None, s)
+            F._lib.call("frcnn_conv2d_backward_weight", F.ptr(x), Cin, H, W, F.ptr(slope) if os.environ.get("WITH_SLOPE") else None, None,
+                        F.ptr(g), O, k, pad, F.ptr(gw), None, s)
         elif kind == "fwd":
-            F._lib.call("frcnn_conv2d_forward", F.ptr(x), Cin, H, W, F.ptr(slope) if act else None, F.ptr(scale) if act else None,
+            F._lib.call("frcnn_conv2d_forward", F.ptr(x), Cin, H, W, F.ptr(slope) if (act or os.environ.get("WITH_SLOPE")) else None, F.ptr(scale) if act else None,
                         F.ptr(w), None, O, k, pad, F.ptr(out), s)
         else:
             F._lib.call("frcnn_conv2d_backward_input", F.ptr(g), O, Ho, Wo, F.ptr(w), Cin, k, pad, F.ptr(gin), 0, s)
