@@ -393,13 +393,33 @@ int act_backward(const float* gy, const float* x, int C, long hw, const float* s
   return FRCNN_OK;
 }
 
+// (16-byte loads where the chunk allows: the first layer's bias gradient of vgg_large sums 64 x 600 x 1000 values -- 120 us one value
+// per load and thread, round 6)
 __global__ void channel_sum_kernel(const float* __restrict__ g, long hw, float* gbias, int chunks, float* part_b) {
   __shared__ float sh[16];
   const int c = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-  const long per = cdivl(hw, chunks);
+  long per = cdivl(hw, chunks);
+  per = (per + 3) & ~3L;
   const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  const float* gc = g + (size_t)c * hw;
   float sb = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) sb += g[(size_t)c * hw + i];
+  if (beg < end) {
+    if ((reinterpret_cast<uintptr_t>(gc + beg) & 15) == 0) {
+      const long n4 = (end - beg) >> 2;
+      const float4* g4 = reinterpret_cast<const float4*>(gc + beg);
+      float s0 = 0.f, s1 = 0.f;
+      long i = threadIdx.x;
+      for (; i + blockDim.x < n4; i += 2 * blockDim.x) {
+        const float4 a = g4[i], b = g4[i + blockDim.x];
+        s0 += (a.x + a.y) + (a.z + a.w); s1 += (b.x + b.y) + (b.z + b.w);
+      }
+      if (i < n4) { const float4 a = g4[i]; s0 += (a.x + a.y) + (a.z + a.w); }
+      sb = s0 + s1;
+      for (long j = beg + (n4 << 2) + threadIdx.x; j < end; j += blockDim.x) sb += gc[j];
+    } else {
+      for (long i = beg + threadIdx.x; i < end; i += blockDim.x) sb += gc[i];
+    }
+  }
   float tb = block_sum(sb, sh);
   if (part_b) { if (threadIdx.x == 0) part_b[blockIdx.x] = tb; return; }
   if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, tb);
