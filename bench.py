@@ -924,7 +924,8 @@ def main():
                          "error against fp64 at the level of the fp32 matrix-core kernel (tools/x3_f16_check.py); the classification net's "
                          "Linear(13824,1024) forward / input-gradient products " + ("take the same two-plane form" if os.environ.get("FRCNN_GEMM_F16", "1") != "0"
                                                                                    else "use three bf16 planes / six partial products (FRCNN_GEMM_F16=0)") +
-                         ", its weight-gradient product three bf16 planes / six partial products; every other product is a plain fp32 product"
+                         (", its weight-gradient product two fp16 planes of both operands" if os.environ.get("FRCNN_GEMM_WGRAD_F16", "1") != "0" and os.environ.get("FRCNN_GEMM_F16", "1") != "0"
+                          else ", its weight-gradient product three bf16 planes / six partial products") + "; every other product is a plain fp32 product"
                          if nprod == F16_PRODUCTS else
                          "fp32 tensors, fp32 accumulation; the 3x3 convolutions (forward, input gradient, weight gradient) form every fp32 "
                          "product from six exact bf16 x bf16 partial products of three-way split operands (24 significand bits, "

@@ -130,11 +130,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tile[(r8 + j) * 65 + c];
         uint4 H, Mi, L;
-        x_split8(v, H, Mi, L);
         unsigned short* d = PT + ((size_t)((r0 + r8) >> 3) * C + c0 + c) * 8;
-        *reinterpret_cast<uint4*>(d) = H;
-        *reinterpret_cast<uint4*>(d + planeT) = Mi;
-        *reinterpret_cast<uint4*>(d + 2 * planeT) = L;
+        if (NP == 2) {   // (round 6: the weight-gradient product in the two-plane form too)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= mul;
+          x_split8h(v, H, L);
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + planeT) = L;
+        } else {
+          x_split8(v, H, Mi, L);
+          *reinterpret_cast<uint4*>(d) = H;
+          *reinterpret_cast<uint4*>(d + planeT) = Mi;
+          *reinterpret_cast<uint4*>(d + 2 * planeT) = L;
+        }
       }
     }
   }
@@ -144,7 +152,6 @@ int linear_x_rows_padded(int R) { return (R + 15) & ~15; }
 
 int split_planes(const float* src, int R, int C, void* P, void* PT, hipStream_t s, const float* amax) {
   FR_CHECK(C % 8 == 0, "split_planes: %d columns (a multiple of 8 is needed for 16-byte plane entries)", C);
-  FR_CHECK(!amax || !PT, "split_planes: the two-plane fp16 form has no transposed planes (the weight-gradient product takes three bf16 planes)");
   const int Rp = linear_x_rows_padded(R);
   dim3 grid(cdiv(C, 64), cdiv(Rp, 64));
   if (amax)
@@ -196,10 +203,9 @@ template <int N> __device__ __forceinline__ void gx_wait_vmcnt() { asm volatile(
 
 template <int TM, int WM, int BMODE, int NP = 3>
 __global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_kernel(GxArgs p) {
-  static_assert(NP == 3 || BMODE != 0, "the two-plane form is built for the fp32-weight modes");
   constexpr int RW = TM / WM, MTW = RW / 32, NTW = WM;  // rows of one wave, its 32-row tiles and its 32-column tiles
   constexpr int SA = 32 * NP * TM;                      // bytes of one A stage: [plane NP][half 2][TM rows][8 x 16 bit]
-  constexpr int SB = BMODE == 0 ? 96 * GX_TN : 64 * GX_TN;   // B stage: planes | [256 n][4 chunks of 4 k] | [16 k][256 n] fp32
+  constexpr int SB = BMODE == 0 ? 32 * NP * GX_TN : 64 * GX_TN;   // B stage: planes | [256 n][4 chunks of 4 k] | [16 k][256 n] fp32
   constexpr int NA = SA / 1024, NB = SB / 1024;         // wave instructions (1 KB each) per stage
   constexpr int IA = (NA + 7) / 8, IB = NB / 8;         // ... per wave (A: the last ones may repeat a slot -- same bytes twice)
   static_assert(NB % 8 == 0, "B stage must deal evenly to the eight waves");
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(512, 2 * gx_blocks_per_cu(TM)) void gemm_planes_ker
         for (int nt = 0; nt < NTW; ++nt)
           bp[nt][pl] = *reinterpret_cast<const uint4*>(B_ + ((pl * 2 + h) * GX_TN + bcol + nt * 32) * 16);
       };
-      load_a(2); load_b(0); load_a(0); load_b(2); load_a(1); load_b(1);   // (BMODE 0 is a three-plane mode)
+      if constexpr (NP == 2) { load_a(1); load_b(0); load_a(0); load_b(1); }
+      else { load_a(2); load_b(0); load_a(0); load_b(2); load_a(1); load_b(1); }
     } else {
       float vv[NTW][8];
 #pragma unroll
@@ -486,6 +493,14 @@ static void gx_plan(int M, int N, int K, int bmode, int splitK_max, int* TM, int
 template <int BMODE>
 static int launch_gx_tm(int TM, GxArgs& a, dim3 grid, double flops, double bytes, hipStream_t s) {
   if constexpr (BMODE == 0) {
+    if (a.amax_a) {   // two fp16 planes of both operands
+      switch (TM) {
+        case 256: return launch_gx<256, 2, 0, 2>(a, grid, flops, bytes, s);
+        case 192: return launch_gx<192, 2, 0, 2>(a, grid, flops, bytes, s);
+        case 128: return launch_gx<128, 2, 0, 2>(a, grid, flops, bytes, s);
+        default: return launch_gx<64, 2, 0, 2>(a, grid, flops, bytes, s);
+      }
+    }
     switch (TM) {
       case 256: return launch_gx<256, 2, 0>(a, grid, flops, bytes, s);
       case 192: return launch_gx<192, 2, 0>(a, grid, flops, bytes, s);
@@ -564,10 +579,12 @@ int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* g
 }
 
 // gW[O][I] += gY^T X ; GpT = planes of gY^T [3][Rp/8][O][8], XpT = planes of X^T [3][Rp/8][I][8] (k = r; r >= R zero)
-int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot) {
+int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot, const float* amax_g,
+                   const float* amax_x) {
+  FR_CHECK((amax_g != nullptr) == (amax_x != nullptr), "linear_x_wgrad: the fp16 form needs the records of both operands");
   const int Rp = linear_x_rows_padded(R);
   GxArgs a;
-  a.amax_a = nullptr; a.amax_b = nullptr;
+  a.amax_a = amax_g; a.amax_b = amax_x;
   a.Ap = (const unsigned short*)GpT; a.aPlane = (long)O * Rp; a.aLd = O;
   a.B = XpT; a.bPlane = (long)I * Rp; a.bLd = I;
   a.ldc = I; a.M = O; a.N = I; a.K = Rp;

@@ -220,7 +220,8 @@ int linear_x_forward(const void* Xp, int R, int I, const float* W, const float* 
                      GemmFold* defer = nullptr, const float* amax_x = nullptr, const float* amax_w = nullptr);
 int linear_x_dgrad(const void* Gp, int R, int O, const float* W, int I, float* gx, int out_mode, hipStream_t s, int ws_slot = 0,
                    GemmFold* defer = nullptr, const float* amax_g = nullptr, const float* amax_w = nullptr);
-int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot = 0);
+int linear_x_wgrad(const void* GpT, const void* XpT, int R, int O, int I, float* gw, hipStream_t s, int ws_slot = 0,
+                   const float* amax_g = nullptr, const float* amax_x = nullptr);   // both records: two fp16 planes per operand (PT of split_planes with amax)
 
 
 // ---------------------------------------------------------------- roi (roi.hip)

@@ -1816,7 +1816,7 @@ static int ensure_cnet(frcnn_model* m, int R) {
     if (L.x_form & 1) FR_TRY(L.xp.ensure((size_t)3 * R * L.in * 2));
     if (L.x_form & 2) FR_TRY(L.gp.ensure((size_t)3 * R * L.n * 2));
     if (L.x_form & 4) { FR_TRY(L.xpT.ensure((size_t)3 * L.in * Rp * 2)); FR_TRY(L.gpT.ensure((size_t)3 * L.n * Rp * 2)); }
-    if (L.x_form & 3) FR_TRY(L.am.ensure((size_t)3 * AMAX_REC * 4));
+    if (L.x_form & 7) FR_TRY(L.am.ensure((size_t)5 * AMAX_REC * 4));   // records: input, output gradient, weights; the weight-gradient stream's own two
   }
   int nc = m->d.class_count + 1;
   int nf = m->cls.empty() ? m->D : m->cls.back().n;
@@ -2012,7 +2012,18 @@ int frcnn_cnet_backward(frcnn_model* m, const float* weights, const float* g_bbo
       FR_TRY(gemm_f32(L.g.f(), L.n, 1, w + L.w_off, L.in, 1, gin, L.in, R, L.in, L.n, OUT_STORE, nullptr, s, 0, gdefer));
     }
     // beside it: the weight gradient (planes in the transposed orientation) and the bias sums
-    if (xw) {
+    static const bool wgrad_f16 = !(getenv("FRCNN_GEMM_WGRAD_F16") && atoi(getenv("FRCNN_GEMM_WGRAD_F16")) == 0);
+    if (xw && wgrad_f16 && gemm_f16_on() && L.am.bytes >= (size_t)5 * AMAX_REC * 4) {
+      // two fp16 planes per operand here too (round 6; three products instead of six): both tensors' magnitudes are taken on this
+      // stream (records 3 and 4 of the layer: the weight-gradient stream forked before the chain took its own)
+      float *rgT = L.am.f() + 3 * AMAX_REC, *rxT = L.am.f() + 4 * AMAX_REC;
+      FR_TRY(tensor_absmax(L.g.f(), (long)R * L.n, rgT, ws));
+      if ((L.x_form & 1) && L.am_w_of == w) rxT = L.am.f();   // (this step's forward pass took the input's magnitude for its own planes)
+      else FR_TRY(tensor_absmax(in, (long)R * L.in, rxT, ws));
+      FR_TRY(split_planes(L.g.f(), R, L.n, nullptr, L.gpT.p, ws, rgT));
+      FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, ws, rxT));
+      FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, ws, wslot, rgT, rxT));
+    } else if (xw) {
       FR_TRY(split_planes(L.g.f(), R, L.n, nullptr, L.gpT.p, ws));
       FR_TRY(split_planes(in, R, L.in, nullptr, L.xpT.p, ws));
       FR_TRY(linear_x_wgrad(L.gpT.p, L.xpT.p, R, L.n, L.in, grad + L.w_off, ws, wslot));
