@@ -374,7 +374,9 @@ int frcnn_pnet_wait_block_gradients(frcnn_model *, int block, void *stream);
  * on the UPDATE STREAM as each slice becomes final, and frcnn_model_update_join before anything reads the weights again.  The
  * result is bit-identical to frcnn_scale_rmsprop on the whole vector (same arithmetic per element, tests/test_gpu_eager.py).
  *   frcnn_model_update_stream : the library-owned stream for this work (the one the classification net's weight gradients
- *                               run on: a slice update queued there is ordered behind them by itself)
+ *                               run on: a slice update queued there is ordered behind them by itself).  Call it BEFORE the pass
+ *                               whose slices are to be updated: from then on the passes record the events the waits below
+ *                               need (each a marker on the caller's stream, which a host that never asks does not pay for)
  *   frcnn_model_update_fork   : the update stream waits for everything queued on `stream` so far (the last readers of the
  *                               weights about to change, e.g. cnet:backward's input-gradient chain)
  *   frcnn_model_update_join   : `stream` waits for everything queued on the update stream so far
